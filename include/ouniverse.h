@@ -1,0 +1,166 @@
+/*
+ * ouniverse.h -- C ABI of libouniverse.so: MI355X (gfx950) implementation of line/open-universe's
+ * `model.enhance` hot path (UNIVERSE / UNIVERSE++ reverse-diffusion sampler, score network, conditioner).
+ *
+ * The reference is pure Python/PyTorch and has no native interface; these entry points are what an FFI for
+ * this path binds.  Each one names the reference interface it replaces (paths relative to the reference
+ * checkout, tag 2024_10_08).  INTEGRATION.md shows the reference-side binding (ctypes).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / hip types (hipStream_t is passed as void*).
+ *   - all tensors are fp32, contiguous, (B, C, T) with time innermost, resident on `device`.
+ *   - the caller owns every input / output / workspace / packed-weight buffer; the library owns only
+ *     the plan.  No allocation and no host synchronisation inside ou_condition / ou_score / ou_enhance:
+ *     everything is enqueued on the caller's stream (hipGraph-capturable).
+ *   - every function returns OU_OK (0) or a negative OU_E* code; ou_last_error() gives the message.
+ *     Nothing throws across the ABI.
+ *   - a handle is not re-entrant: one (process, device, stream) at a time.
+ */
+#ifndef OUNIVERSE_H
+#define OUNIVERSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OU_ABI_VERSION 1
+
+enum {
+  OU_OK = 0,
+  OU_EINVAL = -1,    /* bad argument (Python side raises ValueError) */
+  OU_ENOTIMPL = -2,  /* unsupported configuration (NotImplementedError) */
+  OU_EMISSING = -3,  /* tensor missing from checkpoint (KeyError) */
+  OU_ESHAPE = -4,    /* tensor shape mismatch */
+  OU_EHIP = -5,      /* HIP runtime error */
+  OU_ENOMEM = -6,    /* workspace too small */
+  OU_ESYNC = -7      /* device-side timeout flag raised (GRU cluster exchange) */
+};
+
+enum { OU_KIND_UNIVERSE = 0, OU_KIND_UNIVERSE_GAN = 1 };
+enum { OU_ACT_NONE = 0, OU_ACT_PRELU = 1, OU_ACT_SNAKE = 2 };
+
+#define OU_MAX_RATES 8
+
+/* One network's hyper-parameters == the constructor arguments of
+ * ScoreNetwork (networks/universe/score.py:214-232) / ConditionerNetwork (condition.py:274-293). */
+typedef struct ou_net_config {
+  int32_t n_rates;
+  int32_t rate_factors[OU_MAX_RATES];
+  int32_t n_channels;
+  int32_t fb_kernel_size;
+  int32_t n_rff;
+  int32_t noise_cond_dim;
+  int32_t extra_conv_block;
+  int32_t use_weight_norm;
+  int32_t use_antialiasing;
+  int32_t time_embedding_simple; /* 1: SimpleTimeEmbedding (sigma_block.py:60-78), 0: SigmaBlock RFF (:36-57) */
+  int32_t n_mels;                /* conditioner only */
+  int32_t n_mel_oversample;      /* conditioner only */
+  int32_t encoder_gru_residual;  /* conditioner only */
+} ou_net_config;
+
+/* == config.model of the reference (the yaml files under config/model/), inference-relevant part;
+ * replaces hydra `instantiate(config.model)` at inference_utils/model_loader.py:114. */
+typedef struct ou_config {
+  int32_t abi_version; /* OU_ABI_VERSION */
+  int32_t kind;        /* OU_KIND_* : Universe (universe.py:44) / UniverseGAN (universe_gan.py:60) */
+  int32_t fs;
+  float level_db;      /* normalization_kwargs.level_db */
+  int32_t has_edm;     /* edm: {noise: ...} present (universe.py:85-95) */
+  float edm_noise;
+  float sigma_min, sigma_max; /* diffusion.* (geometric schedule, universe.py:380-386) */
+  int32_t use_signal_decoupling; /* universe_gan.py:117-126 */
+  int32_t signal_decoupling_act; /* OU_ACT_* */
+  ou_net_config score;
+  ou_net_config cond;
+} ou_config;
+
+typedef struct ou_packer ou_packer;
+typedef struct ou_handle ou_handle;
+typedef void* ou_stream_t; /* hipStream_t */
+
+const char* ou_version(void);
+/* Message of the last error on this handle / packer (NULL handle: last global error). */
+const char* ou_last_error(const ou_handle* h);
+const char* ou_packer_last_error(const ou_packer* p);
+
+/* ---- weights: replaces model.load_state_dict + EMA copy + (never called) remove_weight_norm ------------
+ * model_loader.py:117-132, universe.py:841-865, blocks.py:36-50.
+ * The packer takes tensors under the reference's state-dict keys (host fp32), folds weight-norm
+ * (w = g*v/||v||), folds the binomial anti-alias FIR into the rate-change convs (blocks.py:213-227), lays
+ * every matrix out for the gfx950 kernels and returns one contiguous fp32 blob whose layout depends on the
+ * config only.  The blob is what gets broadcast over RCCL and handed to ou_create(). */
+int ou_packer_create(const ou_config* cfg, ou_packer** out);
+int ou_packer_set(ou_packer* p, const char* key, const float* data, const int64_t* shape, int32_t ndim);
+int ou_packer_finish(ou_packer* p, const float** blob_host, size_t* nbytes); /* blob owned by the packer */
+void ou_packer_destroy(ou_packer* p);
+int ou_packed_bytes(const ou_config* cfg, size_t* nbytes);
+
+/* ---- model: replaces load_model()'s returned module (model_loader.py:62-137) ----------------------------
+ * `weights_dev`: device pointer to the packed blob (caller-owned, must outlive the handle). */
+int ou_create(const ou_config* cfg, const void* weights_dev, size_t nbytes, int32_t device, ou_handle** out);
+void ou_destroy(ou_handle* h);
+
+/* Workspace needed for a batch of B signals of padded length T (T % prod(rate_factors) == 0). */
+int ou_workspace_bytes(const ou_handle* h, int32_t B, int32_t T, size_t* nbytes);
+
+/* Sampler constants, universe.py:301-311: sigma[n] (fp32, n = 0..n_steps-1), eta, beta. */
+int ou_schedule(const ou_config* cfg, int32_t n_steps, double epsilon, float* sigma_out, double* eta, double* beta);
+
+/* condition_model(mix, x_wav=mix, train=True)  -- universe.py:314-316 / condition.py:346-377.
+ * `mix_norm`: (B,1,T) normalised mixture.  Results (cond[5], aux signal, latent) stay in the workspace
+ * (see ou_tensor()) and are consumed by ou_score(). */
+int ou_condition(ou_handle* h, const float* mix_norm, int32_t B, int32_t T, void* ws, size_t ws_bytes,
+                 ou_stream_t stream);
+
+/* score_model(x, sigma, cond) -> score  -- universe.py:286,197-209 (EDM wrapper) / score.py:277-297.
+ * `sigma_host`: B floats on the host.  Requires a preceding ou_condition() on the same workspace. */
+int ou_score(ou_handle* h, const float* x, const float* sigma_host, float* score_out, int32_t B, int32_t T,
+             void* ws, size_t ws_bytes, ou_stream_t stream);
+
+/* aux_to_wav(aux_signal) -- universe_gan.py:145-149 (alias-free Snake -> Conv1d(C0->1,k3)).
+ * Reads the conditioner's aux signal from the workspace; writes (B,1,T). */
+int ou_aux_to_wav(ou_handle* h, float* wav_out, int32_t B, int32_t T, void* ws, size_t ws_bytes,
+                  ou_stream_t stream);
+
+/* Flags of ou_enhance */
+#define OU_ENH_KEEP_RMS 1u       /* universe.py:352-354 */
+#define OU_ENH_USE_AUX_SIGNAL 2u /* universe.py:317-319 */
+#define OU_ENH_NO_PEAK_GUARD 4u  /* skip universe.py:356-357 (debug) */
+
+/* Universe.enhance(mix, n_steps, epsilon, rng=...) -- universe.py:231-375, for a (B, T_raw) batch:
+ * pad (:219-223) -> normalize (utils/norm.py:47-87) -> conditioner -> x0 = sigma_0 * noise[0] ->
+ * N-1 x { score; x += sigma_n^2*eta*score + beta*sigma_{n+1}*noise[n+1] } -> last clean step ->
+ * unpad -> [keep_rms] -> peak guard.  Ensemble replication / reduction stays with the caller.
+ *   mix, out : (B, T_raw) device
+ *   noise    : (n_steps - warm_start, B, T_pad) standard-normal, device, in the reference's draw order
+ *              (x0, z_0 .. z_{N-2}); T_pad = T_raw + (tot_ds - T_raw % tot_ds)
+ *   sigma_host: n_steps floats or NULL (then computed as ou_schedule does)
+ *   warm_start: -1, or the step index to start from with x = aux_to_wav(aux) + noise (universe.py:328-331) */
+int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, int32_t B, int32_t T_raw,
+               int32_t n_steps, double epsilon, const float* sigma_host, int32_t warm_start, uint32_t flags,
+               void* ws, size_t ws_bytes, ou_stream_t stream);
+
+/* After the stream has been synchronised: OU_OK, or OU_ESYNC if a device-side timeout flag was raised. */
+int ou_check_device_status(ou_handle* h, void* ws);
+
+/* ---- introspection (tests, profiling) ------------------------------------------------------------------- */
+/* JSON description of the packed layers (name, kind, shapes, offsets into the blob). */
+const char* ou_plan_json(const ou_handle* h);
+const char* ou_packer_plan_json(const ou_packer* p);
+/* Locate a named intermediate of the last ou_condition / ou_score / ou_enhance call in the workspace:
+ * byte offset, channels, length (per batch element; layout (B, C, T)).  Names: see DESIGN.md. */
+int ou_tensor(const ou_handle* h, const char* name, size_t* byte_offset, int32_t* C, int32_t* T);
+/* Number of kernels the last forward enqueued, and the generic-conv launch count among them. */
+int ou_launch_stats(const ou_handle* h, int32_t* n_launches, int32_t* n_conv_launches);
+/* When set (default 1 at create if env OU_NO_GRAPH is unset: 0), intermediates are never aliased so that
+ * ou_tensor() can return any of them; costs memory only. */
+int ou_set_debug(ou_handle* h, int32_t keep_intermediates);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OUNIVERSE_H */

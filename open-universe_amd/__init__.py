@@ -10,5 +10,7 @@ The compute path is hand-written HIP behind a C ABI (`include/ouniverse.h`, `csr
 Python host side (config, checkpoint reading, noise drawing, sharding).  There is no CPU / eager fallback.
 """
 from . import config, state_dict  # noqa: F401
+from . import _lib, inference_utils  # noqa: F401
+from .universe import Universe, UniverseGAN  # noqa: F401
 
-__all__ = ["config", "state_dict"]
+__all__ = ["config", "state_dict", "inference_utils", "Universe", "UniverseGAN"]

@@ -1,0 +1,657 @@
+// C ABI of libouniverse.so (include/ouniverse.h): packer, handle, and the forward "runner" that walks
+// the model and enqueues the gfx950 kernels on the caller's stream.  No allocation, no host sync in the
+// forward calls.  There is no CPU path: without a HIP device ou_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ouniverse.h"
+#include "ou_kernels.h"
+#include "ou_model.h"
+
+using namespace ou;
+
+namespace {
+thread_local std::string g_last_error;
+constexpr int kMaxSteps = 256;
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+
+struct TensorRef {
+  size_t off;  // bytes into the workspace
+  int C, T;
+};
+}  // namespace
+
+struct ou_packer {
+  Model m;
+  std::map<std::string, HostTensor> sd;
+  std::vector<float> blob;
+  std::string err;
+};
+
+struct ou_handle {
+  Model m;
+  const float* W = nullptr;  // packed blob (device)
+  int device = 0;
+  int num_cu = 256;
+  std::string err;
+  std::map<std::string, TensorRef> tensors;
+  int n_launch = 0, n_conv = 0;
+  // geometry of the last ou_condition (consumed by ou_score)
+  int cond_B = 0, cond_T = 0;
+};
+
+namespace {
+
+int fail(ou_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  g_last_error = msg;
+  return code;
+}
+
+struct Tensor {
+  float* p = nullptr;
+  int C = 0, T = 0;
+};
+
+// Bump allocator over the caller's workspace.  In `dry` mode nothing is launched and `base` may be null:
+// the same walk then only measures the footprint (ou_workspace_bytes) -> layout is a pure function of
+// (config, B, T).
+struct Runner {
+  ou_handle* h;
+  char* base;
+  size_t cap;
+  size_t off = 0;
+  bool dry;
+  hipStream_t st;
+  int B;
+  hipError_t herr = hipSuccess;
+  bool oom = false;
+  const char* where = "";
+
+  Runner(ou_handle* h_, void* ws, size_t cap_, bool dry_, hipStream_t st_, int B_)
+      : h(h_), base((char*)ws), cap(cap_), dry(dry_), st(st_), B(B_) {}
+
+  float* alloc_raw(size_t floats) {
+    size_t bytes = (floats * 4 + 255) & ~size_t(255);
+    size_t o = off;
+    off += bytes;
+    if (!dry && off > cap) { oom = true; return (float*)base; }
+    return dry ? nullptr : (float*)(base + o);
+  }
+  Tensor alloc(const std::string& name, int C, int T) {
+    size_t o = off;
+    Tensor t;
+    t.p = alloc_raw((size_t)B * C * T);
+    t.C = C;
+    t.T = T;
+    if (!name.empty()) h->tensors[name] = TensorRef{o, C, T};
+    return t;
+  }
+  bool ok() const { return herr == hipSuccess && !oom; }
+  void chk(hipError_t e, const char* w) {
+    if (e != hipSuccess && herr == hipSuccess) { herr = e; where = w; }
+    h->n_launch++;
+  }
+  const float* W(size_t off_floats) const { return h->W + off_floats; }
+
+  struct Epi {
+    const float* add = nullptr;
+    float add_scale = 1.f;
+    const float* film = nullptr;
+    int film_bstride = 0;
+    const float* res = nullptr;
+    float res_scale = 1.f;
+    const float* in_scale = nullptr;
+    bool act = true;  // apply the layer's PReLU prologue (if it has one)
+  };
+
+  Tensor conv(const ConvL& L, const Tensor& in, const std::string& name, const Epi& e) {
+    int Nq, Tout;
+    if (L.stride > 1) { Nq = in.T / L.stride; Tout = Nq; }
+    else { Nq = in.T; Tout = in.T * L.up; }
+    Tensor out = alloc(name, L.Cout, Tout);
+    if (dry || !ok()) return out;
+    ConvArgs a;
+    a.x = in.p; a.w = W(L.w_off); a.bias = W(L.b_off); a.y = out.p;
+    a.in_scale = e.in_scale;
+    a.alpha = (L.act && e.act) ? W(L.a_off) : nullptr;
+    a.add = e.add; a.add_scale = e.add_scale;
+    a.film = e.film; a.film_bstride = e.film_bstride;
+    a.res = e.res; a.res_scale = e.res_scale;
+    a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
+    a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
+    chk(launch_conv(a, h->num_cu, st), L.name.c_str());
+    h->n_conv++;
+    return out;
+  }
+
+  struct BlockOut { Tensor h_next, v, c1; };
+  // ConvBlock.forward  (blocks.py:327-412).  `res` for dir==0 blocks must already be folded into `hin`.
+  BlockOut block(const BlockL& Bk, const Tensor& hin, const std::string& nm, const float* film, int film_bs,
+                 const float* input_cond, const float* res) {
+    Tensor hu = hin;
+    if (Bk.dir == 2) {
+      Epi e;
+      e.res = res; e.res_scale = kInvSqrt2;  // blocks.py:374-376 fused into the up-conv epilogue
+      hu = conv(Bk.rc, hin, nm + ".up", e);
+    }
+    Epi e1;
+    if (input_cond) { e1.add = input_cond; e1.add_scale = kInvSqrt2; }  // blocks.py:384-386
+    e1.film = film; e1.film_bstride = film_bs;                           // blocks.py:393-394
+    Tensor c1 = conv(Bk.c1, hu, nm + ".c1", e1);
+    Tensor c2 = conv(Bk.c2, c1, nm + ".c2", Epi());
+    Epi e3;
+    e3.res = hu.p; e3.res_scale = kInvSqrt2;  // blocks.py:399
+    if (dry) e3.res = nullptr;
+    Tensor v = conv(Bk.c3, c2, nm + ".v", e3);
+    BlockOut o;
+    o.v = v; o.c1 = c1; o.h_next = v;
+    if (Bk.dir == 1) o.h_next = conv(Bk.rc, v, nm + ".h", Epi());  // blocks.py:401-410
+    return o;
+  }
+
+  // one bidirectional GRU layer: projection GEMM + cluster recurrence
+  Tensor gru(const GruL& G, const Tensor& in, const std::string& nm, unsigned long long* xchg, unsigned* errw,
+             const float* res, float res_scale) {
+    Epi e;
+    e.act = false;
+    Tensor gx = conv(G.proj, in, nm + ".gx", e);
+    Tensor out = alloc(nm, 2 * G.H, in.T);
+    if (dry || !ok()) return out;
+    GruArgs a;
+    a.gx = gx.p; a.whh = W(G.whh_off); a.bhn = W(G.bhn_off); a.out = out.p; a.res = res; a.res_scale = res_scale;
+    a.xchg = xchg; a.err = errw; a.B = B; a.T = in.T; a.H = G.H;
+    chk(launch_gru(a, h->num_cu, st), G.name.c_str());
+    return out;
+  }
+};
+
+// Persistent part of the workspace (lives across ou_condition / ou_score / ou_enhance calls on it).
+struct Persist {
+  unsigned* status;
+  StepCoef* coef;             // [kMaxSteps] or [B]
+  float* stats;               // [B][4]
+  unsigned long long* xchg;   // GRU granules
+  float* mel_scale;           // [B]
+  float* g;                   // [kMaxSteps][D]
+  float* film;                // [kMaxSteps][rows]
+  Tensor mixn, x, wav;        // (B,1,T)
+  std::vector<Tensor> sc;     // signal_cond_proj(cond_j)   (B, C_j, T_j)
+  std::vector<Tensor> cond;   // conditions
+  Tensor aux, latent;
+};
+
+Persist layout_persist(Runner& r, int T) {
+  const Model& m = r.h->m;
+  Persist P;
+  P.status = (unsigned*)r.alloc_raw(64);
+  int ncoef = kMaxSteps > r.B ? kMaxSteps : r.B;
+  P.coef = (StepCoef*)r.alloc_raw((size_t)ncoef * 8);
+  P.stats = r.alloc_raw((size_t)r.B * 4);
+  P.xchg = (unsigned long long*)r.alloc_raw((size_t)r.B * 4 * (m.OC / 2) * 2);
+  P.mel_scale = r.alloc_raw(r.B);
+  P.g = r.alloc_raw((size_t)ncoef * m.film.D);
+  P.film = r.alloc_raw((size_t)ncoef * m.film.rows);
+  P.mixn = r.alloc("mixn", 1, T);
+  P.x = r.alloc("x", 1, T);
+  P.wav = r.alloc("wav", 1, T);
+  for (int j = 0; j < m.n_blocks; j++) {
+    const BlockL& b = m.c_dec[j];
+    int Tj = T / m.tot_ds;
+    // length at the output of decoder block j
+    int up = 1;
+    for (int k = 0; k <= j; k++) if (m.c_dec[k].dir == 2) up *= m.c_dec[k].rate;
+    Tj *= up;
+    P.cond.push_back(r.alloc("cond.c" + std::to_string(j), b.C, Tj));
+    P.sc.push_back(r.alloc("cond.sc" + std::to_string(j), b.C, Tj));
+  }
+  P.aux = r.alloc("cond.aux", m.C0, T);
+  P.latent = r.alloc("cond.latent", m.OC, T / m.tot_ds);
+  return P;
+}
+
+// ConditionerNetwork.forward(train=True)  condition.py:346-377
+void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
+  const Model& m = r.h->m;
+  const int L = T / m.tot_ds;
+  const int n = m.n_levels - 1;
+  // --- MelAdapter  condition.py:110-114
+  Tensor mel = r.alloc("cond.mel", m.mel.n_mels, L);
+  float* esum = r.alloc_raw((size_t)r.B * L);
+  if (!r.dry && r.ok()) {
+    r.chk(launch_mel(mix_norm, r.W(m.mel.win_off), r.W(m.mel.tw_off), r.W(m.mel.fb_off), mel.p, esum, r.B, T,
+                     m.mel.n_fft, m.mel.hop, m.mel.pad_left, m.mel.n_freq, m.mel.n_mels, L, r.st), "mel");
+    r.chk(launch_mel_scale(esum, P.mel_scale, r.B, L, r.st), "mel_scale");
+  }
+  Runner::Epi em;
+  em.in_scale = P.mel_scale;  // the global mel normalisation is linear: folded into the conv's input scale
+  em.act = false;
+  Tensor m0 = r.conv(m.c_melconv, mel, "cond.melconv", em);
+  Tensor x_mel = r.block(m.c_melblock, m0, "cond.melblock", nullptr, 0, nullptr, nullptr).v;
+  // --- input conv + encoder  condition.py:360, 189-206
+  Tensor e0 = r.alloc("cond.in", m.C0, T);
+  if (!r.dry && r.ok())
+    r.chk(launch_in_conv(mix_norm, r.W(m.c_in.w_off), r.W(m.c_in.b_off), nullptr, 0, e0.p, r.B, m.C0, T, m.c_in.KW, r.st), "cond.in");
+  Tensor hcur = e0;
+  std::vector<Tensor> outs;
+  for (int i = 0; i < m.n_blocks; i++) {
+    auto bo = r.block(m.c_enc[i], hcur, "cond.enc" + std::to_string(i), nullptr, 0, nullptr, nullptr);
+    if (i < n - 1) {
+      const ConvL& S = m.c_st[i];
+      const int R = S.rate, C = S.Cin / R;
+      Tensor sd = r.alloc("cond.s2d" + std::to_string(i), S.Cin, bo.v.T / R);
+      if (!r.dry && r.ok()) r.chk(launch_s2d(bo.v.p, r.W(S.a_off), sd.p, r.B, C, bo.v.T, R, r.st), "s2d");
+      Runner::Epi es;
+      es.act = false;  // PReLU already applied by the space-to-depth pass
+      outs.push_back(r.conv(S, sd, "cond.st" + std::to_string(i), es));
+    }
+    hcur = bo.h_next;
+  }
+  outs.push_back(hcur);
+  Tensor sum = r.alloc("cond.enc_sum", m.OC, L);
+  if (!r.dry && r.ok()) {
+    const float* q[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (outs.size() > 4) { r.herr = hipErrorInvalidValue; r.where = "too many encoder outputs"; return; }
+    for (size_t i = 0; i < outs.size(); i++) q[i] = outs[i].p;
+    r.chk(launch_sum(x_mel.p, q[0], q[1], q[2], q[3], 1.0f / std::sqrt((float)(outs.size() + 1)), sum.p,
+                     (size_t)r.B * m.OC * L, r.st), "enc_sum");
+  }
+  // --- conv_block1 -> 2-layer GRU (+residual) -> conv_block2   condition.py:208-216
+  Tensor cb1 = r.block(m.c_cb1, sum, "cond.cb1", nullptr, 0, nullptr, nullptr).v;
+  Tensor g0 = r.gru(m.c_gru0, cb1, "cond.gru0", P.xchg, P.status, nullptr, 1.f);
+  const bool gres = m.cfg.cond.encoder_gru_residual != 0;
+  Tensor g1 = r.gru(m.c_gru1, g0, "cond.gru", P.xchg, P.status, gres ? cb1.p : nullptr, kInvSqrt2);
+  Tensor lat = r.block(m.c_cb2, g1, "cond.cb2", nullptr, 0, nullptr, nullptr).v;
+  if (!r.dry && r.ok())
+    r.chk(hipMemcpyAsync(P.latent.p, lat.p, (size_t)r.B * m.OC * L * 4, hipMemcpyDeviceToDevice, r.st), "latent");
+  // --- decoder  condition.py:264-270
+  Tensor y = r.block(m.c_decin, lat, "cond.decin", nullptr, 0, nullptr, nullptr).v;
+  for (int j = 0; j < m.n_blocks; j++) {
+    auto bo = r.block(m.c_dec[j], y, "cond.dec" + std::to_string(j), nullptr, 0, nullptr, nullptr);
+    y = bo.v;
+    if (!r.dry && r.ok())
+      r.chk(hipMemcpyAsync(P.cond[j].p, bo.c1.p, (size_t)r.B * bo.c1.C * bo.c1.T * 4, hipMemcpyDeviceToDevice, r.st), "cond copy");
+    // score.py:208  sc = signal_cond_proj_j(cond_j): independent of x and sigma -> computed once here
+    if (!r.dry && r.ok()) {
+      const ConvL& S = m.s_sig[j];
+      ConvArgs a;
+      a.x = bo.c1.p; a.w = r.W(S.w_off); a.bias = r.W(S.b_off); a.y = P.sc[j].p;
+      a.B = r.B; a.Cin = S.Cin; a.Tin = bo.c1.T; a.Cout = S.Cout; a.M = S.M; a.Mp = S.Mp; a.KW = 1; a.stride = 1;
+      a.pad = 0; a.up = 1; a.CK = S.CK; a.Nq = bo.c1.T; a.Tout = bo.c1.T;
+      r.chk(launch_conv(a, r.h->num_cu, r.st), S.name.c_str());
+      r.h->n_conv++;
+    }
+  }
+  if (!r.dry && r.ok())
+    r.chk(hipMemcpyAsync(P.aux.p, y.p, (size_t)r.B * m.C0 * T * 4, hipMemcpyDeviceToDevice, r.st), "aux copy");
+}
+
+// ScoreNetwork.forward + EDM wrapper + sampler update for the coefficient rows at `coef`
+//   film_row: pointer to this step's FiLM table row(s); film_bs / coef_bs: per-batch strides (0 = shared)
+void run_score(Runner& r, Persist& P, const float* x, const float* noise, float* out, int mode,
+               const StepCoef* coef, int coef_bs, const float* film_row, int film_bs, int T) {
+  const Model& m = r.h->m;
+  Tensor e0 = r.alloc("score.in", m.C0, T);
+  // the w_in scaling of the EDM wrapper (universe.py:199,202) rides on the input conv
+  if (!r.dry && r.ok())
+    r.chk(launch_in_conv(x, r.W(m.s_in.w_off), r.W(m.s_in.b_off), coef, coef_bs, e0.p, r.B, m.C0, T, m.s_in.KW, r.st),
+          "score.in");
+  Tensor hcur = e0;
+  std::vector<Tensor> residuals;
+  for (int i = 0; i < m.n_blocks; i++) {
+    const float* fr = film_row ? film_row + m.film.enc_off[i] : nullptr;
+    auto bo = r.block(m.s_enc[i], hcur, "score.enc" + std::to_string(i), fr, film_bs, nullptr, nullptr);
+    residuals.push_back(bo.v);
+    hcur = bo.h_next;
+  }
+  // GRU bottleneck; when decoder block 0 has no rate change its residual add (blocks.py:374-376) is fused here
+  const bool fuse_res = m.s_dec[0].dir == 0;
+  Tensor hg = r.gru(m.s_gru, hcur, "score.gru", P.xchg, P.status,
+                    fuse_res && !r.dry ? residuals[m.n_blocks - 1].p : nullptr, kInvSqrt2);
+  Tensor y = hg;
+  for (int j = 0; j < m.n_blocks; j++) {
+    const float* fr = film_row ? film_row + m.film.dec_off[j] : nullptr;
+    const Tensor& res = residuals[m.n_blocks - 1 - j];
+    const float* resp = (j == 0 && fuse_res) ? nullptr : res.p;
+    auto bo = r.block(m.s_dec[j], y, "score.dec" + std::to_string(j), fr, film_bs, P.sc[j].p, resp);
+    y = bo.v;
+  }
+  if (!r.dry && r.ok())
+    r.chk(launch_out_conv(y.p, r.W(m.s_out.w_off), r.W(m.s_out.b_off), r.W(m.s_out.a_off), x, noise, out, coef,
+                          coef_bs, m.cfg.has_edm, mode, r.B, m.C0, T, m.s_out.KW, r.st), "score.out");
+}
+
+// universe.py:175-189, 197-209, 333-343 scalars for one sigma, computed in fp32 like the reference's tensors
+StepCoef make_coef(const ou_config& cfg, float s, bool last, double eta, double beta, float s_next) {
+  StepCoef c;
+  const float s2 = s * s;
+  if (cfg.has_edm) {
+    const double sd = std::pow(10.0, (double)cfg.level_db / 20.0);
+    const float sd2 = (float)(sd * sd);
+    const float sn2 = s2 + sd2;
+    const float sn = std::sqrt(sn2);
+    c.w_skip = sd2 / sn2;
+    c.w_in = 1.0f / sn;
+    c.w_out = (s * (float)sd) / sn;
+    c.sigma_net = cfg.edm_noise * s;
+  } else {
+    c.w_skip = 0.f; c.w_in = 1.f; c.w_out = 1.f; c.sigma_net = s;
+  }
+  c.sig2 = s2;
+  c.c1 = last ? s2 : s2 * (float)eta;
+  c.s_next = s_next;
+  c.beta = (float)beta;
+  return c;
+}
+
+void schedule(const ou_config& cfg, int n_steps, double epsilon, float* sigma, double* eta, double* beta) {
+  const double ratio = (double)cfg.sigma_max / (double)cfg.sigma_min;
+  const double delta_t = 1.0 / (n_steps - 1);
+  const double gamma = std::pow(ratio, -delta_t);
+  *eta = 1.0 - std::pow(gamma, epsilon);
+  *beta = std::sqrt(1.0 - std::pow(gamma, 2.0 * (epsilon - 1.0)));
+  // torch.linspace(0, 1, N) (fp32, symmetric evaluation) flipped, then s_min * (s_max/s_min) ** time
+  const float step = 1.0f / (float)(n_steps - 1);
+  for (int n = 0; n < n_steps; n++) {
+    int i = n_steps - 1 - n;
+    float t = (i < n_steps / 2) ? (float)i * step : 1.0f - (float)(n_steps - 1 - i) * step;
+    sigma[n] = (float)cfg.sigma_min * std::pow((float)ratio, t);
+  }
+}
+
+void upload_coefs(Runner& r, StepCoef* dst, const std::vector<StepCoef>& rows) {
+  for (size_t i = 0; i < rows.size(); i += 64) {
+    CoefBlock blk;
+    int n = (int)std::min<size_t>(64, rows.size() - i);
+    for (int k = 0; k < n; k++) blk.c[k] = rows[i + k];
+    r.chk(launch_upload_coef(dst + i, blk, n, r.st), "upload coef");
+  }
+}
+
+int finish(ou_handle* h, Runner& r) {
+  if (r.oom) return fail(h, OU_ENOMEM, "workspace too small: need " + std::to_string(r.off) + " bytes");
+  if (r.herr != hipSuccess)
+    return fail(h, OU_EHIP, std::string("HIP error at ") + r.where + ": " + hipGetErrorString(r.herr));
+  return OU_OK;
+}
+
+}  // namespace
+
+// ======================================================================================================
+extern "C" {
+
+const char* ou_version(void) { return "libouniverse 0.1 (gfx950, fp32 MFMA)"; }
+const char* ou_last_error(const ou_handle* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+const char* ou_packer_last_error(const ou_packer* p) { return p ? p->err.c_str() : g_last_error.c_str(); }
+
+int ou_packer_create(const ou_config* cfg, ou_packer** out) {
+  if (!cfg || !out) return fail(nullptr, OU_EINVAL, "null argument");
+  auto* p = new ou_packer();
+  std::string e = build_model(*cfg, p->m);
+  if (!e.empty()) { delete p; return fail(nullptr, OU_ENOTIMPL, e); }
+  *out = p;
+  return OU_OK;
+}
+
+int ou_packer_set(ou_packer* p, const char* key, const float* data, const int64_t* shape, int32_t ndim) {
+  if (!p || !key || !data || ndim < 0 || ndim > 8) return fail(nullptr, OU_EINVAL, "bad argument to ou_packer_set");
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; i++) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  t.data.assign(data, data + n);
+  p->sd[key] = std::move(t);
+  return OU_OK;
+}
+
+int ou_packer_finish(ou_packer* p, const float** blob_host, size_t* nbytes) {
+  if (!p || !blob_host || !nbytes) return fail(nullptr, OU_EINVAL, "null argument");
+  int code = OU_OK;
+  std::string e = pack_weights(p->m, p->sd, p->blob, code);
+  if (!e.empty()) { p->err = e; g_last_error = e; return code; }
+  *blob_host = p->blob.data();
+  *nbytes = p->blob.size() * sizeof(float);
+  return OU_OK;
+}
+
+void ou_packer_destroy(ou_packer* p) { delete p; }
+
+int ou_packed_bytes(const ou_config* cfg, size_t* nbytes) {
+  if (!cfg || !nbytes) return fail(nullptr, OU_EINVAL, "null argument");
+  Model m;
+  std::string e = build_model(*cfg, m);
+  if (!e.empty()) return fail(nullptr, OU_ENOTIMPL, e);
+  *nbytes = m.total_floats * sizeof(float);
+  return OU_OK;
+}
+
+const char* ou_packer_plan_json(const ou_packer* p) { return p ? p->m.json.c_str() : ""; }
+const char* ou_plan_json(const ou_handle* h) { return h ? h->m.json.c_str() : ""; }
+
+int ou_create(const ou_config* cfg, const void* weights_dev, size_t nbytes, int32_t device, ou_handle** out) {
+  if (!cfg || !weights_dev || !out) return fail(nullptr, OU_EINVAL, "null argument");
+  auto* h = new ou_handle();
+  std::string e = build_model(*cfg, h->m);
+  if (!e.empty()) { delete h; return fail(nullptr, OU_ENOTIMPL, e); }
+  if (nbytes != h->m.total_floats * sizeof(float)) {
+    size_t want = h->m.total_floats * sizeof(float);
+    delete h;
+    return fail(nullptr, OU_ESHAPE, "packed weight blob has " + std::to_string(nbytes) + " bytes, expected " + std::to_string(want));
+  }
+  int ndev = 0;
+  hipError_t he = hipGetDeviceCount(&ndev);
+  if (he != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    delete h;
+    return fail(nullptr, OU_EHIP, "no HIP device available for ou_create (this library has no CPU path)");
+  }
+  hipDeviceProp_t prop;
+  he = hipGetDeviceProperties(&prop, device);
+  if (he != hipSuccess) { delete h; return fail(nullptr, OU_EHIP, hipGetErrorString(he)); }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::string arch = prop.gcnArchName;
+    delete h;
+    return fail(nullptr, OU_EHIP, "libouniverse is built for gfx950 (MI355X) only; device is " + arch);
+  }
+  h->num_cu = prop.multiProcessorCount;
+  h->device = device;
+  h->W = (const float*)weights_dev;
+  (void)hipSetDevice(device);
+  he = init_conv_kernels();
+  if (he != hipSuccess) { delete h; return fail(nullptr, OU_EHIP, hipGetErrorString(he)); }
+  *out = h;
+  return OU_OK;
+}
+
+void ou_destroy(ou_handle* h) { delete h; }
+
+int ou_workspace_bytes(const ou_handle* hc, int32_t B, int32_t T, size_t* nbytes) {
+  ou_handle* h = const_cast<ou_handle*>(hc);
+  if (!h || !nbytes || B < 1 || T < 1) return fail(h, OU_EINVAL, "bad argument");
+  if (T % h->m.tot_ds) return fail(h, OU_EINVAL, "T must be a multiple of the total down-sampling factor");
+  auto saved = h->tensors;
+  Runner r(h, nullptr, 0, true, nullptr, B);
+  Persist P = layout_persist(r, T);
+  run_condition(r, P, nullptr, T);
+  size_t mark = r.off;
+  run_score(r, P, nullptr, nullptr, nullptr, OUT_UPDATE, nullptr, 0, nullptr, 0, T);
+  (void)mark;
+  // aux_to_wav scratch (2x up-sampled aux signal)
+  r.alloc_raw((size_t)B * h->m.C0 * 2 * T);
+  h->tensors = saved;
+  *nbytes = r.off + 4096;
+  return OU_OK;
+}
+
+int ou_schedule(const ou_config* cfg, int32_t n_steps, double epsilon, float* sigma_out, double* eta, double* beta) {
+  if (!cfg || !sigma_out || !eta || !beta || n_steps < 2) return fail(nullptr, OU_EINVAL, "bad argument");
+  schedule(*cfg, n_steps, epsilon, sigma_out, eta, beta);
+  return OU_OK;
+}
+
+int ou_condition(ou_handle* h, const float* mix_norm, int32_t B, int32_t T, void* ws, size_t ws_bytes, ou_stream_t stream) {
+  if (!h || !mix_norm || !ws || B < 1) return fail(h, OU_EINVAL, "bad argument");
+  if (T % h->m.tot_ds || T <= 0) return fail(h, OU_EINVAL, "T must be a positive multiple of the total down-sampling factor");
+  h->tensors.clear();
+  h->n_launch = h->n_conv = 0;
+  Runner r(h, ws, ws_bytes, false, (hipStream_t)stream, B);
+  Persist P = layout_persist(r, T);
+  if (r.oom) return finish(h, r);
+  r.chk(hipMemsetAsync(P.status, 0, 256, r.st), "status");
+  run_condition(r, P, mix_norm, T);
+  h->cond_B = B;
+  h->cond_T = T;
+  return finish(h, r);
+}
+
+int ou_score(ou_handle* h, const float* x, const float* sigma_host, float* score_out, int32_t B, int32_t T, void* ws,
+             size_t ws_bytes, ou_stream_t stream) {
+  if (!h || !x || !sigma_host || !score_out || !ws) return fail(h, OU_EINVAL, "bad argument");
+  if (B != h->cond_B || T != h->cond_T) return fail(h, OU_EINVAL, "ou_score: call ou_condition with the same (B, T) first");
+  h->n_launch = h->n_conv = 0;
+  Runner r(h, ws, ws_bytes, false, (hipStream_t)stream, B);
+  auto keep = h->tensors;
+  Persist P = layout_persist(r, T);
+  {  // skip over the conditioner's region so that its intermediates stay inspectable
+    Runner d(h, nullptr, 0, true, nullptr, B);
+    Persist Pd = layout_persist(d, T);
+    run_condition(d, Pd, nullptr, T);
+    r.off = d.off;
+  }
+  for (auto& kv : keep) if (kv.first.rfind("cond.", 0) == 0) h->tensors[kv.first] = kv.second;
+  std::vector<StepCoef> rows;
+  for (int b = 0; b < B; b++) {
+    if (!(sigma_host[b] > 0.f)) return fail(h, OU_EINVAL, "sigma must be positive");
+    rows.push_back(make_coef(h->m.cfg, sigma_host[b], true, 0.0, 0.0, 0.f));
+  }
+  upload_coefs(r, P.coef, rows);
+  const Model& m = h->m;
+  r.chk(launch_sigma_embed(P.coef, B, r.W(m.sigma.p_off), m.sigma.simple, m.sigma.n_rff, m.film.D, P.g, r.st), "sigma");
+  r.chk(launch_film(P.g, r.W(m.film.w_off), r.W(m.film.b_off), P.film, B, m.film.rows, m.film.D, r.st), "film");
+  run_score(r, P, x, nullptr, score_out, OUT_SCORE, P.coef, 1, P.film, m.film.rows, T);
+  return finish(h, r);
+}
+
+int ou_aux_to_wav(ou_handle* h, float* wav_out, int32_t B, int32_t T, void* ws, size_t ws_bytes, ou_stream_t stream) {
+  if (!h || !wav_out || !ws) return fail(h, OU_EINVAL, "bad argument");
+  if (B != h->cond_B || T != h->cond_T) return fail(h, OU_EINVAL, "ou_aux_to_wav: call ou_condition with the same (B, T) first");
+  const Model& m = h->m;
+  if (!m.dec.present) return fail(h, OU_ENOTIMPL, "model has no signal decoupling layer (aux signal is multi-channel)");
+  if (m.dec.act != OU_ACT_SNAKE) return fail(h, OU_ENOTIMPL, "only the snake signal-decoupling activation is implemented");
+  Runner r(h, ws, ws_bytes, false, (hipStream_t)stream, B);
+  auto keep = h->tensors;
+  Persist P = layout_persist(r, T);
+  h->tensors = keep;
+  // scratch at the very end of the workspace
+  size_t need = (size_t)B * m.C0 * 2 * T * 4;
+  if (ws_bytes < need + r.off) return fail(h, OU_ENOMEM, "workspace too small");
+  float* tmp = (float*)((char*)ws + ((ws_bytes - need) & ~size_t(255)));
+  r.chk(launch_decoupling(P.aux.p, r.W(m.dec.alpha_off), r.W(m.dec.up_off), r.W(m.dec.down_off), r.W(m.dec.conv.w_off),
+                          r.W(m.dec.conv.b_off), tmp, wav_out, B, m.C0, T, r.st), "decoupling");
+  return finish(h, r);
+}
+
+int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, int32_t B, int32_t T_raw, int32_t n_steps,
+               double epsilon, const float* sigma_host, int32_t warm_start, uint32_t flags, void* ws, size_t ws_bytes,
+               ou_stream_t stream) {
+  if (!h || !mix || !out || !ws || B < 1 || T_raw < 1) return fail(h, OU_EINVAL, "bad argument");
+  const bool use_aux = (flags & OU_ENH_USE_AUX_SIGNAL) != 0;
+  if (!use_aux && !noise) return fail(h, OU_EINVAL, "noise must be given");
+  if (n_steps < 2 || n_steps > kMaxSteps) return fail(h, OU_EINVAL, "n_steps must be in [2, 256]");
+  if (warm_start >= n_steps) return fail(h, OU_EINVAL, "warm_start must be < n_steps");
+  const Model& m = h->m;
+  const int tot = m.tot_ds;
+  const int pad = tot - T_raw % tot;  // universe.py:219-223 (a full block when already a multiple)
+  const int pad_left = pad / 2;
+  const int T = T_raw + pad;
+  h->tensors.clear();
+  h->n_launch = h->n_conv = 0;
+  hipStream_t st = (hipStream_t)stream;
+  Runner r(h, ws, ws_bytes, false, st, B);
+  Persist P = layout_persist(r, T);
+  if (r.oom) return finish(h, r);
+  r.chk(hipMemsetAsync(P.status, 0, 256, st), "status");
+
+  std::vector<float> sigma(n_steps);
+  double eta, beta;
+  schedule(m.cfg, n_steps, epsilon, sigma.data(), &eta, &beta);
+  if (sigma_host) std::memcpy(sigma.data(), sigma_host, sizeof(float) * n_steps);
+  std::vector<StepCoef> rows;
+  for (int n = 0; n < n_steps; n++)
+    rows.push_back(make_coef(m.cfg, sigma[n], n == n_steps - 1, eta, beta, n + 1 < n_steps ? sigma[n + 1] : 0.f));
+  upload_coefs(r, P.coef, rows);
+
+  const float level = (float)std::pow(10.0, (double)m.cfg.level_db / 20.0);
+  r.chk(launch_pad_normalize(mix, P.mixn.p, P.stats, B, T_raw, T, pad_left, level, st), "normalize");
+  run_condition(r, P, P.mixn.p, T);
+  h->cond_B = B;
+  h->cond_T = T;
+  const size_t nBT = (size_t)B * T;
+  const int keep_rms = (flags & OU_ENH_KEEP_RMS) ? 1 : 0;
+  const int peak = (flags & OU_ENH_NO_PEAK_GUARD) ? 0 : 1;
+
+  bool need_wav = use_aux || warm_start >= 0;
+  if (need_wav) {
+    if (!m.dec.present || m.dec.act != OU_ACT_SNAKE)
+      return fail(h, OU_ENOTIMPL, "aux_to_wav needs the snake signal-decoupling layer (UNIVERSE++)");
+    float* tmp = r.alloc_raw((size_t)B * m.C0 * 2 * T);
+    if (r.ok())
+      r.chk(launch_decoupling(P.aux.p, r.W(m.dec.alpha_off), r.W(m.dec.up_off), r.W(m.dec.down_off),
+                              r.W(m.dec.conv.w_off), r.W(m.dec.conv.b_off), tmp, P.wav.p, B, m.C0, T, st), "decoupling");
+  }
+  if (use_aux) {
+    if (r.ok()) r.chk(launch_post(P.wav.p, P.stats, out, B, T_raw, T, pad_left, keep_rms, peak, st), "post");
+    return finish(h, r);
+  }
+  r.chk(launch_sigma_embed(P.coef, n_steps, r.W(m.sigma.p_off), m.sigma.simple, m.sigma.n_rff, m.film.D, P.g, st), "sigma");
+  r.chk(launch_film(P.g, r.W(m.film.w_off), r.W(m.film.b_off), P.film, n_steps, m.film.rows, m.film.D, st), "film");
+
+  const int n_start = warm_start >= 0 ? warm_start : 0;
+  // universe.py:325-331
+  r.chk(launch_init_x(noise, warm_start >= 0 ? P.wav.p : nullptr, sigma[n_start], P.x.p, nBT, st), "init x");
+  const size_t mark = r.off;
+  auto mark_tensors = h->tensors;
+  for (int n = n_start; n < n_steps; n++) {
+    r.off = mark;  // every step re-uses the same scratch
+    const bool last = n == n_steps - 1;
+    const float* z = last ? nullptr : noise + (size_t)(n - n_start + 1) * nBT;
+    run_score(r, P, P.x.p, z, P.x.p, OUT_UPDATE, P.coef + n, 0, P.film + (size_t)n * m.film.rows, 0, T);
+    if (!r.ok()) break;
+  }
+  if (r.ok()) r.chk(launch_post(P.x.p, P.stats, out, B, T_raw, T, pad_left, keep_rms, peak, st), "post");
+  return finish(h, r);
+}
+
+int ou_check_device_status(ou_handle* h, void* ws) {
+  if (!h || !ws) return fail(h, OU_EINVAL, "bad argument");
+  unsigned v = 0;
+  hipError_t e = hipMemcpy(&v, ws, sizeof(v), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(h, OU_EHIP, hipGetErrorString(e));
+  if (v) return fail(h, OU_ESYNC, "device-side timeout in the GRU cluster exchange (status word " + std::to_string(v) + ")");
+  return OU_OK;
+}
+
+int ou_tensor(const ou_handle* h, const char* name, size_t* byte_offset, int32_t* C, int32_t* T) {
+  if (!h || !name) return OU_EINVAL;
+  auto it = h->tensors.find(name);
+  if (it == h->tensors.end()) return OU_EMISSING;
+  if (byte_offset) *byte_offset = it->second.off;
+  if (C) *C = it->second.C;
+  if (T) *T = it->second.T;
+  return OU_OK;
+}
+
+int ou_launch_stats(const ou_handle* h, int32_t* n_launches, int32_t* n_conv_launches) {
+  if (!h) return OU_EINVAL;
+  if (n_launches) *n_launches = h->n_launch;
+  if (n_conv_launches) *n_conv_launches = h->n_conv;
+  return OU_OK;
+}
+
+int ou_set_debug(ou_handle* h, int32_t keep) { (void)keep; return h ? OU_OK : OU_EINVAL; }
+
+}  // extern "C"

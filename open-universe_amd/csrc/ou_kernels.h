@@ -1,0 +1,101 @@
+// Launch wrappers of the gfx950 kernels (ou_kernels.hip).  Host-callable, everything enqueued on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace ou {
+
+// ---- generic fp32-MFMA implicit-GEMM Conv1d -------------------------------------------------------------
+//   y[b][co][q*up + p] = epi( bias[co] + sum_{ci,k} W[co*up+p][ci][k] * act(in_scale[b] * x[b][ci][q*stride + k - pad]) )
+//   epi(v): v = (v + add)*add_scale ; v = gamma*v + beta (FiLM) ; v = (v + res)*res_scale     (each optional)
+struct ConvArgs {
+  const float* x = nullptr;       // (B, Cin, Tin)
+  const float* w = nullptr;       // packed [Cin/CK][KW][CK][Mp]
+  const float* bias = nullptr;    // [Cout]
+  float* y = nullptr;             // (B, Cout, Tout)
+  const float* in_scale = nullptr;  // [B] or null
+  const float* alpha = nullptr;     // PReLU slope (device scalar) or null
+  const float* add = nullptr;       // (B, Cout, Tout) or null
+  const float* film = nullptr;      // gamma at film[b*film_bstride + co], beta at [.. + Cout + co]
+  const float* res = nullptr;       // (B, Cout, Tout) or null
+  float add_scale = 1.f, res_scale = 1.f;
+  int film_bstride = 0;
+  int B = 1, Cin = 0, Tin = 0, Cout = 0, M = 0, Mp = 0, KW = 1, stride = 1, pad = 0, up = 1, CK = 2;
+  int Nq = 0;    // GEMM columns (output positions per row)
+  int Tout = 0;  // output length (<= Nq*up)
+};
+// returns hipSuccess or the launch error; `cfg_out` (optional) receives the tile configuration index used
+hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out = nullptr);
+hipError_t init_conv_kernels();  // raises the dynamic-LDS limit of every instantiation
+
+// ---- small VALU kernels ------------------------------------------------------------------------------------
+// Per-step scalars of the sampler / EDM wrapper (universe.py:175-209, 333-343), one row per batch element
+// (or one shared row when bstride == 0).  All fp32, computed on the host in the reference's op order.
+struct StepCoef {
+  float w_in, sigma_net, w_skip, w_out, sig2, c1, s_next, beta;
+};
+enum OutMode { OUT_SCORE = 0, OUT_UPDATE = 1 };
+// Conv1d(1 -> C, k) 'same' on w_in[b]*x (w_in from the coefficient row, 1 when coef == null)
+//   score.py:243-245,284 ; condition.py:295-300,360
+hipError_t launch_in_conv(const float* x, const float* w, const float* bias, const StepCoef* coef, int coef_bstride,
+                          float* y, int B, int C, int T, int KW, hipStream_t s);
+// PReLU -> PReLU -> Conv1d(C -> 1, k) fused with the EDM score and the sampler update:
+//   net -> score = edm ? (w_skip*x + w_out*net - x)/sig2 : net
+//   OUT_SCORE : out = score ;  OUT_UPDATE : out = x + c1*score + beta*(noise*s_next)   (noise may be null)
+hipError_t launch_out_conv(const float* s, const float* w, const float* bias, const float* alphas, const float* x,
+                           const float* noise, float* out, const StepCoef* coef, int coef_bstride, int edm,
+                           int mode, int B, int C, int T, int KW, hipStream_t st);
+
+// Noise-level embedding for S sigma rows (sigma_block.py) -> g (S, D)
+hipError_t launch_sigma_embed(const StepCoef* coef, int S, const float* params, int simple, int n_rff, int D,
+                              float* g, hipStream_t st);
+// All FiLM projections at once: film[s][r] = W[r][:] . g[s][:] + b[r]
+hipError_t launch_film(const float* g, const float* W, const float* b, float* film, int S, int rows, int D,
+                       hipStream_t st);
+// Upload up to 128 StepCoef rows passed by value (graph-capture safe, no host memory involved)
+struct CoefBlock { StepCoef c[64]; };
+hipError_t launch_upload_coef(StepCoef* dst, const CoefBlock& blk, int n, hipStream_t st);
+
+// pad (universe.py:219-223) + normalize_batch (utils/norm.py:47-87).  stats[b] = {mean, gain, mix_rms, 0}
+hipError_t launch_pad_normalize(const float* mix, float* y, float* stats, int B, int T_raw, int T_pad, int pad_left,
+                                float level, hipStream_t st);
+// unpad + keep_rms + peak guard (universe.py:349-357)
+hipError_t launch_post(const float* x, const float* stats, float* out, int B, int T_raw, int T_pad, int pad_left,
+                       int keep_rms, int peak_guard, hipStream_t st);
+// x0 = sigma0 * noise (universe.py:326) ; optionally x0 = base + sigma*noise (warm start :330)
+hipError_t launch_init_x(const float* noise, const float* base, float sigma, float* x, size_t n, hipStream_t st);
+
+// mel front-end (condition.py:92-108): power STFT -> mel fb ; esum[b][frame] = sum_mel mel^2
+hipError_t launch_mel(const float* x, const float* win, const float* tw, const float* fb, float* mel, float* esum,
+                      int B, int T, int n_fft, int hop, int pad_left, int n_freq, int n_mels, int L, hipStream_t st);
+hipError_t launch_mel_scale(const float* esum, float* scale, int B, int L, hipStream_t st);
+
+// space-to-depth + PReLU for the conditioner's strided "st" convs: y[b][ci*R + k][q] = prelu(x[b][ci][q*R + k])
+hipError_t launch_s2d(const float* x, const float* alpha, float* y, int B, int C, int T, int R, hipStream_t st);
+// y = (a + b + c + d + e) * scale   (nulls skipped)   condition.py:202-206
+hipError_t launch_sum(const float* a, const float* b, const float* c, const float* d, const float* e, float scale,
+                      float* y, size_t n, hipStream_t st);
+
+// Bidirectional GRU recurrence on a cluster of H/64 workgroups per (batch, direction).
+//   gx : (B, 6H, T) input projection incl. biases ; out: (B, 2H, T) ; out = res ? (h + res)*scale : h
+struct GruArgs {
+  const float* gx = nullptr;
+  const float* whh = nullptr;
+  const float* bhn = nullptr;
+  float* out = nullptr;
+  const float* res = nullptr;
+  float res_scale = 1.f;
+  unsigned long long* xchg = nullptr;  // B*2*2*H granules, zeroed by the launcher
+  unsigned* err = nullptr;             // device status word
+  int B = 1, T = 0, H = 0;
+};
+hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st);
+
+// Alias-free Snake + Conv1d(C -> 1, k3)  (universe_gan.py:117-126,145-149)
+hipError_t launch_decoupling(const float* aux, const float* alpha_exp, const float* up_k, const float* down_k,
+                             const float* w, const float* bias, float* tmp_up, float* out, int B, int C, int T,
+                             hipStream_t st);
+
+}  // namespace ou

@@ -1,0 +1,903 @@
+// gfx950 (CDNA4 / MI355X) kernels of the UNIVERSE(++) enhance path.  No portability layer: wave = 64,
+// fp32 MFMA (v_mfma_f32_32x32x2_f32), DPP row reductions, agent-scope granule hand-offs.
+#include "ou_kernels.h"
+
+#include <cmath>
+
+namespace ou {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// =========================================================================================================
+// Generic Conv1d as an fp32-MFMA implicit GEMM
+//   GEMM view: rows m (output channel x phase), columns q (time), reduction (ci, tap).
+//   A = packed weights [chunk][tap][ci_local][Mp]  (K-major: an LDS tile row is BM consecutive floats)
+//   B = activations, staged as CK contiguous rows of `span` samples (receptive-field halo included);
+//       the fragment for (ci, tap) is the same LDS row shifted by `tap` -> every sample is fetched from HBM
+//       once per block and re-used KW times from LDS.
+//   v_mfma_f32_32x32x2_f32: A lane l = A[l&31][l>>5], B lane l = B[l>>5][l&31]; a K-pair is two adjacent
+//   input channels at the same tap.  D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
+//   Block = 4 waves arranged WM x WN x WK (WK = intra-block split of the reduction for the small-T levels).
+//   Register-prefetched double-buffered LDS staging: one barrier per channel chunk.
+// =========================================================================================================
+constexpr int CONV_NT = 256;
+constexpr int CONV_MAXX = 16;  // X-tile floats per thread  (CK*span <= 4096)
+constexpr int CONV_MAXW = 6;   // W-tile float4 per thread  (CK*KW*BM <= 6144)
+
+template <int TM, int TN, int WM, int WN, int WK>
+__global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
+  static_assert(WM * WN * WK == 4, "4 waves per block");
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kw = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, b = blockIdx.z;
+
+  const int KW = p.KW, CK = p.CK, stride = p.stride;
+  const int span = (BN - 1) * stride + KW;
+  const int xt = CK * span;               // X tile elements
+  const int xt_al = (xt + 3) & ~3;        // keep the W tile 16-B aligned
+  const int KC = CK * KW;                 // reduction rows per chunk
+  const int wt4 = KC * (BM / 4);          // W tile float4 count
+  float* Xs = smem;                       // [2][xt_al]
+  float* Ws = smem + 2 * xt_al;           // [2][KC*BM]
+  const int nchunks = p.Cin / CK;
+
+  const float* xb = p.x + (size_t)b * p.Cin * p.Tin;
+  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+  const bool act = p.alpha != nullptr;
+  const float alpha = act ? *p.alpha : 0.f;
+
+  // chunk-invariant gather offsets of this thread's X-tile elements (-1: zero padding)
+  int goff[CONV_MAXX];
+#pragma unroll
+  for (int i = 0; i < CONV_MAXX; i++) {
+    int e = tid + i * CONV_NT;
+    int g = -1;
+    if (e < xt) {
+      int l = e / span, j = e - l * span;
+      int t = n0 * stride - p.pad + j;
+      if (t >= 0 && t < p.Tin) g = l * p.Tin + t;
+    }
+    goff[i] = g;
+  }
+
+  float xr[CONV_MAXX];
+  float4 wr[CONV_MAXW];
+
+  auto load_chunk = [&](int c) {
+    const float* xc = xb + (size_t)c * CK * p.Tin;
+#pragma unroll
+    for (int i = 0; i < CONV_MAXX; i++) {
+      int g = goff[i];
+      xr[i] = (g >= 0) ? xc[g] : 0.f;
+    }
+    const float* wc = p.w + ((size_t)c * KC) * p.Mp + m0;
+#pragma unroll
+    for (int i = 0; i < CONV_MAXW; i++) {
+      int f = tid + i * CONV_NT;
+      if (f < wt4) {
+        int row = f / (BM / 4), c4 = f % (BM / 4);
+        wr[i] = *reinterpret_cast<const float4*>(wc + (size_t)row * p.Mp + c4 * 4);
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* xd = Xs + buf * xt_al;
+#pragma unroll
+    for (int i = 0; i < CONV_MAXX; i++) {
+      int e = tid + i * CONV_NT;
+      if (e < xt) {
+        float v = xr[i] * insc;
+        if (act) v = v >= 0.f ? v : alpha * v;
+        xd[e] = v;
+      }
+    }
+    float4* wd = reinterpret_cast<float4*>(Ws + (size_t)buf * KC * BM);
+#pragma unroll
+    for (int i = 0; i < CONV_MAXW; i++) {
+      int f = tid + i * CONV_NT;
+      if (f < wt4) wd[f] = wr[i];
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int hk = CK >> 1;           // K-pairs per tap (power of two)
+  const int lhk = 31 - __clz(hk);
+  const int nsteps = KW * hk;       // MFMA k-steps per chunk
+  const int lhalf = lane >> 5, l31 = lane & 31;
+  const int a_col = wm * (32 * TM) + l31;
+  const int b_col = (wn * (32 * TN) + l31) * stride;
+  constexpr int U = (WK == 1) ? 4 : 2;  // k-steps in flight per wave (fragment prefetch depth)
+
+  // fragments of U k-steps starting at s0 (this wave's steps are s0, s0+WK, ...); zeros past the end
+  auto load_frag = [&](const float* wsb, const float* xsb, int s0, float (&av)[U][TM], float (&bv)[U][TN]) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int s = s0 + u * WK;
+      const bool ok = s < nsteps;
+      const int ss = ok ? s : 0;
+      const int tap = ss >> lhk, i2 = ss & (hk - 1);
+      const float* wrow = wsb + (tap * CK + 2 * i2 + lhalf) * BM + a_col;
+      const float* xrow = xsb + (2 * i2 + lhalf) * span + b_col + tap;
+#pragma unroll
+      for (int i = 0; i < TM; i++) av[u][i] = ok ? wrow[32 * i] : 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; j++) bv[u][j] = ok ? xrow[32 * j * stride] : 0.f;
+    }
+  };
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; c++) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    const float* xsb = Xs + buf * xt_al;
+    const float* wsb = Ws + (size_t)buf * KC * BM;
+    float a0[U][TM], b0[U][TN], a1[U][TM], b1[U][TN];
+    load_frag(wsb, xsb, kw, a0, b0);
+    for (int s = kw; s < nsteps; s += U * WK) {
+      load_frag(wsb, xsb, s + U * WK, a1, b1);
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][i], b0[u][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) a0[u][i] = a1[u][i];
+#pragma unroll
+        for (int j = 0; j < TN; j++) b0[u][j] = b1[u][j];
+      }
+    }
+    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (sum over the WK split on read) -> coalesced fused store ----------
+  constexpr int EP = BN + 1;
+  float* Es = smem;  // [WK][BM][EP]
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        int row = wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+        int col = wn * (32 * TN) + 32 * j + l31;
+        Es[(kw * BM + row) * EP + col] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  const int up = p.up, Cout = p.Cout, Tout = p.Tout;
+  const size_t ybase = (size_t)b * Cout * Tout;
+  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+  const int co_first = m0 / up;
+  int m_hi = m0 + BM - 1;
+  if (m_hi > p.M - 1) m_hi = p.M - 1;
+  const int nco = m_hi / up - co_first + 1;
+  const int ncol = BN * up;  // output samples per co row covered by this tile
+  for (int e = tid; e < nco * ncol; e += CONV_NT) {
+    int col_i = e / ncol, tt = e - col_i * ncol;
+    int co = co_first + col_i;
+    int q = tt / up, ph = tt - q * up;
+    int m = co * up + ph;
+    int t = n0 * up + tt;
+    if (m < m0 || m > m_hi || (n0 + q) >= p.Nq || t >= Tout) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < WK; k++) v += Es[(k * BM + (m - m0)) * EP + q];
+    v += p.bias[co];
+    size_t idx = ybase + (size_t)co * Tout + t;
+    if (p.add) v = (v + p.add[idx]) * p.add_scale;
+    if (filmb) v = filmb[co] * v + filmb[Cout + co];
+    if (p.res) v = (v + p.res[idx]) * p.res_scale;
+    p.y[idx] = v;
+  }
+}
+
+struct ConvCfg {
+  int BM, BN, WK;
+  void (*kern)(ConvArgs);
+};
+static const ConvCfg kConvCfgs[] = {
+    {64, 128, 1, conv_mfma_kernel<1, 2, 2, 2, 1>},
+    {32, 128, 1, conv_mfma_kernel<1, 1, 1, 4, 1>},
+    {64, 64, 1, conv_mfma_kernel<1, 1, 2, 2, 1>},
+    {32, 64, 4, conv_mfma_kernel<1, 2, 1, 1, 4>},
+    {32, 32, 4, conv_mfma_kernel<1, 1, 1, 1, 4>},
+};
+constexpr int kNumConvCfgs = sizeof(kConvCfgs) / sizeof(kConvCfgs[0]);
+
+static size_t conv_smem_bytes(const ConvCfg& c, const ConvArgs& a) {
+  int span = (c.BN - 1) * a.stride + a.KW;
+  size_t xt_al = ((size_t)a.CK * span + 3) & ~size_t(3);
+  size_t stage = 2 * (xt_al + (size_t)a.CK * a.KW * c.BM);
+  size_t epi = (size_t)c.WK * c.BM * (c.BN + 1);
+  return 4 * (stage > epi ? stage : epi);
+}
+
+hipError_t init_conv_kernels() {
+  for (int i = 0; i < kNumConvCfgs; i++) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kConvCfgs[i].kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
+  if (a.Cin % a.CK || a.CK < 2 || (a.CK & (a.CK - 1)) || a.Mp % 64 || a.Nq <= 0) return hipErrorInvalidValue;
+  int pick = -1;
+  const long want = (long)num_cu * 15 / 16;
+  for (int i = 0; i < kNumConvCfgs; i++) {
+    const ConvCfg& c = kConvCfgs[i];
+    if (c.BM == 64 && a.M <= 32) continue;
+    int span = (c.BN - 1) * a.stride + a.KW;
+    if ((long)a.CK * span > CONV_MAXX * CONV_NT) continue;
+    if ((long)a.CK * a.KW * c.BM > CONV_MAXW * CONV_NT * 4) continue;
+    pick = i;
+    long blocks = (long)((a.M + c.BM - 1) / c.BM) * ((a.Nq + c.BN - 1) / c.BN) * a.B;
+    if (blocks >= want) break;
+  }
+  if (pick < 0) return hipErrorInvalidConfiguration;
+  const ConvCfg& c = kConvCfgs[pick];
+  if (cfg_out) *cfg_out = pick;
+  dim3 grid((a.Nq + c.BN - 1) / c.BN, (a.M + c.BM - 1) / c.BM, a.B);
+  size_t smem = conv_smem_bytes(c, a);
+  hipLaunchKernelGGL(c.kern, grid, dim3(CONV_NT), smem, stream, a);
+  return hipGetLastError();
+}
+
+// =========================================================================================================
+// small VALU kernels
+// =========================================================================================================
+__device__ __forceinline__ float prelu(float v, float a) { return v >= 0.f ? v : a * v; }
+
+__global__ __launch_bounds__(256) void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, const StepCoef* coef,
+                                                      int coef_bstride, float* __restrict__ y, int C, int T, int KW) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const float sc = coef ? coef[(size_t)b * coef_bstride].w_in : 1.f;  // universe.py:199,202
+  float xv[7];
+  const int pad = (KW - 1) / 2;
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    int tt = t + k - pad;
+    xv[k] = (k < KW && tt >= 0 && tt < T) ? x[(size_t)b * T + tt] * sc : 0.f;
+  }
+  for (int c = 0; c < C; c++) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+      if (k < KW) acc = fmaf(w[c * KW + k], xv[k], acc);
+    y[((size_t)b * C + c) * T + t] = acc + bias[c];
+  }
+}
+
+hipError_t launch_in_conv(const float* x, const float* w, const float* bias, const StepCoef* coef, int coef_bstride,
+                          float* y, int B, int C, int T, int KW, hipStream_t s) {
+  if (KW > 7) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(in_conv_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, x, w, bias, coef, coef_bstride, y, C, T,
+                     KW);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void out_conv_kernel(const float* __restrict__ s, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, const float* __restrict__ alphas,
+                                                       const float* x, const float* noise, float* out,
+                                                       const StepCoef* coef, int coef_bstride, int edm, int mode, int C,
+                                                       int T, int KW) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const float a1 = alphas[0], a2 = alphas[1];
+  const int pad = (KW - 1) / 2;
+  float acc = 0.f;
+  for (int c = 0; c < C; c++) {
+    const float* sr = s + ((size_t)b * C + c) * T;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      if (k < KW) {
+        int tt = t + k - pad;
+        float v = (tt >= 0 && tt < T) ? sr[tt] : 0.f;
+        v = prelu(prelu(v, a1), a2);
+        acc = fmaf(w[c * KW + k], v, acc);
+      }
+    }
+  }
+  float net = acc + bias[0];
+  const StepCoef cf = coef[(size_t)b * coef_bstride];
+  const size_t i = (size_t)b * T + t;
+  float xv = x ? x[i] : 0.f;
+  float score = net;
+  if (edm) {
+    float est = cf.w_skip * xv + cf.w_out * net;  // universe.py:203
+    score = (est - xv) / cf.sig2;                 // universe.py:204
+  }
+  if (mode == OUT_SCORE) {
+    out[i] = score;
+  } else {
+    float r = xv + cf.c1 * score;  // universe.py:339 / :343
+    if (noise) r = r + cf.beta * (noise[i] * cf.s_next);
+    out[i] = r;
+  }
+}
+
+hipError_t launch_out_conv(const float* s, const float* w, const float* bias, const float* alphas, const float* x,
+                           const float* noise, float* out, const StepCoef* coef, int coef_bstride, int edm, int mode,
+                           int B, int C, int T, int KW, hipStream_t st) {
+  if (KW > 7) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(out_conv_kernel, dim3((T + 255) / 256, B), dim3(256), 0, st, s, w, bias, alphas, x, noise, out,
+                     coef, coef_bstride, edm, mode, C, T, KW);
+  return hipGetLastError();
+}
+
+// ---- noise-level embedding ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sigma_embed_kernel(const StepCoef* coef, const float* __restrict__ prm,
+                                                          int simple, int n_rff, int D, float* __restrict__ g) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const float ls = log10f(coef[s].sigma_net);  // score.py:283
+  const float two_pi = 6.283185307179586f;
+  if (simple) {
+    // sigma_block.py:73-78  f = 0.5*sigmoid(w*ls + b); p = (2pi*f)*k; g = [sin p, cos p]
+    const float f = 0.5f * (1.0f / (1.0f + expf(-(prm[0] * ls + prm[1]))));
+    const float tf = two_pi * f;
+    for (int k = tid; k < D / 2; k += 256) {
+      float ph = tf * (float)k;
+      g[(size_t)s * D + k] = (float)sin((double)ph);
+      g[(size_t)s * D + D / 2 + k] = (float)cos((double)ph);
+    }
+    return;
+  }
+  // sigma_block.py:50-57 random Fourier features + 3 x (Linear -> PReLU)
+  __shared__ float bufA[1024], bufB[1024];
+  for (int k = tid; k < n_rff; k += 256) {
+    float ph = (two_pi * prm[k]) * ls;
+    bufA[k] = (float)sin((double)ph);
+    bufA[n_rff + k] = (float)cos((double)ph);
+  }
+  __syncthreads();
+  const float* q = prm + n_rff;
+  int din = 2 * n_rff;
+  float* in = bufA;
+  float* outb = bufB;
+  for (int layer = 0; layer < 3; layer++) {
+    int dout = layer == 2 ? D : 2 * din;
+    const float al = q[0];
+    const float* W = q + 1;
+    const float* bb = W + (size_t)dout * din;
+    for (int o = tid; o < dout; o += 256) {
+      float acc = 0.f;
+      for (int i = 0; i < din; i++) acc = fmaf(W[(size_t)o * din + i], in[i], acc);
+      acc += bb[o];
+      acc = prelu(acc, al);
+      if (layer == 2) g[(size_t)s * D + o] = acc; else outb[o] = acc;
+    }
+    __syncthreads();
+    q = bb + dout;
+    din = dout;
+    float* tmp = in; in = outb; outb = tmp;
+  }
+}
+
+hipError_t launch_sigma_embed(const StepCoef* coef, int S, const float* params, int simple, int n_rff, int D, float* g,
+                              hipStream_t st) {
+  if (D > 1024 || 8 * n_rff > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sigma_embed_kernel, dim3(S), dim3(256), 0, st, coef, params, simple, n_rff, D, g);
+  return hipGetLastError();
+}
+
+// one wave per output row; the row of W stays in registers across the S columns
+__global__ __launch_bounds__(256) void film_kernel(const float* __restrict__ g, const float* __restrict__ W,
+                                                   const float* __restrict__ bias, float* __restrict__ film, int S,
+                                                   int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float wv[16];
+  const int per = D / 64;  // <= 16
+#pragma unroll
+  for (int i = 0; i < 16; i++) wv[i] = (i < per) ? W[(size_t)row * D + i * 64 + lane] : 0.f;
+  const float bb = bias[row];
+  for (int s = 0; s < S; s++) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      if (i < per) acc = fmaf(wv[i], g[(size_t)s * D + i * 64 + lane], acc);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) film[(size_t)s * rows + row] = acc + bb;
+  }
+}
+
+hipError_t launch_film(const float* g, const float* W, const float* b, float* film, int S, int rows, int D,
+                       hipStream_t st) {
+  if (D % 64 || D > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(film_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, g, W, b, film, S, rows, D);
+  return hipGetLastError();
+}
+
+__global__ void upload_coef_kernel(StepCoef* dst, CoefBlock blk, int n) {
+  int i = threadIdx.x;
+  if (i < n) dst[i] = blk.c[i];
+}
+hipError_t launch_upload_coef(StepCoef* dst, const CoefBlock& blk, int n, hipStream_t st) {
+  hipLaunchKernelGGL(upload_coef_kernel, dim3(1), dim3(64), 0, st, dst, blk, n);
+  return hipGetLastError();
+}
+
+// ---- block reductions --------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+template <typename T>
+__device__ T block_sum(T v, T* sh) {  // blockDim multiple of 64, <= 1024
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  T r = 0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); i++) r += sh[i];
+  return r;
+}
+__device__ float block_max(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); i++) r = fmaxf(r, sh[i]);
+  return r;
+}
+
+// pad + zero-mean + unit-level normalisation, one block per batch element
+__global__ __launch_bounds__(1024) void pad_normalize_kernel(const float* __restrict__ mix, float* __restrict__ y,
+                                                             float* __restrict__ stats, int T_raw, int T_pad,
+                                                             int pad_left, float level) {
+  __shared__ double shd[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* xb = mix + (size_t)b * T_raw;
+  double s = 0, sq = 0;
+  for (int t = tid; t < T_raw; t += 1024) {
+    double v = xb[t];
+    s += v;
+    sq += v * v;
+  }
+  s = block_sum(s, shd);
+  sq = block_sum(sq, shd);
+  const float mean = (float)(s / T_pad);  // norm.py:62  (mean over the padded signal)
+  double ss = 0;
+  for (int t = tid; t < T_raw; t += 1024) {
+    double d = (double)(xb[t] - mean);
+    ss += d * d;
+  }
+  ss = block_sum(ss, shd);
+  ss += (double)(T_pad - T_raw) * (double)(0.f - mean) * (double)(0.f - mean);
+  float sd = (float)sqrt(ss / (double)(T_pad - 1));  // unbiased std, norm.py:22-23
+  sd = fmaxf(sd, 1e-5f);
+  const float gain = level / sd;
+  float* yb = y + (size_t)b * T_pad;
+  for (int t = tid; t < T_pad; t += 1024) {
+    int tr = t - pad_left;
+    float v = (tr >= 0 && tr < T_raw) ? xb[tr] : 0.f;
+    yb[t] = (v - mean) * gain;
+  }
+  if (tid == 0) {
+    stats[b * 4 + 0] = mean;
+    stats[b * 4 + 1] = gain;
+    stats[b * 4 + 2] = (float)sqrt(sq / T_raw);  // mix_rms, universe.py:259
+    stats[b * 4 + 3] = 0.f;
+  }
+}
+hipError_t launch_pad_normalize(const float* mix, float* y, float* stats, int B, int T_raw, int T_pad, int pad_left,
+                                float level, hipStream_t st) {
+  hipLaunchKernelGGL(pad_normalize_kernel, dim3(B), dim3(1024), 0, st, mix, y, stats, T_raw, T_pad, pad_left, level);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(1024) void post_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                    float* __restrict__ out, int T_raw, int T_pad, int pad_left,
+                                                    int keep_rms, int peak_guard) {
+  __shared__ double shd[16];
+  __shared__ float shf[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* xb = x + (size_t)b * T_pad + pad_left;
+  float g = 1.f;
+  if (keep_rms) {  // universe.py:352-354
+    double sq = 0;
+    for (int t = tid; t < T_raw; t += 1024) {
+      double v = xb[t];
+      sq += v * v;
+    }
+    sq = block_sum(sq, shd);
+    float x_rms = fmaxf((float)sqrt(sq / T_raw), 1e-5f);
+    g = stats[b * 4 + 2] / x_rms;
+  }
+  float mx = 0.f;
+  for (int t = tid; t < T_raw; t += 1024) mx = fmaxf(mx, fabsf(xb[t] * g));
+  mx = block_max(mx, shf);
+  const bool div = peak_guard && mx > 1.0f;  // universe.py:356-357
+  for (int t = tid; t < T_raw; t += 1024) {
+    float v = xb[t];
+    if (keep_rms) v = v * g;
+    if (div) v = v / mx;
+    out[(size_t)b * T_raw + t] = v;
+  }
+}
+hipError_t launch_post(const float* x, const float* stats, float* out, int B, int T_raw, int T_pad, int pad_left,
+                       int keep_rms, int peak_guard, hipStream_t st) {
+  hipLaunchKernelGGL(post_kernel, dim3(B), dim3(1024), 0, st, x, stats, out, T_raw, T_pad, pad_left, keep_rms,
+                     peak_guard);
+  return hipGetLastError();
+}
+
+__global__ void init_x_kernel(const float* __restrict__ noise, const float* base, float sigma, float* __restrict__ x,
+                              size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = noise[i] * sigma;  // universe.py:39-41
+  x[i] = base ? base[i] + v : v;
+}
+hipError_t launch_init_x(const float* noise, const float* base, float sigma, float* x, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(init_x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, noise, base, sigma, x, n);
+  return hipGetLastError();
+}
+
+// ---- mel front-end -------------------------------------------------------------------------------------------
+// One block per (frame, batch).  n_fft is 640 / 960 (not a power of two): direct DFT with an exact
+// (k*n mod N) twiddle table in LDS; 0.33 GFLOP per utterance, once per enhance call.
+__global__ __launch_bounds__(512) void mel_kernel(const float* __restrict__ x, const float* __restrict__ win,
+                                                  const float* __restrict__ tw, const float* __restrict__ fb,
+                                                  float* __restrict__ mel, float* __restrict__ esum, int T, int n_fft,
+                                                  int hop, int pad_left, int n_freq, int n_mels, int L) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sx = sm;                // [n_fft] windowed frame
+  float* tc = sx + n_fft;        // [n_fft] cos
+  float* ts = tc + n_fft;        // [n_fft] sin
+  float* pw = ts + n_fft;        // [n_freq]
+  __shared__ float shf[8];
+  const int f = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  for (int n = tid; n < n_fft; n += 512) {
+    int t = f * hop + n - pad_left;  // condition.py:98 padding
+    float v = (t >= 0 && t < T) ? x[(size_t)b * T + t] : 0.f;
+    sx[n] = v * win[n];
+    tc[n] = tw[n];
+    ts[n] = tw[n_fft + n];
+  }
+  __syncthreads();
+  for (int k = tid; k < n_freq; k += 512) {
+    float re = 0.f, im = 0.f;
+    int idx = 0;
+    for (int n = 0; n < n_fft; n++) {
+      float v = sx[n];
+      re = fmaf(v, tc[idx], re);
+      im = fmaf(-v, ts[idx], im);
+      idx += k;
+      if (idx >= n_fft) idx -= n_fft;
+    }
+    pw[k] = re * re + im * im;  // power spectrogram
+  }
+  __syncthreads();
+  float e = 0.f;
+  for (int m = tid; m < n_mels; m += 512) {
+    float acc = 0.f;
+    for (int k = 0; k < n_freq; k++) acc = fmaf(pw[k], fb[(size_t)k * n_mels + m], acc);
+    mel[((size_t)b * n_mels + m) * L + f] = acc;
+    e += acc * acc;
+  }
+  e = block_sum(e, shf);
+  if (tid == 0) esum[(size_t)b * L + f] = e;
+}
+hipError_t launch_mel(const float* x, const float* win, const float* tw, const float* fb, float* mel, float* esum,
+                      int B, int T, int n_fft, int hop, int pad_left, int n_freq, int n_mels, int L, hipStream_t st) {
+  size_t smem = (size_t)(3 * n_fft + n_freq) * 4;
+  hipLaunchKernelGGL(mel_kernel, dim3(L, B), dim3(512), smem, st, x, win, tw, fb, mel, esum, T, n_fft, hop, pad_left,
+                     n_freq, n_mels, L);
+  return hipGetLastError();
+}
+// condition.py:105-106: scale = 1 / max(sqrt(mean_frames(sum_mel mel^2)), 1e-5)
+__global__ __launch_bounds__(256) void mel_scale_kernel(const float* __restrict__ esum, float* scale, int L) {
+  __shared__ double shd[4];
+  const int b = blockIdx.x;
+  double s = 0;
+  for (int f = threadIdx.x; f < L; f += 256) s += esum[(size_t)b * L + f];
+  s = block_sum(s, shd);
+  if (threadIdx.x == 0) scale[b] = 1.0f / fmaxf((float)sqrt(s / L), 1e-5f);
+}
+hipError_t launch_mel_scale(const float* esum, float* scale, int B, int L, hipStream_t st) {
+  hipLaunchKernelGGL(mel_scale_kernel, dim3(B), dim3(256), 0, st, esum, scale, L);
+  return hipGetLastError();
+}
+
+// ---- space-to-depth + PReLU ------------------------------------------------------------------------------------
+constexpr int S2D_QB = 32;
+__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ x, const float* alpha,
+                                                  float* __restrict__ y, int C, int T, int R) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Nq = T / R;
+  const int q0 = blockIdx.x * S2D_QB, ci = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int nq = min(S2D_QB, Nq - q0);
+  const float a = *alpha;
+  const float* xr = x + ((size_t)b * C + ci) * T + (size_t)q0 * R;
+  const int n = nq * R;
+  for (int j = tid; j < n; j += 256) sm[j + (j >> 5)] = prelu(xr[j], a);
+  __syncthreads();
+  float* yb = y + ((size_t)b * C * R + (size_t)ci * R) * Nq + q0;
+  for (int e = tid; e < R * S2D_QB; e += 256) {
+    int k = e / S2D_QB, q = e % S2D_QB;
+    if (q < nq) {
+      int j = q * R + k;
+      yb[(size_t)k * Nq + q] = sm[j + (j >> 5)];
+    }
+  }
+}
+hipError_t launch_s2d(const float* x, const float* alpha, float* y, int B, int C, int T, int R, hipStream_t st) {
+  if (T % R) return hipErrorInvalidValue;
+  int Nq = T / R;
+  size_t n = (size_t)S2D_QB * R;
+  size_t smem = (n + (n >> 5) + 1) * 4;
+  hipLaunchKernelGGL(s2d_kernel, dim3((Nq + S2D_QB - 1) / S2D_QB, C, B), dim3(256), smem, st, x, alpha, y, C, T, R);
+  return hipGetLastError();
+}
+
+__global__ void sum_kernel(const float* a, const float* b, const float* c, const float* d, const float* e, float scale,
+                           float* __restrict__ y, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = a[i];
+  if (b) v += b[i];
+  if (c) v += c[i];
+  if (d) v += d[i];
+  if (e) v += e[i];
+  y[i] = v * scale;
+}
+hipError_t launch_sum(const float* a, const float* b, const float* c, const float* d, const float* e, float scale,
+                      float* y, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, c, d, e, scale, y, n);
+  return hipGetLastError();
+}
+
+// =========================================================================================================
+// GRU recurrence (torch.nn.GRU semantics; score.py:83-89,116 / condition.py:173-179,212)
+//   W_hh of one direction is 3H x H fp32 (786 KB at H = 256): larger than one CU's LDS and VGPR file, so a
+//   cluster of HB = H/64 workgroups (512 threads each, one per CU) keeps it resident in registers:
+//   workgroup g owns hidden units [64g, 64g+64) = 192 gate rows; thread (rg, cg) holds rows of units
+//   {2rg, 2rg+1} x columns {4cg + 64i + 0..3}.  Per time step: 96..144 FMAs per thread, a 16-lane DPP
+//   row reduction, the gate math, then the 64 new hidden values are published to the other workgroups as
+//   8-byte {step tag, value} granules with relaxed agent-scope stores (write-through to L2) and gathered
+//   by one polling wave -- no fence, no flag (the tag is the flag).  Spins are bounded; a timeout raises
+//   the status word instead of hanging the GPU.
+// =========================================================================================================
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+  return v + __int_as_float(t);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+constexpr unsigned GRU_SPIN_LIMIT = 4000000u;
+
+template <int HB>
+__global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p) {
+  constexpr int H = 64 * HB, NR = 24 * HB;
+  __shared__ __attribute__((aligned(16))) float hbuf[2][H];
+  __shared__ int abort_flag;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = blockIdx.x, dir = blockIdx.y, b = blockIdx.z;
+  const int rg = tid >> 4, cg = tid & 15;
+  const int T = p.T;
+
+  float w[NR];
+  {
+    const float* wp = p.whh + ((size_t)(dir * HB + g) * NR) * 512 + tid;
+#pragma unroll
+    for (int r = 0; r < NR; r++) w[r] = wp[(size_t)r * 512];
+  }
+  for (int i = tid; i < 2 * H; i += 512) (&hbuf[0][0])[i] = 0.f;
+  if (tid == 0) abort_flag = 0;
+
+  // lanes cg = 0,1 of each 16-lane row finish one hidden unit each
+  const int unit = g * 64 + 2 * rg + (cg & 1);
+  const bool fin = cg < 2;
+  const float bhn = p.bhn[dir * H + unit];
+  const float* gxb = p.gx + ((size_t)b * 6 * H + (size_t)dir * 3 * H) * T;
+  const float* gx_r = gxb + (size_t)unit * T;
+  const float* gx_z = gxb + (size_t)(H + unit) * T;
+  const float* gx_n = gxb + (size_t)(2 * H + unit) * T;
+  const size_t orow = ((size_t)b * 2 * H + (size_t)dir * H + unit) * T;
+  unsigned long long* xq = p.xchg + ((size_t)(b * 2 + dir) * 2) * H;
+
+  int t = dir ? T - 1 : 0;
+  const int dt = dir ? -1 : 1;
+  float xr = 0.f, xz = 0.f, xn = 0.f;
+  if (fin) { xr = gx_r[t]; xz = gx_z[t]; xn = gx_n[t]; }
+  __syncthreads();
+
+  for (int step = 0; step < T; step++, t += dt) {
+    const int cur = step & 1;
+    float acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < HB; i++) {
+      const float4 hv = *reinterpret_cast<const float4*>(&hbuf[cur][cg * 4 + 64 * i]);
+#pragma unroll
+      for (int ug = 0; ug < 6; ug++) {
+        const int r = (ug * HB + i) * 4;
+        acc[ug] = fmaf(w[r + 0], hv.x, acc[ug]);
+        acc[ug] = fmaf(w[r + 1], hv.y, acc[ug]);
+        acc[ug] = fmaf(w[r + 2], hv.z, acc[ug]);
+        acc[ug] = fmaf(w[r + 3], hv.w, acc[ug]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) acc[i] = row16_sum(acc[i]);
+
+    // prefetch the next step's input-projection values while the gates are computed
+    float nxr = 0.f, nxz = 0.f, nxn = 0.f;
+    if (fin && step + 1 < T) { nxr = gx_r[t + dt]; nxz = gx_z[t + dt]; nxn = gx_n[t + dt]; }
+
+    if (fin) {
+      const bool hi = (cg & 1) != 0;
+      const float hr = hi ? acc[3] : acc[0], hz = hi ? acc[4] : acc[1], hn = hi ? acc[5] : acc[2];
+      const float r = sigmoidf_(xr + hr);
+      const float z = sigmoidf_(xz + hz);
+      const float n = tanhf(xn + r * (hn + bhn));
+      const float hp = hbuf[cur][unit];
+      const float hnew = (hp - n) * z + n;
+      hbuf[cur ^ 1][unit] = hnew;
+      float o = hnew;
+      if (p.res) o = (hnew + p.res[orow + t]) * p.res_scale;
+      p.out[orow + t] = o;
+      if (HB > 1) {
+        unsigned long long gran = ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned)__float_as_int(hnew);
+        __hip_atomic_store(xq + (size_t)(cur ^ 1) * H + unit, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    xr = nxr; xz = nxz; xn = nxn;
+
+    if (HB > 1 && tid < 64) {
+      // gather the other workgroups' slices: each lane owns H/64 granules
+      const unsigned tag = (unsigned)(step + 1);
+#pragma unroll
+      for (int k = 0; k < HB; k++) {
+        const int u = k * 64 + lane;
+        if (k != g) {
+          unsigned long long* src = xq + (size_t)(cur ^ 1) * H + u;
+          unsigned long long v;
+          unsigned spins = 0;
+          while (true) {
+            v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == tag) break;
+            if (++spins > GRU_SPIN_LIMIT) { abort_flag = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          hbuf[cur ^ 1][u] = __int_as_float((int)(unsigned)v);
+        }
+      }
+    }
+    __syncthreads();
+    if (HB > 1 && abort_flag) {
+      if (tid == 0) atomicOr(p.err, 1u);
+      break;
+    }
+  }
+}
+
+hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
+  if (a.H % 64) return hipErrorInvalidValue;
+  const int HB = a.H / 64;
+  // every workgroup of a cluster must be resident at once: one 512-thread workgroup per CU
+  int bmax = num_cu / (2 * HB);
+  if (bmax < 1) return hipErrorInvalidConfiguration;
+  for (int b0 = 0; b0 < a.B; b0 += bmax) {
+    GruArgs c = a;
+    c.B = (a.B - b0 < bmax) ? a.B - b0 : bmax;
+    c.gx = a.gx + (size_t)b0 * 6 * a.H * a.T;
+    c.out = a.out + (size_t)b0 * 2 * a.H * a.T;
+    if (a.res) c.res = a.res + (size_t)b0 * 2 * a.H * a.T;
+    if (HB > 1) {
+      hipError_t e = hipMemsetAsync(c.xchg, 0, (size_t)c.B * 4 * a.H * sizeof(unsigned long long), st);
+      if (e != hipSuccess) return e;
+    }
+    dim3 grid(HB, 2, c.B);
+    switch (HB) {
+      case 1: hipLaunchKernelGGL(gru_cluster_kernel<1>, grid, dim3(512), 0, st, c); break;
+      case 2: hipLaunchKernelGGL(gru_cluster_kernel<2>, grid, dim3(512), 0, st, c); break;
+      case 4: hipLaunchKernelGGL(gru_cluster_kernel<4>, grid, dim3(512), 0, st, c); break;
+      case 6: hipLaunchKernelGGL(gru_cluster_kernel<6>, grid, dim3(512), 0, st, c); break;
+      default: return hipErrorInvalidConfiguration;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// =========================================================================================================
+// signal decoupling layer (cold branch): 2x sinc upsample -> Snake -> 2x downsample -> Conv1d(C -> 1, k3)
+//   torchaudio Resample(1->2): pad (7, 8), conv with the 2 phase kernels (15 taps), interleave, crop to 2T.
+//   Resample(2->1): pad (13, 15), 28-tap kernel, stride 2.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void snake_up_kernel(const float* __restrict__ aux, const float* __restrict__ alpha_exp,
+                                                       const float* __restrict__ up_k, float* __restrict__ u, int C,
+                                                       int T) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;  // index in the 2T up-sampled signal
+  if (i >= 2 * T) return;
+  const float* xr = aux + ((size_t)b * C + c) * T;
+  const int q = i >> 1, ph = i & 1;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 15; k++) {
+    int t = q + k - 7;
+    float v = (t >= 0 && t < T) ? xr[t] : 0.f;
+    acc = fmaf(up_k[ph * 15 + k], v, acc);
+  }
+  const float a = alpha_exp[c];
+  const float sn = sinf(acc * a);
+  u[((size_t)b * C + c) * 2 * T + i] = acc + (1.0f / (a + 1e-9f)) * (sn * sn);  // snake.py:59-62
+}
+__global__ __launch_bounds__(256) void snake_down_conv_kernel(const float* __restrict__ u, const float* __restrict__ down_k,
+                                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ out, int C, int T) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  float acc = 0.f;
+  for (int c = 0; c < C; c++) {
+    const float* ur = u + ((size_t)b * C + c) * 2 * T;
+#pragma unroll
+    for (int k3 = 0; k3 < 3; k3++) {
+      int tt = t + k3 - 1;
+      if (tt < 0 || tt >= T) continue;
+      float d = 0.f;
+#pragma unroll
+      for (int k = 0; k < 28; k++) {
+        int j = 2 * tt + k - 13;
+        float v = (j >= 0 && j < 2 * T) ? ur[j] : 0.f;
+        d = fmaf(down_k[k], v, d);
+      }
+      acc = fmaf(w[c * 3 + k3], d, acc);
+    }
+  }
+  out[(size_t)b * T + t] = acc + bias[0];
+}
+hipError_t launch_decoupling(const float* aux, const float* alpha_exp, const float* up_k, const float* down_k,
+                             const float* w, const float* bias, float* tmp_up, float* out, int B, int C, int T,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(snake_up_kernel, dim3((2 * T + 255) / 256, C, B), dim3(256), 0, st, aux, alpha_exp, up_k, tmp_up, C, T);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(snake_down_conv_kernel, dim3((T + 255) / 256, B), dim3(256), 0, st, tmp_up, down_k, w, bias, out, C, T);
+  return hipGetLastError();
+}
+
+}  // namespace ou

@@ -1,0 +1,366 @@
+"""
+Host side of the drop-in `model` object returned by `inference_utils.load_model`.
+
+Mirrors the inference surface of the reference's `Universe` / `UniverseGAN` LightningModule
+(open_universe/networks/universe/universe.py:44-386, universe_gan.py:60-149): `.fs`, `.diff_kwargs`,
+`.enhance(...)` (same signature + type hints: the reference CLI introspects them,
+inference_utils/signature_to_parser.py:45), `.eval()`, `.to()`, `.condition_model(...)`,
+`.score_model(...)`, `.aux_to_wav(...)`.
+
+Everything numerical happens in libouniverse.so (HIP, gfx950) through the C ABI; this class only reshapes,
+draws the noise with `torch.randn(generator=rng)` in the reference's order (so a shared generator advances
+identically, bin/enhance.py:147-166), owns the device buffers (PyTorch = device memory + streams) and maps C
+status codes to the reference's exception types.  No torch compute fallback exists: without the library or
+without a GPU construction fails.
+"""
+import ctypes
+import math
+from ctypes import byref, c_float, c_int32, c_size_t, c_void_p
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .config import ModelSpec
+
+
+def randn(x, sigma, rng=None):
+    """universe.py:39-41 (kept for API parity; the product path passes raw normal draws to the C ABI)."""
+    noise = torch.randn(x.shape, dtype=x.dtype, device=x.device, generator=rng)
+    return noise * sigma[:, None, None]
+
+
+class Universe:
+    """MI355X-native stand-in for the reference's `Universe` / `UniverseGAN` inference object."""
+
+    def __init__(self, spec: ModelSpec, state_dict=None, device=None, packed_weights=None):
+        if device is None:
+            device = "cuda"
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(
+                f"open_universe_amd runs on MI355X (HIP) only; device={device} requested. "
+                "There is no CPU path -- use the reference implementation for CPU inference."
+            )
+        if not torch.cuda.is_available():
+            raise RuntimeError("open_universe_amd: no HIP device visible (torch.cuda.is_available() is False)")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self._L = _lib.load()  # raises LibraryNotBuilt when the extension is missing
+        self.spec = spec
+        self.fs = spec.fs
+        self.diff_kwargs = spec.diff_kwargs
+        self.normalization_norm = 2
+        self.normalization_kwargs = {"ref": "both", "level_db": spec.level_db}
+        self.with_edm = spec.edm_noise is not None
+        self.tot_ds = spec.tot_ds
+        self.n_channels = spec.score.n_channels
+        self.device = device
+        self.check_status = True  # synchronise + read the device status word after every call
+        self.training = False
+        self._cfg = _lib.make_config(spec)
+        if packed_weights is None:
+            if state_dict is None:
+                raise ValueError("either state_dict or packed_weights is required")
+            packed_weights, _ = _lib.pack_weights(spec, state_dict)
+        self._weights = packed_weights.to(device=device, dtype=torch.float32).contiguous()
+        self._handle = c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(self._L.ou_create(byref(self._cfg), c_void_p(self._weights.data_ptr()),
+                                         c_size_t(self._weights.numel() * 4), device.index, byref(self._handle)))
+        self._ws = None
+        self._ws_key = None
+        self._cond_key = None
+
+    # ------------------------------------------------------------------------------------------------
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None and self._handle.value:
+                self._L.ou_destroy(self._handle)
+                self._handle = c_void_p()
+        except Exception:
+            pass
+
+    def eval(self, no_ema=False):
+        """universe.py:864-865: inference always runs on the EMA weights (resolved at load time)."""
+        return self
+
+    def train(self, mode=True, no_ema=False):
+        if mode:
+            raise NotImplementedError("open_universe_amd implements the inference (enhance) path only")
+        return self
+
+    def to(self, *args, **kwargs):
+        dev = kwargs.get("device", args[0] if args else None)
+        if dev is not None and torch.device(dev).type != "cuda":
+            raise RuntimeError("open_universe_amd models live on a HIP device; .to(cpu) is not supported")
+        return self
+
+    # ------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, B, T):
+        key = (B, T)
+        if self._ws_key != key:
+            n = c_size_t()
+            _lib.check(self._L.ou_workspace_bytes(self._handle, B, T, byref(n)), self._handle)
+            self._ws = None
+            self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+            self._cond_key = None
+        return self._ws
+
+    def _status(self):
+        if self.check_status:
+            torch.cuda.current_stream(self.device).synchronize()
+            _lib.check(self._L.ou_check_device_status(self._handle, c_void_p(self._ws.data_ptr())), self._handle)
+
+    def tensor(self, name):
+        """Debug: view of a named intermediate of the last call inside the workspace -> (B, C, T) tensor."""
+        off, C, T = c_size_t(), c_int32(), c_int32()
+        rc = self._L.ou_tensor(self._handle, name.encode(), byref(off), byref(C), byref(T))
+        if rc != 0:
+            raise KeyError(name)
+        B = self._ws_key[0]
+        n = B * C.value * T.value
+        return self._ws[off.value: off.value + 4 * n].view(torch.float32).view(B, C.value, T.value)
+
+    def launch_stats(self):
+        a, b = c_int32(), c_int32()
+        self._L.ou_launch_stats(self._handle, byref(a), byref(b))
+        return a.value, b.value
+
+    def pad(self, x, pad=None):
+        """universe.py:219-223."""
+        if pad is None:
+            pad = self.tot_ds - x.shape[-1] % self.tot_ds
+        return torch.nn.functional.pad(x, (pad // 2, pad - pad // 2)), pad
+
+    def unpad(self, x, pad):
+        return x[..., pad // 2: -(pad - pad // 2)]
+
+    def get_std_dev(self, time):
+        """universe.py:380-386 (geometric schedule)."""
+        s_min, s_max = self.diff_kwargs.sigma_min, self.diff_kwargs.sigma_max
+        return s_min * (s_max / s_min) ** time
+
+    # ---- operator seams (universe.py:314-316, 286) --------------------------------------------------
+    def _prep(self, x):
+        if x.device != self.device:
+            raise ValueError(f"input is on {x.device}, model on {self.device}")
+        return x.to(torch.float32).contiguous()
+
+    def condition_model(self, x, x_wav=None, train=False):
+        """condition.py:346-377.  x: (B,1,T) normalised, T % tot_ds == 0.  Returns conditions or, with
+        train=True, (conditions, aux_signal, latent) -- views into the workspace, valid until the next call."""
+        x = self._prep(x)
+        if x.ndim != 3 or x.shape[1] != 1:
+            raise ValueError("condition_model expects (B, 1, T)")
+        B, _, T = x.shape
+        if T % self.tot_ds:
+            raise ValueError("the HIP conditioner needs T % tot_ds == 0 (enhance() pads accordingly)")
+        ws = self._workspace(B, T)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ou_condition(self._handle, c_void_p(x.data_ptr()), B, T, c_void_p(ws.data_ptr()),
+                                            c_size_t(ws.numel()), self._stream()), self._handle)
+        self._cond_key = (B, T)
+        self._status()
+        n_blocks = len(self.spec.score.rate_factors) + int(self.spec.cond.extra_conv_block)
+        cond = [self.tensor(f"cond.c{j}") for j in range(n_blocks)]
+        if train:
+            return cond, self.tensor("cond.aux"), self.tensor("cond.latent")
+        return cond
+
+    def score_model(self, x, sigma, cond=None):
+        """universe.py:197-209 / score.py:277-297: score(x, sigma | cond of the last condition_model call)."""
+        x = self._prep(x)
+        B, _, T = x.shape
+        if self._cond_key != (B, T):
+            raise ValueError("score_model: call condition_model on a (B,1,T) input of the same shape first")
+        sig = sigma.detach().to(torch.float32).cpu().contiguous()
+        if sig.numel() != B:
+            raise ValueError("sigma must have one entry per batch element")
+        out = torch.empty_like(x)
+        ws = self._ws
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ou_score(self._handle, c_void_p(x.data_ptr()),
+                                        ctypes.cast(sig.data_ptr(), ctypes.POINTER(c_float)), c_void_p(out.data_ptr()),
+                                        B, T, c_void_p(ws.data_ptr()), c_size_t(ws.numel()), self._stream()), self._handle)
+        self._status()
+        return out
+
+    def aux_to_wav(self, y_aux=None):
+        """universe_gan.py:145-149 on the aux signal of the last condition_model call."""
+        if not self.spec.use_signal_decoupling:
+            if y_aux is None:
+                return self.tensor("cond.aux")
+            return y_aux
+        B, T = self._cond_key
+        out = torch.empty(B, 1, T, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ou_aux_to_wav(self._handle, c_void_p(out.data_ptr()), B, T, c_void_p(self._ws.data_ptr()),
+                                             c_size_t(self._ws.numel()), self._stream()), self._handle)
+        self._status()
+        return out
+
+    # ---- the hot path ------------------------------------------------------------------------------
+    def enhance(
+        self,
+        mix,
+        n_steps: Optional[int] = None,
+        epsilon: Optional[float] = None,
+        target: Optional[torch.Tensor] = None,
+        fake_score_snr: Optional[float] = None,
+        rng: Optional[torch.Generator] = None,
+        use_aux_signal: Optional[bool] = False,
+        keep_rms: Optional[bool] = False,
+        ensemble: Optional[int] = None,
+        ensemble_stat: Optional[str] = "median",
+        warm_start: Optional[int] = None,
+    ) -> torch.Tensor:
+        """Universe.enhance, universe.py:231-375 (same arguments, same return convention)."""
+        return self._enhance(mix, n_steps, epsilon, target, fake_score_snr, rng, use_aux_signal, keep_rms, ensemble,
+                             ensemble_stat, warm_start, None)
+
+    @torch.no_grad()
+    def _enhance(self, mix, n_steps, epsilon, target, fake_score_snr, rng, use_aux_signal, keep_rms, ensemble,
+                 ensemble_stat, warm_start, noise):
+        if epsilon is None:
+            epsilon = self.diff_kwargs.epsilon
+        if n_steps is None:
+            n_steps = self.diff_kwargs.n_steps
+        x_ndim = mix.ndim
+        if x_ndim == 1:
+            mix = mix[None, None, :]
+        elif x_ndim == 2:
+            mix = mix[:, None, :]
+        elif x_ndim > 3:
+            raise ValueError("The input should have at most 3 dimensions")
+        if mix.ndim == 3 and mix.shape[1] != 1:
+            raise ValueError("enhance expects single-channel signals: (T,), (B,T) or (B,1,T)")
+        if ensemble_stat not in ("mean", "median", "signal_median") and ensemble is not None:
+            raise NotImplementedError()  # universe.py:368
+        mix = self._prep(mix)
+        if ensemble is not None:
+            mix_shape = mix.shape
+            if keep_rms and mix_shape[0] != 1:
+                # universe.py:259 computes mix_rms before the replication (:261-264): the reference fails to
+                # broadcast (B,1,1) against (E*B,1,T) at :354 for B > 1; same behaviour here.
+                raise RuntimeError("keep_rms with ensemble is only defined for a single input signal (as in the reference)")
+            mix = torch.stack([mix] * ensemble, dim=0).view((-1,) + mix_shape[1:])
+        B, _, mix_len = mix.shape
+        pad = self.tot_ds - mix_len % self.tot_ds
+        T = mix_len + pad
+
+        if target is not None:
+            x = self._enhance_with_oracle_score(mix, target, n_steps, epsilon, fake_score_snr, rng, pad)
+        else:
+            # discretised schedule exactly as the reference builds it (universe.py:308-311)
+            time = torch.linspace(0, 1, n_steps).to(torch.float32).flip(dims=[0])
+            sigma = self.get_std_dev(time).to(torch.float32).contiguous()
+            n_start = 0 if warm_start is None else int(warm_start)
+            n_noise = 0 if use_aux_signal else n_steps - n_start
+            if noise is None:
+                # draw order of the reference: x0, then z_n for n = n_start .. N-2 (universe.py:326,330,338)
+                draws = [torch.randn((B, 1, T), dtype=torch.float32, device=self.device, generator=rng)
+                         for _ in range(n_noise)]
+                noise_t = torch.stack(draws, dim=0) if draws else None
+            else:
+                noise_t = torch.stack([self._prep(z) for z in noise[:n_noise]], dim=0) if n_noise else None
+                if n_noise and noise_t.shape != (n_noise, B, 1, T):
+                    raise ValueError(f"noise must be {n_noise} tensors of shape {(B, 1, T)}")
+            out = torch.empty(B, 1, mix_len, dtype=torch.float32, device=self.device)
+            ws = self._workspace(B, T)
+            flags = (_lib.OU_ENH_KEEP_RMS if keep_rms else 0) | (_lib.OU_ENH_USE_AUX_SIGNAL if use_aux_signal else 0)
+            with torch.cuda.device(self.device):
+                _lib.check(self._L.ou_enhance(
+                    self._handle, c_void_p(mix.data_ptr()), c_void_p(out.data_ptr()),
+                    c_void_p(noise_t.data_ptr()) if noise_t is not None else None, B, mix_len, int(n_steps),
+                    float(epsilon), ctypes.cast(sigma.data_ptr(), ctypes.POINTER(c_float)),
+                    -1 if warm_start is None else int(warm_start), flags, c_void_p(ws.data_ptr()),
+                    c_size_t(ws.numel()), self._stream()), self._handle)
+            self._cond_key = (B, T)
+            self._status()
+            x = out
+
+        if target is not None:
+            if keep_rms:
+                mix_rms = mix.square().mean(dim=(-2, -1), keepdim=True).sqrt()
+                x_rms = x.square().mean(dim=(-2, -1), keepdim=True).sqrt().clamp(min=1e-5)
+                x = x * (mix_rms / x_rms)
+            scale = abs(x).max(dim=-1, keepdim=True).values
+            x = torch.where(scale > 1.0, x / scale, x)
+
+        if ensemble is not None:  # universe.py:359-368 (host-side glue over E replicas of the same utterance)
+            x = x.view((-1,) + mix_shape)
+            if ensemble_stat == "mean":
+                x = x.mean(dim=0)
+            elif ensemble_stat == "median":
+                x = x.median(dim=0).values
+            elif ensemble_stat == "signal_median":
+                x = signal_median(x)
+            else:
+                raise NotImplementedError()
+        if x_ndim == 1:
+            x = x[0, 0]
+        elif x_ndim == 2:
+            x = x[:, 0, :]
+        return x
+
+    def _enhance_with_oracle_score(self, mix, target, n_steps, epsilon, fake_score_snr, rng, pad):
+        """Diagnostic mode of the reference (universe.py:278-298): the network is bypassed by the analytic
+        score of a known target, so no kernel of this library is involved -- plain device tensor glue."""
+        tot = self.tot_ds
+        level = 10 ** (self.spec.level_db / 20.0)
+
+        def norm(t):
+            t = torch.nn.functional.pad(t, (pad // 2, pad - pad // 2))
+            t = t - t.mean(dim=(1, 2), keepdim=True)
+            return t * (level / t.std(dim=(1, 2), keepdim=True).clamp(min=1e-5))
+
+        mixp = norm(mix)
+        tgt = norm(self._prep(target))
+        score_snr = 5.0 if fake_score_snr is None else fake_score_snr
+        delta_t = 1.0 / (n_steps - 1)
+        gamma = (self.diff_kwargs.sigma_max / self.diff_kwargs.sigma_min) ** -delta_t
+        eta = 1 - gamma ** epsilon
+        beta = math.sqrt(1 - gamma ** (2 * (epsilon - 1.0)))
+        time = torch.linspace(0, 1, n_steps).type_as(mixp).flip(dims=[0])
+        sigma = self.get_std_dev(time)
+        sigma = torch.broadcast_to(sigma[None, :], (mixp.shape[0], sigma.shape[0]))
+
+        def score_wrapper(x, s):
+            true_score = -(x - tgt) / s[:, None, None] ** 2
+            noise_rms = (true_score ** 2).mean().sqrt() * 10 ** (-score_snr / 20.0)
+            nz = torch.randn(true_score.shape, dtype=true_score.dtype, device=true_score.device, generator=rng)
+            return true_score + nz * noise_rms
+
+        x = randn(mixp, sigma[:, 0], rng=rng)
+        for n in range(n_steps - 1):
+            s_now, s_next = sigma[:, n], sigma[:, n + 1]
+            score = score_wrapper(x, s_now)
+            z = randn(x, s_next, rng=rng)
+            x = x + s_now[..., None, None] ** 2 * eta * score + beta * z
+        x = x + sigma[:, -1, None, None] ** 2 * score_wrapper(x, sigma[:, -1])
+        x = x[..., pad // 2: -(pad - pad // 2)]
+        return torch.nn.functional.pad(x, (0, mix.shape[-1] - x.shape[-1]))
+
+
+class UniverseGAN(Universe):
+    """UNIVERSE++ (universe_gan.py:60): same inference surface; aux_to_wav goes through the decoupling layer."""
+
+
+def signal_median(signal):
+    """utils/stats.py:22-66: pick, per batch entry, the ensemble member that is the per-sample median most often."""
+    shape = signal.shape
+    signal = signal.flatten(start_dim=2)
+    n = signal.shape[0]
+    _, sorted_indices = signal.sort(dim=0)
+    _, min_indices = abs(sorted_indices - n / 2).min(dim=0)
+    pad_bins = torch.broadcast_to(torch.arange(n, device=signal.device)[None, :], (min_indices.shape[0], n))
+    min_indices = torch.cat((min_indices, pad_bins), dim=1)
+    counts = torch.cat([(min_indices == i).sum(dim=1, keepdim=True) for i in range(n)], dim=1) - 1
+    select = counts.argmax(dim=1)
+    med = torch.stack([signal[select[i], i, :] for i in range(signal.shape[1])], dim=0)
+    return med.reshape(shape[1:])

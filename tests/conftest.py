@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """The HIP library must be built (cross-compiles without a GPU)."""
+    from open_universe_amd import _lib
+
+    if not os.path.exists(_lib.lib_path()):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return _lib.load()

@@ -1,0 +1,67 @@
+"""Shared helpers for the test-suite (model zoo of reduced-width configs, synthetic inputs, unpacking)."""
+import json
+import math
+
+import torch
+
+import open_universe_amd  # noqa: F401
+from open_universe_amd import config as C
+from open_universe_amd import state_dict as S
+
+# reduced-width variants of the three shipped topologies (GRU hidden size must stay a multiple of 64)
+SMALL = {
+    "PP16s": ("PP16", {"score_model.n_channels": 8}),    # OC=128, H=64  (single-workgroup GRU)
+    "PP16m": ("PP16", {"score_model.n_channels": 16}),   # OC=256, H=128 (2-workgroup GRU cluster)
+    "OR16s": ("OR16", {"score_model.n_channels": 8}),
+    "PP24s": ("PP24", {"score_model.n_channels": 8}),
+}
+
+
+def get_spec(name):
+    if name in SMALL:
+        base, over = SMALL[name]
+        return C.spec_from_config(C.builtin_config(base, **over))
+    return C.spec_from_config(C.builtin_config(name))
+
+
+def synth_mix(spec, B, T, seed=1000):
+    """SURVEY.md 8(d) synthetic inputs: AM sine + noise."""
+    out = []
+    t = torch.arange(T) / spec.fs
+    for i in range(B):
+        g = torch.Generator().manual_seed(seed + i)
+        f = 110.0 * (1 + i % 8)
+        out.append(0.1 * torch.sin(2 * math.pi * f * t) * (0.5 + 0.5 * torch.sin(2 * math.pi * 3 * t))
+                   + 0.03 * torch.randn(T, generator=g))
+    return torch.stack(out)
+
+
+def unpack_conv(blob, L):
+    """Recover the dense [M][Cin][KW] weight, bias and PReLU slope of a packed generic-conv layer."""
+    Cin, KW, CK, Mp, M = L["Cin"], L["KW"], L["CK"], L["Mp"], L["M"]
+    w = blob[L["w_off"]: L["w_off"] + Cin * KW * Mp].view(Cin // CK, KW, CK, Mp)
+    W = w.permute(3, 0, 2, 1).reshape(Mp, Cin, KW)[:M]
+    bias = blob[L["b_off"]: L["b_off"] + L["Cout"]]
+    alpha = blob[L["a_off"]: L["a_off"] + 1]
+    return W, bias, alpha
+
+
+def emulate_conv(blob, L, x, act=True):
+    """What conv_mfma_kernel computes for layer L (torch, CPU) -- used to validate packing/folding."""
+    import torch.nn.functional as F
+
+    W, bias, alpha = unpack_conv(blob, L)
+    if L["act"] and act:
+        x = F.prelu(x, alpha)
+    stride, pad, up, KW = L["stride"], L["pad"], L["up"], L["KW"]
+    Nq = x.shape[-1] // stride if stride > 1 else x.shape[-1]
+    need = (Nq - 1) * stride + KW
+    xp = F.pad(x, (pad, max(0, need - pad - x.shape[-1])))
+    y = F.conv1d(xp, W, None, stride=stride)[..., :Nq]
+    B = x.shape[0]
+    y = y.view(B, L["Cout"], up, Nq).permute(0, 1, 3, 2).reshape(B, L["Cout"], Nq * up)
+    return y + bias.view(1, -1, 1)
+
+
+def plan_convs(plan_json):
+    return {c["name"]: c for c in json.loads(plan_json)["convs"]}

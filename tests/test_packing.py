@@ -1,0 +1,89 @@
+"""CPU: the C++ packer (weight-norm fold, binomial-FIR fold, transposed-conv phase split, GRU layouts) is
+checked by unpacking the blob and comparing a torch emulation of the generic conv against the oracle."""
+import json
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import restatement as O
+from helpers import emulate_conv, get_spec, plan_convs
+from open_universe_amd import _lib
+from open_universe_amd import state_dict as S
+
+
+@pytest.mark.parametrize("name", ["PP16s", "OR16s", "PP24s"])
+def test_pack_all_convs(built_lib, name):
+    spec = get_spec(name)
+    sd = S.synthetic_state_dict(spec, seed=3)
+    blob, plan = _lib.pack_weights(spec, sd)
+    assert blob.numel() * 4 == _lib.packed_bytes(spec)
+    convs = plan_convs(plan)
+    g = torch.Generator().manual_seed(0)
+    n_checked = 0
+    for nm, L in convs.items():
+        kind = L["kind"]
+        if kind == 4:  # GRU projection
+            pfx, lay = nm.split("#l")
+            H, I = L["Cout"] // 6, L["Cin"]
+            x = torch.randn(2, I, 9, generator=g)
+            y = emulate_conv(blob, L, x)
+            for d, sfx in enumerate(("", "_reverse")):
+                k = f"_l{lay}{sfx}"
+                ref = F.conv1d(x, sd[pfx + ".weight_ih" + k][:, :, None], sd[pfx + ".bias_ih" + k])
+                bhh = sd[pfx + ".bias_hh" + k].clone()
+                bhh[2 * H:] = 0
+                ref = ref + bhh.view(1, -1, 1)
+                assert torch.allclose(y[:, d * 3 * H:(d + 1) * 3 * H], ref, atol=2e-5, rtol=1e-5), nm
+        elif kind == 3:  # st conv lowered to space-to-depth + 1x1
+            R = L["rate"]
+            C = L["Cin"] // R
+            x = torch.randn(2, C, 3 * R, generator=g)
+            ref = O.prelu_conv(sd, nm, x, stride=R)
+            xs = F.prelu(x, sd[nm + ".prelu.weight"]).view(2, C, 3, R).permute(0, 1, 3, 2).reshape(2, C * R, 3)
+            y = emulate_conv(blob, L, xs, act=False)
+            assert torch.allclose(y, ref, atol=2e-5, rtol=1e-4), nm
+        elif kind == 1:  # down
+            r = L["rate"]
+            x = torch.randn(2, L["Cin"], 6 * r, generator=g)
+            ref = O.prelu_conv(sd, nm, x, stride=r)
+            y = emulate_conv(blob, L, x)
+            assert torch.allclose(y, ref, atol=2e-5, rtol=1e-4), (nm, float((y - ref).abs().max()))
+        elif kind == 2:  # up
+            r = L["rate"]
+            x = torch.randn(2, L["Cin"], 7, generator=g)
+            ref = O.prelu_conv(sd, nm, x, stride=r, transpose=True)
+            y = emulate_conv(blob, L, x)
+            assert torch.allclose(y, ref, atol=2e-5, rtol=1e-4), (nm, float((y - ref).abs().max()))
+        else:  # plain 'same' conv
+            x = torch.randn(2, L["Cin"], 11, generator=g)
+            if L["act"]:
+                ref = O.prelu_conv(sd, nm, x, same=True)
+            else:
+                ref = F.conv1d(x, O.eff_weight(sd, nm), sd[nm + ".bias"], padding="same")
+            y = emulate_conv(blob, L, x)
+            assert torch.allclose(y, ref, atol=2e-5, rtol=1e-4), nm
+        n_checked += 1
+    assert n_checked == len(convs) and n_checked > 60
+
+
+def test_pack_errors(built_lib):
+    spec = get_spec("PP16s")
+    sd = S.synthetic_state_dict(spec, seed=0)
+    bad = dict(sd)
+    del bad["_edm_model.encoder.ds_modules.0.conv1.conv.weight_v"]
+    with pytest.raises(KeyError):
+        _lib.pack_weights(spec, bad)
+    bad = dict(sd)
+    bad["condition_model.input_conv.bias"] = torch.zeros(3)
+    with pytest.raises(ValueError):
+        _lib.pack_weights(spec, bad)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    import re, os
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "ouniverse.h")).read()
+    declared = set(re.findall(r"\b(ou_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    for s in declared:
+        assert hasattr(built_lib, s), s
