@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -44,6 +45,7 @@ struct ou_handle {
   int n_launch = 0, n_conv = 0;
   // geometry of the last ou_condition (consumed by ou_score)
   int cond_B = 0, cond_T = 0;
+  bool trace = false;
 };
 
 namespace {
@@ -126,7 +128,12 @@ struct Runner {
     a.res = e.res; a.res_scale = e.res_scale;
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
-    chk(launch_conv(a, h->num_cu, st), L.name.c_str());
+    int cfg = -1;
+    chk(launch_conv(a, h->num_cu, st, &cfg), L.name.c_str());
+    if (h->trace)
+      std::fprintf(stderr, "OU_TRACE conv %-64s cfg=%d M=%d Nq=%d K=%d(Cin=%d KW=%d CK=%d) stride=%d up=%d B=%d MFLOP=%.1f\n",
+                   name.c_str(), cfg, L.M, Nq, L.Cin * L.KW, L.Cin, L.KW, L.CK, L.stride, L.up, B,
+                   2.0 * L.M * Nq * L.Cin * L.KW * B * 1e-6);
     h->n_conv++;
     return out;
   }
@@ -458,6 +465,7 @@ int ou_create(const ou_config* cfg, const void* weights_dev, size_t nbytes, int3
     return fail(nullptr, OU_EHIP, "libouniverse is built for gfx950 (MI355X) only; device is " + arch);
   }
   h->num_cu = prop.multiProcessorCount;
+  h->trace = std::getenv("OU_TRACE") != nullptr;
   h->device = device;
   h->W = (const float*)weights_dev;
   (void)hipSetDevice(device);

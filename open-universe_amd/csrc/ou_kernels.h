@@ -25,6 +25,8 @@ struct ConvArgs {
   int B = 1, Cin = 0, Tin = 0, Cout = 0, M = 0, Mp = 0, KW = 1, stride = 1, pad = 0, up = 1, CK = 2;
   int Nq = 0;    // GEMM columns (output positions per row)
   int Tout = 0;  // output length (<= Nq*up)
+  unsigned magic_span[3] = {0, 0, 0};  // filled by launch_conv: 2^32/span + 1 for BN = 128 / 64 / 32
+  unsigned magic_up = 0;               // 2^32/up + 1 (0 when up == 1)
 };
 // returns hipSuccess or the launch error; `cfg_out` (optional) receives the tile configuration index used
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out = nullptr);

@@ -7,6 +7,7 @@
 namespace ou {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // =========================================================================================================
 // Generic Conv1d as an fp32-MFMA implicit GEMM
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
     int e = tid + i * CONV_NT;
     int g = -1;
     if (e < xt) {
-      int l = e / span, j = e - l * span;
+      int l = (int)__umulhi((unsigned)e, p.magic_span[BN == 128 ? 0 : (BN == 64 ? 1 : 2)]);  // e / span
+      int j = e - l * span;
       int t = n0 * stride - p.pad + j;
       if (t >= 0 && t < p.Tin) g = l * p.Tin + t;
     }
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
   }
 
   float xr[CONV_MAXX];
-  float4 wr[CONV_MAXW];
+  f32x4 wr[CONV_MAXW];
 
   auto load_chunk = [&](int c) {
     const float* xc = xb + (size_t)c * CK * p.Tin;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
       int f = tid + i * CONV_NT;
       if (f < wt4) {
         int row = f / (BM / 4), c4 = f % (BM / 4);
-        wr[i] = *reinterpret_cast<const float4*>(wc + (size_t)row * p.Mp + c4 * 4);
+        wr[i] = *reinterpret_cast<const f32x4*>(wc + (size_t)row * p.Mp + c4 * 4);
       }
     }
   };
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
         xd[e] = v;
       }
     }
-    float4* wd = reinterpret_cast<float4*>(Ws + (size_t)buf * KC * BM);
+    f32x4* wd = reinterpret_cast<f32x4*>(Ws + (size_t)buf * KC * BM);
 #pragma unroll
     for (int i = 0; i < CONV_MAXW; i++) {
       int f = tid + i * CONV_NT;
@@ -116,24 +118,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
   const int lhalf = lane >> 5, l31 = lane & 31;
   const int a_col = wm * (32 * TM) + l31;
   const int b_col = (wn * (32 * TN) + l31) * stride;
-  constexpr int U = (WK == 1) ? 4 : 2;  // k-steps in flight per wave (fragment prefetch depth)
-
-  // fragments of U k-steps starting at s0 (this wave's steps are s0, s0+WK, ...); zeros past the end
-  auto load_frag = [&](const float* wsb, const float* xsb, int s0, float (&av)[U][TM], float (&bv)[U][TN]) {
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int s = s0 + u * WK;
-      const bool ok = s < nsteps;
-      const int ss = ok ? s : 0;
-      const int tap = ss >> lhk, i2 = ss & (hk - 1);
-      const float* wrow = wsb + (tap * CK + 2 * i2 + lhalf) * BM + a_col;
-      const float* xrow = xsb + (2 * i2 + lhalf) * span + b_col + tap;
-#pragma unroll
-      for (int i = 0; i < TM; i++) av[u][i] = ok ? wrow[32 * i] : 0.f;
-#pragma unroll
-      for (int j = 0; j < TN; j++) bv[u][j] = ok ? xrow[32 * j * stride] : 0.f;
-    }
-  };
+  constexpr int U = (WK == 1) ? 4 : 2;  // k-steps issued back to back (LDS reads of a group precede its MFMAs)
 
   load_chunk(0);
   store_chunk(0);
@@ -141,34 +126,51 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
   for (int c = 0; c < nchunks; c++) {
     const int buf = c & 1;
     if (c + 1 < nchunks) load_chunk(c + 1);
-    const float* xsb = Xs + buf * xt_al;
-    const float* wsb = Ws + (size_t)buf * KC * BM;
-    float a0[U][TM], b0[U][TN], a1[U][TM], b1[U][TN];
-    load_frag(wsb, xsb, kw, a0, b0);
-    for (int s = kw; s < nsteps; s += U * WK) {
-      load_frag(wsb, xsb, s + U * WK, a1, b1);
+    const float* xsb = Xs + buf * xt_al + lhalf * span + b_col;
+    const float* wsb = Ws + (size_t)buf * KC * BM + lhalf * BM + a_col;
+    int s = kw;
+    for (; s + (U - 1) * WK < nsteps; s += U * WK) {
+      float av[U][TM], bv[U][TN];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int ss = s + u * WK;
+        const int tap = ss >> lhk, i2 = ss & (hk - 1);
+        const float* wrow = wsb + (tap * CK + 2 * i2) * BM;
+        const float* xrow = xsb + (2 * i2) * span + tap;
+#pragma unroll
+        for (int i = 0; i < TM; i++) av[u][i] = wrow[32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bv[u][j] = xrow[32 * j * stride];
+      }
 #pragma unroll
       for (int u = 0; u < U; u++)
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
           for (int j = 0; j < TN; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][i], b0[u][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+    }
+    for (; s < nsteps; s += WK) {
+      const int tap = s >> lhk, i2 = s & (hk - 1);
+      const float* wrow = wsb + (tap * CK + 2 * i2) * BM;
+      const float* xrow = xsb + (2 * i2) * span + tap;
+      float av[TM], bv[TN];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
+      for (int i = 0; i < TM; i++) av[i] = wrow[32 * i];
 #pragma unroll
-        for (int i = 0; i < TM; i++) a0[u][i] = a1[u][i];
+      for (int j = 0; j < TN; j++) bv[j] = xrow[32 * j * stride];
 #pragma unroll
-        for (int j = 0; j < TN; j++) b0[u][j] = b1[u][j];
-      }
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     if (c + 1 < nchunks) store_chunk(buf ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue: accumulators -> LDS (sum over the WK split on read) -> coalesced fused store ----------
-  constexpr int EP = BN + 1;
-  float* Es = smem;  // [WK][BM][EP]
+  constexpr int EP = BN + 4;  // keeps rows 16-B aligned for the float4 read-back
+  float* Es = smem;           // [WK][BM][EP]
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -184,23 +186,49 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
   const int up = p.up, Cout = p.Cout, Tout = p.Tout;
   const size_t ybase = (size_t)b * Cout * Tout;
   const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
-  const int co_first = m0 / up;
   int m_hi = m0 + BM - 1;
   if (m_hi > p.M - 1) m_hi = p.M - 1;
-  const int nco = m_hi / up - co_first + 1;
-  const int ncol = BN * up;  // output samples per co row covered by this tile
-  for (int e = tid; e < nco * ncol; e += CONV_NT) {
-    int col_i = e / ncol, tt = e - col_i * ncol;
-    int co = co_first + col_i;
-    int q = tt / up, ph = tt - q * up;
-    int m = co * up + ph;
-    int t = n0 * up + tt;
-    if (m < m0 || m > m_hi || (n0 + q) >= p.Nq || t >= Tout) continue;
-    float v = 0.f;
+
+  if (up == 1 && (Tout & 3) == 0) {
+    // fast path: one float4 of consecutive time samples per thread and pass, shift-only indexing
+    constexpr int C4 = BN / 4, RPP = CONV_NT / C4;
+    const int c4 = tid % C4, q = c4 * 4;
+    if (n0 + q < p.Nq) {
+      for (int row = tid / C4; row < BM; row += RPP) {
+        const int m = m0 + row;
+        if (m > m_hi) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&Es[row * EP + q]);
 #pragma unroll
-    for (int k = 0; k < WK; k++) v += Es[(k * BM + (m - m0)) * EP + q];
+        for (int k = 1; k < WK; k++) v += *reinterpret_cast<const f32x4*>(&Es[(k * BM + row) * EP + q]);
+        v += p.bias[m];
+        const size_t idx = ybase + (size_t)m * Tout + n0 + q;
+        if (p.add) v = (v + *reinterpret_cast<const f32x4*>(p.add + idx)) * p.add_scale;
+        if (filmb) v = filmb[m] * v + filmb[Cout + m];
+        if (p.res) v = (v + *reinterpret_cast<const f32x4*>(p.res + idx)) * p.res_scale;
+        *reinterpret_cast<f32x4*>(p.y + idx) = v;
+      }
+    }
+    return;
+  }
+  // general path (transposed-conv phase interleave, or rows that are not 16-B aligned):
+  //   e -> (co, q, ph) with the output sample t = (n0 + q)*up + ph fastest across threads
+  constexpr int LBN = (BN == 128) ? 7 : (BN == 64 ? 6 : 5);
+  const int co_first = up == 1 ? m0 : (int)__umulhi((unsigned)m0, p.magic_up);
+  const int nco = (up == 1 ? m_hi : (int)__umulhi((unsigned)m_hi, p.magic_up)) - co_first + 1;
+  const int total = nco * BN * up;
+  for (int e = tid; e < total; e += CONV_NT) {
+    const int rest = up == 1 ? e : (int)__umulhi((unsigned)e, p.magic_up);  // e / up
+    const int ph = e - rest * up;
+    const int q = rest & (BN - 1);
+    const int co = co_first + (rest >> LBN);
+    const int m = co * up + ph;
+    const int t = (n0 + q) * up + ph;
+    if (m < m0 || m > m_hi || (n0 + q) >= p.Nq || t >= Tout) continue;
+    float v = Es[(m - m0) * EP + q];
+#pragma unroll
+    for (int k = 1; k < WK; k++) v += Es[(k * BM + (m - m0)) * EP + q];
     v += p.bias[co];
-    size_t idx = ybase + (size_t)co * Tout + t;
+    const size_t idx = ybase + (size_t)co * Tout + t;
     if (p.add) v = (v + p.add[idx]) * p.add_scale;
     if (filmb) v = filmb[co] * v + filmb[Cout + co];
     if (p.res) v = (v + p.res[idx]) * p.res_scale;
@@ -225,7 +253,7 @@ static size_t conv_smem_bytes(const ConvCfg& c, const ConvArgs& a) {
   int span = (c.BN - 1) * a.stride + a.KW;
   size_t xt_al = ((size_t)a.CK * span + 3) & ~size_t(3);
   size_t stage = 2 * (xt_al + (size_t)a.CK * a.KW * c.BM);
-  size_t epi = (size_t)c.WK * c.BM * (c.BN + 1);
+  size_t epi = (size_t)c.WK * c.BM * (c.BN + 4);
   return 4 * (stage > epi ? stage : epi);
 }
 
@@ -255,9 +283,14 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   if (pick < 0) return hipErrorInvalidConfiguration;
   const ConvCfg& c = kConvCfgs[pick];
   if (cfg_out) *cfg_out = pick;
+  ConvArgs aa = a;
+  // exact for the index ranges used (e < 2^13, divisor < 2^11): floor(e/d) == umulhi(e, 2^32/d + 1)
+  const int bns[3] = {128, 64, 32};
+  for (int i = 0; i < 3; i++) aa.magic_span[i] = (unsigned)(0x100000000ull / (unsigned)((bns[i] - 1) * a.stride + a.KW)) + 1u;
+  aa.magic_up = a.up == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.up) + 1u;
   dim3 grid((a.Nq + c.BN - 1) / c.BN, (a.M + c.BM - 1) / c.BM, a.B);
   size_t smem = conv_smem_bytes(c, a);
-  hipLaunchKernelGGL(c.kern, grid, dim3(CONV_NT), smem, stream, a);
+  hipLaunchKernelGGL(c.kern, grid, dim3(CONV_NT), smem, stream, aa);
   return hipGetLastError();
 }
 
@@ -705,12 +738,20 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 constexpr unsigned GRU_SPIN_LIMIT = 4000000u;
 
 template <int HB>
-__global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p) {
+__global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int nclusters) {
   constexpr int H = 64 * HB, NR = 24 * HB;
   __shared__ __attribute__((aligned(16))) float hbuf[2][H];
   __shared__ int abort_flag;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int g = blockIdx.x, dir = blockIdx.y, b = blockIdx.z;
+  // Workgroup -> (cluster, member): the dispatcher places block i on XCD i % 8 (observed, speed only), so the
+  // HB members of a cluster are given ids that are congruent mod 8 and share one L2.  Correctness does not
+  // depend on it: the exchange below is agent-scope.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int cluster = xcd + 8 * (slot / HB);
+  const int g = slot % HB;
+  if (cluster >= nclusters) return;
+  const int dir = cluster & 1, b = cluster >> 1;
   const int rg = tid >> 4, cg = tid & 15;
   const int T = p.T;
 
@@ -733,11 +774,15 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p) {
   const float* gx_n = gxb + (size_t)(2 * H + unit) * T;
   const size_t orow = ((size_t)b * 2 * H + (size_t)dir * H + unit) * T;
   unsigned long long* xq = p.xchg + ((size_t)(b * 2 + dir) * 2) * H;
+  const bool has_res = p.res != nullptr;
 
   int t = dir ? T - 1 : 0;
   const int dt = dir ? -1 : 1;
-  float xr = 0.f, xz = 0.f, xn = 0.f;
-  if (fin) { xr = gx_r[t]; xz = gx_z[t]; xn = gx_n[t]; }
+  float xr = 0.f, xz = 0.f, xn = 0.f, rs = 0.f;
+  if (fin) {
+    xr = gx_r[t]; xz = gx_z[t]; xn = gx_n[t];
+    if (has_res) rs = p.res[orow + t];
+  }
   __syncthreads();
 
   for (int step = 0; step < T; step++, t += dt) {
@@ -760,9 +805,13 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p) {
 #pragma unroll
     for (int i = 0; i < 6; i++) acc[i] = row16_sum(acc[i]);
 
-    // prefetch the next step's input-projection values while the gates are computed
-    float nxr = 0.f, nxz = 0.f, nxn = 0.f;
-    if (fin && step + 1 < T) { nxr = gx_r[t + dt]; nxz = gx_z[t + dt]; nxn = gx_n[t + dt]; }
+    // next step's input-projection / residual values: issued now, consumed one iteration later, so that no
+    // global-load latency ever sits between the gate math and the publish below
+    float nxr = 0.f, nxz = 0.f, nxn = 0.f, nrs = 0.f;
+    if (fin && step + 1 < T) {
+      nxr = gx_r[t + dt]; nxz = gx_z[t + dt]; nxn = gx_n[t + dt];
+      if (has_res) nrs = p.res[orow + t + dt];
+    }
 
     if (fin) {
       const bool hi = (cg & 1) != 0;
@@ -772,36 +821,35 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p) {
       const float n = tanhf(xn + r * (hn + bhn));
       const float hp = hbuf[cur][unit];
       const float hnew = (hp - n) * z + n;
-      hbuf[cur ^ 1][unit] = hnew;
-      float o = hnew;
-      if (p.res) o = (hnew + p.res[orow + t]) * p.res_scale;
-      p.out[orow + t] = o;
-      if (HB > 1) {
+      if (HB > 1) {  // publish first: the other workgroups are waiting on this
         unsigned long long gran = ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned)__float_as_int(hnew);
         __hip_atomic_store(xq + (size_t)(cur ^ 1) * H + unit, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      hbuf[cur ^ 1][unit] = hnew;
+      p.out[orow + t] = has_res ? (hnew + rs) * p.res_scale : hnew;
     }
-    xr = nxr; xz = nxz; xn = nxn;
+    xr = nxr; xz = nxz; xn = nxn; rs = nrs;
 
     if (HB > 1 && tid < 64) {
-      // gather the other workgroups' slices: each lane owns H/64 granules
+      // gather the other workgroups' slices: each lane owns H/64 granules; all polls in flight together
       const unsigned tag = (unsigned)(step + 1);
+      unsigned long long* src = xq + (size_t)(cur ^ 1) * H + lane;
+      unsigned long long v[HB];
+      unsigned spins = 0;
+      while (true) {
+        bool ok = true;
 #pragma unroll
-      for (int k = 0; k < HB; k++) {
-        const int u = k * 64 + lane;
-        if (k != g) {
-          unsigned long long* src = xq + (size_t)(cur ^ 1) * H + u;
-          unsigned long long v;
-          unsigned spins = 0;
-          while (true) {
-            v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(v >> 32) == tag) break;
-            if (++spins > GRU_SPIN_LIMIT) { abort_flag = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          hbuf[cur ^ 1][u] = __int_as_float((int)(unsigned)v);
+        for (int k = 0; k < HB; k++) {
+          v[k] = (k == g) ? ((unsigned long long)tag << 32)
+                          : __hip_atomic_load(src + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && ((unsigned)(v[k] >> 32) == tag);
         }
+        if (ok) break;
+        if (++spins > GRU_SPIN_LIMIT) { abort_flag = 1; break; }
       }
+#pragma unroll
+      for (int k = 0; k < HB; k++)
+        if (k != g) hbuf[cur ^ 1][k * 64 + lane] = __int_as_float((int)(unsigned)v[k]);
     }
     __syncthreads();
     if (HB > 1 && abort_flag) {
@@ -815,7 +863,7 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
   if (a.H % 64) return hipErrorInvalidValue;
   const int HB = a.H / 64;
   // every workgroup of a cluster must be resident at once: one 512-thread workgroup per CU
-  int bmax = num_cu / (2 * HB);
+  int bmax = (num_cu / (8 * HB)) * 8 / 2;  // clusters are dealt to XCDs in groups of 8
   if (bmax < 1) return hipErrorInvalidConfiguration;
   for (int b0 = 0; b0 < a.B; b0 += bmax) {
     GruArgs c = a;
@@ -827,12 +875,13 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
       hipError_t e = hipMemsetAsync(c.xchg, 0, (size_t)c.B * 4 * a.H * sizeof(unsigned long long), st);
       if (e != hipSuccess) return e;
     }
-    dim3 grid(HB, 2, c.B);
+    const int nclusters = 2 * c.B;
+    dim3 grid(8 * HB * ((nclusters + 7) / 8));
     switch (HB) {
-      case 1: hipLaunchKernelGGL(gru_cluster_kernel<1>, grid, dim3(512), 0, st, c); break;
-      case 2: hipLaunchKernelGGL(gru_cluster_kernel<2>, grid, dim3(512), 0, st, c); break;
-      case 4: hipLaunchKernelGGL(gru_cluster_kernel<4>, grid, dim3(512), 0, st, c); break;
-      case 6: hipLaunchKernelGGL(gru_cluster_kernel<6>, grid, dim3(512), 0, st, c); break;
+      case 1: hipLaunchKernelGGL(gru_cluster_kernel<1>, grid, dim3(512), 0, st, c, nclusters); break;
+      case 2: hipLaunchKernelGGL(gru_cluster_kernel<2>, grid, dim3(512), 0, st, c, nclusters); break;
+      case 4: hipLaunchKernelGGL(gru_cluster_kernel<4>, grid, dim3(512), 0, st, c, nclusters); break;
+      case 6: hipLaunchKernelGGL(gru_cluster_kernel<6>, grid, dim3(512), 0, st, c, nclusters); break;
       default: return hipErrorInvalidConfiguration;
     }
     hipError_t e = hipGetLastError();

@@ -92,7 +92,36 @@ def run(name, B=2, T=None, n_steps=4, seed=0):
     print(f"  oracle {t1-t0:.2f}s hip(first call) {t2-t1:.3f}s launches {model.launch_stats()}")
 
 
+
+
+def timing(name="PP16", B=1, T=64000, n_steps=8, iters=5):
+    spec = get_spec(name)
+    sd = S.synthetic_state_dict(spec, seed=0)
+    model = Universe(spec, state_dict=sd, device="cuda:0")
+    mix = synth_mix(spec, B, T).cuda()
+    rng = torch.Generator(device="cuda").manual_seed(1028282)
+    model.check_status = False
+    for _ in range(2):
+        model.enhance(mix, n_steps=n_steps, rng=rng)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        t0 = time.time()
+        model.enhance(mix, n_steps=n_steps, rng=rng)
+        torch.cuda.synchronize()
+        ts.append(time.time() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    print(f"TIMING {name} B={B} T={T} N={n_steps}: median {med*1e3:.2f} ms  min {ts[0]*1e3:.2f} ms  "
+          f"RTF {B*T/spec.fs/med:.1f}x  utt/s {B/med:.2f}  launches {model.launch_stats()}")
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or ["PP16s", "PP16m", "OR16s", "PP24s"]
-    for n in names:
-        run(n)
+    args = sys.argv[1:]
+    if args and args[0] == "timing":
+        timing(*(args[1:2] or ["PP16"]), **{k: int(v) for k, v in (a.split("=") for a in args[2:])})
+    elif args and args[0] == "full":
+        run(args[1], B=int(args[2]), T=int(args[3]), n_steps=int(args[4]))
+    else:
+        for n in args or ["PP16s", "PP16m", "OR16s", "PP24s"]:
+            run(n)
