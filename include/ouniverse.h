@@ -71,7 +71,7 @@ typedef struct ou_config {
   float level_db;      /* normalization_kwargs.level_db */
   int32_t has_edm;     /* edm: {noise: ...} present (universe.py:85-95) */
   float edm_noise;
-  float sigma_min, sigma_max; /* diffusion.* (geometric schedule, universe.py:380-386) */
+  double sigma_min, sigma_max; /* diffusion.* (geometric schedule, universe.py:380-386) */
   int32_t use_signal_decoupling; /* universe_gan.py:117-126 */
   int32_t signal_decoupling_act; /* OU_ACT_* */
   ou_net_config score;
@@ -156,9 +156,14 @@ const char* ou_packer_plan_json(const ou_packer* p);
 int ou_tensor(const ou_handle* h, const char* name, size_t* byte_offset, int32_t* C, int32_t* T);
 /* Number of kernels the last forward enqueued, and the generic-conv launch count among them. */
 int ou_launch_stats(const ou_handle* h, int32_t* n_launches, int32_t* n_conv_launches);
-/* When set (default 1 at create if env OU_NO_GRAPH is unset: 0), intermediates are never aliased so that
- * ou_tensor() can return any of them; costs memory only. */
+/* Reserved (intermediates are never aliased in this version, so ou_tensor() can return any of them). */
 int ou_set_debug(ou_handle* h, int32_t keep_intermediates);
+/* Measurement: when enabled, every launch of the generic conv kernel in subsequent forward calls is bracketed
+ * by HIP events on the caller's stream.  ou_profile_read() synchronises them and returns, per launch, the
+ * elapsed ms, the layer's algorithmic FLOPs / bytes (reference, un-folded accounting) and the tile config. */
+int ou_profile_enable(ou_handle* h, int32_t on);
+int ou_profile_read(ou_handle* h, int32_t max_records, float* ms, double* flops, double* bytes, int32_t* cfg,
+                    int32_t* n_records);
 
 #ifdef __cplusplus
 }

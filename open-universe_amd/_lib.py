@@ -42,8 +42,8 @@ class Config(Structure):
         ("level_db", c_float),
         ("has_edm", c_int32),
         ("edm_noise", c_float),
-        ("sigma_min", c_float),
-        ("sigma_max", c_float),
+        ("sigma_min", c_double),
+        ("sigma_max", c_double),
         ("use_signal_decoupling", c_int32),
         ("signal_decoupling_act", c_int32),
         ("score", NetConfig),
@@ -98,6 +98,8 @@ def load():
         "ou_tensor": (i32, [vp, c_char_p, POINTER(sz), POINTER(i32), POINTER(i32)]),
         "ou_launch_stats": (i32, [vp, POINTER(i32), POINTER(i32)]),
         "ou_set_debug": (i32, [vp, i32]),
+        "ou_profile_enable": (i32, [vp, i32]),
+        "ou_profile_read": (i32, [vp, i32, POINTER(c_float), POINTER(c_double), POINTER(c_double), POINTER(i32), POINTER(i32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -111,7 +113,7 @@ EXPORTED_SYMBOLS = [
     "ou_version", "ou_last_error", "ou_packer_last_error", "ou_packer_create", "ou_packer_set", "ou_packer_finish",
     "ou_packer_destroy", "ou_packed_bytes", "ou_create", "ou_destroy", "ou_workspace_bytes", "ou_schedule",
     "ou_condition", "ou_score", "ou_aux_to_wav", "ou_enhance", "ou_check_device_status", "ou_plan_json",
-    "ou_packer_plan_json", "ou_tensor", "ou_launch_stats", "ou_set_debug",
+    "ou_packer_plan_json", "ou_tensor", "ou_launch_stats", "ou_set_debug", "ou_profile_enable", "ou_profile_read",
 ]
 
 _EXC = {OU_EINVAL: ValueError, OU_ENOTIMPL: NotImplementedError, OU_EMISSING: KeyError, OU_ESHAPE: ValueError,

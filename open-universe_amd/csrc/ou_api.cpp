@@ -46,6 +46,11 @@ struct ou_handle {
   // geometry of the last ou_condition (consumed by ou_score)
   int cond_B = 0, cond_T = 0;
   bool trace = false;
+  // per-launch HIP-event profiling of the generic conv kernel (bench.py roofline)
+  bool profile = false;
+  struct ProfRec { hipEvent_t a, b; double flops, bytes; int cfg; };
+  std::vector<ProfRec> prof;
+  size_t prof_used = 0;
 };
 
 namespace {
@@ -129,7 +134,23 @@ struct Runner {
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
     int cfg = -1;
+    ou_handle::ProfRec* pr = nullptr;
+    if (h->profile) {
+      if (h->prof_used == h->prof.size()) {
+        ou_handle::ProfRec r{};
+        if (hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess) h->prof.push_back(r);
+      }
+      if (h->prof_used < h->prof.size()) {
+        pr = &h->prof[h->prof_used++];
+        // algorithmic (reference, un-folded) work of this layer: dense FLOPs, activations once, weights once
+        const int kref = L.kind == CK_DOWN ? L.rate : (L.kind == CK_UP ? 1 : L.KW);
+        pr->flops = 2.0 * L.M * (double)Nq * L.Cin * kref * B;
+        pr->bytes = 4.0 * ((double)B * ((double)L.Cin * in.T + (double)L.Cout * Tout) + (double)L.M * L.Cin * kref);
+        (void)hipEventRecord(pr->a, st);
+      }
+    }
     chk(launch_conv(a, h->num_cu, st, &cfg), L.name.c_str());
+    if (pr) { pr->cfg = cfg; (void)hipEventRecord(pr->b, st); }
     if (h->trace)
       std::fprintf(stderr, "OU_TRACE conv %-64s cfg=%d M=%d Nq=%d K=%d(Cin=%d KW=%d CK=%d) stride=%d up=%d B=%d MFLOP=%.1f\n",
                    name.c_str(), cfg, L.M, Nq, L.Cin * L.KW, L.Cin, L.KW, L.CK, L.stride, L.up, B,
@@ -368,7 +389,7 @@ void schedule(const ou_config& cfg, int n_steps, double epsilon, float* sigma, d
   for (int n = 0; n < n_steps; n++) {
     int i = n_steps - 1 - n;
     float t = (i < n_steps / 2) ? (float)i * step : 1.0f - (float)(n_steps - 1 - i) * step;
-    sigma[n] = (float)cfg.sigma_min * std::pow((float)ratio, t);
+    sigma[n] = (float)cfg.sigma_min * std::pow((float)ratio, t);  // fp32 pow like torch.pow(Scalar, fp32 Tensor)
   }
 }
 
@@ -475,7 +496,11 @@ int ou_create(const ou_config* cfg, const void* weights_dev, size_t nbytes, int3
   return OU_OK;
 }
 
-void ou_destroy(ou_handle* h) { delete h; }
+void ou_destroy(ou_handle* h) {
+  if (!h) return;
+  for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  delete h;
+}
 
 int ou_workspace_bytes(const ou_handle* hc, int32_t B, int32_t T, size_t* nbytes) {
   ou_handle* h = const_cast<ou_handle*>(hc);
@@ -661,5 +686,32 @@ int ou_launch_stats(const ou_handle* h, int32_t* n_launches, int32_t* n_conv_lau
 }
 
 int ou_set_debug(ou_handle* h, int32_t keep) { (void)keep; return h ? OU_OK : OU_EINVAL; }
+
+int ou_profile_enable(ou_handle* h, int32_t on) {
+  if (!h) return OU_EINVAL;
+  h->profile = on != 0;
+  h->prof_used = 0;
+  return OU_OK;
+}
+
+int ou_profile_read(ou_handle* h, int32_t max_records, float* ms, double* flops, double* bytes, int32_t* cfg,
+                    int32_t* n_records) {
+  if (!h || !n_records) return OU_EINVAL;
+  int n = (int)h->prof_used;
+  if (n > max_records) n = max_records;
+  for (int i = 0; i < n; i++) {
+    auto& r = h->prof[i];
+    hipError_t e = hipEventSynchronize(r.b);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, r.a, r.b);
+    if (e != hipSuccess) return fail(h, OU_EHIP, hipGetErrorString(e));
+    if (ms) ms[i] = t;
+    if (flops) flops[i] = r.flops;
+    if (bytes) bytes[i] = r.bytes;
+    if (cfg) cfg[i] = r.cfg;
+  }
+  *n_records = n;
+  return OU_OK;
+}
 
 }  // extern "C"

@@ -131,6 +131,20 @@ class Universe:
         self._L.ou_launch_stats(self._handle, byref(a), byref(b))
         return a.value, b.value
 
+    def profile(self, on):
+        """Bracket every generic-conv launch of the following calls with HIP events (measurement only)."""
+        _lib.check(self._L.ou_profile_enable(self._handle, int(bool(on))), self._handle)
+
+    def profile_read(self, max_records=8192):
+        """-> list of (ms, algorithmic_flops, algorithmic_bytes, tile_cfg) per conv launch since profile(True)."""
+        ms = (c_float * max_records)()
+        fl = (ctypes.c_double * max_records)()
+        by = (ctypes.c_double * max_records)()
+        cf = (c_int32 * max_records)()
+        n = c_int32()
+        _lib.check(self._L.ou_profile_read(self._handle, max_records, ms, fl, by, cf, byref(n)), self._handle)
+        return [(ms[i], fl[i], by[i], cf[i]) for i in range(n.value)]
+
     def pad(self, x, pad=None):
         """universe.py:219-223."""
         if pad is None:

@@ -1,0 +1,141 @@
+"""
+Generates the golden fixtures in this directory by importing the REAL reference (/root/reference, build
+container only -- it never travels to the GPU box) with framework stubs (oracle/ref_import.py), loading the
+seeded synthetic weights (recipe: open_universe_amd.state_dict.synthetic_state_dict) and running the
+reference's own `Universe.enhance` / networks on CPU.
+
+Fixtures are DATA only: inputs are regenerated from seeds, outputs are stored as float32 arrays.
+    keys_<cfg>.json      ordered (key, shape, is_parameter) of the reference state dict + model_parameters() order
+    small_<cfg>.npz      reduced-width models: conditioner / score-net / enhance outputs (several option sets)
+    full_PP16.npz        UNIVERSE++ 16 kHz full size, 4 s, 8 steps (the headline configuration)
+    schedule.npz         sampler constants for N in {2, 8, 32, 64}
+Run:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import ref_import as R  # noqa: E402
+from helpers import SMALL, get_spec, synth_mix  # noqa: E402
+from open_universe_amd import state_dict as S  # noqa: E402
+
+REF_CFG = {"PP16": "default", "OR16": "universe_original", "PP24": "universepp_24k"}
+
+
+def build(name):
+    base, over = SMALL.get(name, (name, {}))
+    ov = {}
+    for k, v in over.items():
+        ov[k] = v
+        ov[k.replace("score_model", "condition_model")] = v
+    m, cfg = R.build_reference_model(REF_CFG[base], ov)
+    spec = get_spec(name)
+    sd = S.synthetic_state_dict(spec, seed=0)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("loss_") for k in missing)
+    if m.ema is not None:
+        m.ema.shadow_params = [p.clone().detach() for p in m.model_parameters()]
+    m.eval()
+    return m, spec, sd
+
+
+def noise_list(seed, n, B, T):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(B, 1, T, generator=g) for _ in range(n)]
+
+
+class NoiseGen:
+    """Stands in for torch.Generator in the reference's randn(): we monkey-patch torch.randn instead."""
+
+
+def enhance_with_noise(m, mix, noise, **kw):
+    """Run the reference's enhance with pre-drawn noise by temporarily replacing torch.randn."""
+    it = iter(noise)
+    real = torch.randn
+
+    def fake(*a, **k):
+        return next(it).clone()
+
+    torch.randn = fake
+    try:
+        with torch.no_grad():
+            return m.enhance(mix, **kw)
+    finally:
+        torch.randn = real
+
+
+def main():
+    torch.set_num_threads(8)
+    # ---- key schema
+    for name, ref in REF_CFG.items():
+        m, cfg = R.build_reference_model(ref)
+        pn = set(n for n, _ in m.named_parameters())
+        keys = [[k, list(v.shape), k in pn] for k, v in m.state_dict().items() if not k.startswith("loss_")]
+        ids = {id(p): n for n, p in m.named_parameters()}
+        order = [ids[id(p)] for p in m.model_parameters()]
+        json.dump({"keys": keys, "parameter_order": order}, open(os.path.join(HERE, f"keys_{name}.json"), "w"))
+        print("keys", name, len(keys))
+    # ---- small models
+    for name in ("PP16s", "PP16m", "OR16s", "PP24s"):
+        m, spec, sd = build(name)
+        B, T = 2, spec.tot_ds * 20 + 37
+        mix = synth_mix(spec, B, T)
+        Tp = T + (spec.tot_ds - T % spec.tot_ds)
+        out = {"B": B, "T": T}
+        with torch.no_grad():
+            xin = torch.nn.functional.pad(mix[:, None, :], ((Tp - T) // 2, (Tp - T) - (Tp - T) // 2))
+            xin = (xin - xin.mean(dim=(1, 2), keepdim=True))
+            xin = xin * (10 ** (spec.level_db / 20) / xin.std(dim=(1, 2), keepdim=True).clamp(min=1e-5))
+            cond, aux, lat = m.condition_model(xin, x_wav=xin, train=True)
+            for j, c in enumerate(cond):
+                out[f"cond{j}"] = c.numpy()
+            out["aux"] = aux.numpy()
+            out["latent"] = lat.numpy()
+            sig = torch.tensor([0.3, 1.7])
+            xs = noise_list(11, 1, B, Tp)[0] * sig[:, None, None]
+            out["score"] = m.score_model(xs, sig, cond).numpy()
+        opts = {"plain": dict(n_steps=4), "keep_rms": dict(n_steps=3, keep_rms=True),
+                "ens_median": dict(n_steps=3, ensemble=3, ensemble_stat="median"),
+                "ens_mean": dict(n_steps=3, ensemble=2, ensemble_stat="mean"),
+                "ens_sigmed": dict(n_steps=3, ensemble=3, ensemble_stat="signal_median")}
+        if spec.use_signal_decoupling:
+            opts["warm"] = dict(n_steps=5, warm_start=2)
+            opts["aux"] = dict(n_steps=4, use_aux_signal=True)
+        for tag, kw in opts.items():
+            E = kw.get("ensemble") or 1
+            nz = noise_list(7, kw["n_steps"], B * E, Tp)
+            out["enh_" + tag] = enhance_with_noise(m, mix, nz, **kw).numpy()
+        np.savez_compressed(os.path.join(HERE, f"small_{name}.npz"), **out)
+        print("small", name, {k: getattr(v, "shape", v) for k, v in out.items()})
+    # ---- full-size headline config
+    m, spec, sd = build("PP16")
+    T = 64000
+    mix = synth_mix(spec, 1, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(1028282, 8, 1, Tp)
+    enh = enhance_with_noise(m, mix, nz, n_steps=8)
+    np.savez_compressed(os.path.join(HERE, "full_PP16.npz"), enh=enh.numpy().astype(np.float32), T=T)
+    print("full PP16", enh.shape, float(enh.std()))
+    # ---- sampler constants (universe.py:301-311)
+    sch = {}
+    for N in (2, 8, 32, 64):
+        delta_t = 1.0 / (N - 1)
+        gamma = (spec.sigma_max / spec.sigma_min) ** -delta_t
+        eps = 1.3
+        sch[f"eta_{N}"] = 1 - gamma ** eps
+        sch[f"beta_{N}"] = (1 - gamma ** (2 * (eps - 1.0))) ** 0.5
+        time = torch.linspace(0, 1, N).flip(dims=[0])
+        sch[f"sigma_{N}"] = m.get_std_dev(time).numpy()
+    np.savez(os.path.join(HERE, "schedule.npz"), **sch)
+
+
+if __name__ == "__main__":
+    main()

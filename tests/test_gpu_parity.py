@@ -1,0 +1,213 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (ctypes), against the CPU oracle on the same seeded inputs,
+against the committed golden vectors of the real reference, and through size-independent properties.
+
+Gate (BASELINE.json north_star): SI-SDR(new vs reference output) >= 60 dB.  All arithmetic is fp32; the observed
+agreement is 100-130 dB, so the tests assert >= 80 dB on intermediates and >= 60 dB on end-to-end outputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import restatement as O
+from helpers import get_spec, synth_mix
+from open_universe_amd import state_dict as S
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+GATE_DB = 60.0
+
+
+def noise_list(seed, n, B, T):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(B, 1, T, generator=g) for _ in range(n)]
+
+
+_models = {}
+
+
+def get_model(name, seed=0):
+    from open_universe_amd import Universe, UniverseGAN
+
+    key = (name, seed)
+    if key not in _models:
+        spec = get_spec(name)
+        sd = S.synthetic_state_dict(spec, seed=seed)
+        cls = UniverseGAN if spec.kind == "universe_gan" else Universe
+        _models[key] = (cls(spec, state_dict=sd, device="cuda:0"), spec, sd)
+    return _models[key]
+
+
+def run_enhance(model, mix, noise, **kw):
+    a = dict(n_steps=None, epsilon=None, target=None, fake_score_snr=None, rng=None, use_aux_signal=False,
+             keep_rms=False, ensemble=None, ensemble_stat="median", warm_start=None)
+    a.update(kw)
+    return model._enhance(mix.cuda(), a["n_steps"], a["epsilon"], a["target"], a["fake_score_snr"], a["rng"],
+                          a["use_aux_signal"], a["keep_rms"], a["ensemble"], a["ensemble_stat"], a["warm_start"],
+                          [z.cuda() for z in noise] if noise is not None else None).cpu()
+
+
+def test_native_library_is_loaded():
+    """The extension must be the thing that runs: in-tree .so mapped into this process, device = gfx950."""
+    model, spec, sd = get_model("PP16s")
+    maps = open("/proc/self/maps").read()
+    assert "libouniverse.so" in maps
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+@pytest.mark.parametrize("name", ["PP16s", "PP16m", "OR16s", "PP24s"])
+def test_networks_vs_oracle_intermediates(name):
+    model, spec, sd = get_model(name)
+    sdict = spec.to_dict()
+    B, T = 2, spec.tot_ds * 20
+    mix = synth_mix(spec, B, T)
+    xin = O.normalize(mix[:, None, :], spec.level_db)
+    taps = {}
+    c_ref, y_ref, h_ref = O.conditioner_network(sd, "condition_model", sdict, xin, taps=taps)
+    cond, aux, lat = model.condition_model(xin.cuda(), train=True)
+    for b in range(B):  # the stored mel is un-normalised: per-utterance scale, so compare per batch element
+        assert O.si_sdr(taps["mel"][b], model.tensor("cond.mel")[b].cpu()) > 80
+    checks = [("x_mel", "cond.melblock.v"), ("enc_sum", "cond.enc_sum"), ("gru", "cond.gru")]
+    checks += [(f"st{i}", f"cond.st{i}") for i in range(len(spec.score.rate_factors) - 1)]
+    for tap, nm in checks:
+        assert O.si_sdr(taps[tap], model.tensor(nm).cpu()) > 80, nm
+    for j, (a, b) in enumerate(zip(c_ref, cond)):
+        assert a.shape == b.shape and O.si_sdr(a, b.cpu()) > 80, j
+    assert O.si_sdr(y_ref, aux.cpu()) > 80 and O.si_sdr(h_ref, lat.cpu()) > 80
+    if spec.use_signal_decoupling:
+        assert O.si_sdr(O.aux_to_wav(sd, sdict, y_ref), model.aux_to_wav().cpu()) > 80
+    # score network, per-batch sigma (the operator seam score_model(x, sigma, cond))
+    g = torch.Generator().manual_seed(5)
+    sig = torch.tensor([0.3, 1.7])
+    xs = torch.randn(xin.shape, generator=g) * sig[:, None, None]
+    taps = {}
+    if spec.edm_noise is not None:
+        w = O.edm_weights(sdict, sig)
+        O.score_network(sd, "_edm_model", sdict, w["in"][:, None, None] * xs, w["noise"] * sig, c_ref, taps=taps)
+    else:
+        O.score_network(sd, "score_model", sdict, xs, sig, c_ref, taps=taps)
+    s_hip = model.score_model(xs.cuda(), sig).cpu()
+    nb = len(spec.score.rate_factors) + int(spec.score.extra_conv_block)
+    assert torch.equal(taps["input_conv"], model.tensor("score.in").cpu()) or \
+        O.si_sdr(taps["input_conv"], model.tensor("score.in").cpu()) > 120
+    for i in range(nb):
+        assert O.si_sdr(taps[f"enc{i}.v"], model.tensor(f"score.enc{i}.v").cpu()) > 80, i
+        assert O.si_sdr(taps[f"dec{i}.v"], model.tensor(f"score.dec{i}.v").cpu()) > 80, i
+    assert O.si_sdr(O.score_model(sd, sdict, xs, sig, c_ref), s_hip) > 80
+
+
+@pytest.mark.parametrize("name", ["PP16s", "PP16m", "OR16s", "PP24s"])
+def test_enhance_vs_reference_goldens(name):
+    """End-to-end against outputs of the REAL reference (tests/golden/small_*.npz), ragged length T % tot_ds != 0."""
+    gold = np.load(os.path.join(G, f"small_{name}.npz"))
+    model, spec, sd = get_model(name)
+    B, T = int(gold["B"]), int(gold["T"])
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    opts = {"plain": dict(n_steps=4), "keep_rms": dict(n_steps=3, keep_rms=True),
+            "ens_median": dict(n_steps=3, ensemble=3, ensemble_stat="median"),
+            "ens_mean": dict(n_steps=3, ensemble=2, ensemble_stat="mean"),
+            "ens_sigmed": dict(n_steps=3, ensemble=3, ensemble_stat="signal_median")}
+    if spec.use_signal_decoupling:
+        opts["warm"] = dict(n_steps=5, warm_start=2)
+        opts["aux"] = dict(n_steps=4, use_aux_signal=True)
+    for tag, kw in opts.items():
+        if tag == "keep_rms" and False:
+            continue
+        E = kw.get("ensemble") or 1
+        nz = noise_list(7, kw["n_steps"], B * E, Tp)
+        out = run_enhance(model, mix, nz, **kw)
+        ref = torch.from_numpy(gold["enh_" + tag])
+        assert out.shape == ref.shape
+        assert O.si_sdr(ref, out) >= GATE_DB, (tag, O.si_sdr(ref, out))
+
+
+def test_full_size_headline_config_vs_reference_golden():
+    """UNIVERSE++ 16 kHz, 4 s, 8 steps, B=1 (BASELINE.json configs[1]) against the reference's own output."""
+    gold = np.load(os.path.join(G, "full_PP16.npz"))
+    model, spec, sd = get_model("PP16")
+    T = int(gold["T"])
+    mix = synth_mix(spec, 1, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    out = run_enhance(model, mix, noise_list(1028282, 8, 1, Tp), n_steps=8)
+    snr = O.si_sdr(torch.from_numpy(gold["enh"]), out)
+    assert snr >= GATE_DB, snr
+    # properties that do not depend on the oracle
+    assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6  # peak guard, universe.py:356-357
+    out2 = run_enhance(model, mix, noise_list(1028282, 8, 1, Tp), n_steps=8)
+    assert torch.equal(out, out2)  # deterministic given the noise
+
+
+def test_batch_independence_and_rank_conventions():
+    """Utterances are independent (what the multi-GPU sharding relies on): enhancing a batch equals enhancing each
+    utterance alone with its own noise slice; 1-D / 2-D / 3-D inputs keep their rank (universe.py:251-257, 370-375)."""
+    model, spec, sd = get_model("PP16m")
+    B, T = 3, 2000
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(3, 3, B, Tp)
+    full = run_enhance(model, mix, nz, n_steps=3)
+    assert full.shape == (B, T)
+    for b in range(B):
+        one = run_enhance(model, mix[b], [z[b:b + 1] for z in nz], n_steps=3)
+        assert one.shape == (T,)
+        assert O.si_sdr(full[b], one) > 100
+    assert run_enhance(model, mix[:, None, :], nz, n_steps=3).shape == (B, 1, T)
+    with pytest.raises(ValueError):
+        model.enhance(mix.cuda()[None, :, None, :])
+    with pytest.raises(NotImplementedError):
+        model.enhance(mix.cuda(), ensemble=2, ensemble_stat="bogus")
+
+
+def test_rng_draw_order_matches_reference_convention():
+    """enhance(rng=...) draws x0 then z_0..z_{N-2} with torch.randn on the model device: replaying the same
+    generator by hand gives the identical result, and the generator state advances across calls
+    (bin/enhance.py:147-166 shares one generator over all files)."""
+    model, spec, sd = get_model("PP16s")
+    B, T = 1, 1600
+    mix = synth_mix(spec, B, T).cuda()
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    g1 = torch.Generator(device="cuda").manual_seed(1028282)
+    a = model.enhance(mix, n_steps=3, rng=g1)
+    b = model.enhance(mix, n_steps=3, rng=g1)
+    g2 = torch.Generator(device="cuda").manual_seed(1028282)
+    nz = [torch.randn((B, 1, Tp), device="cuda", generator=g2) for _ in range(6)]
+    a2 = run_enhance(model, mix.cpu(), [z.cpu() for z in nz[:3]], n_steps=3)
+    b2 = run_enhance(model, mix.cpu(), [z.cpu() for z in nz[3:]], n_steps=3)
+    assert torch.equal(a.cpu(), a2) and torch.equal(b.cpu(), b2) and not torch.equal(a, b)
+
+
+def test_oracle_score_mode_bypasses_network():
+    """target=... (universe.py:278-298): analytic score, no network; parity with the oracle on shared CPU noise is
+    not possible (device RNG), so check the defining property: with a high-SNR fake score the sampler converges
+    to the (normalised) target."""
+    model, spec, sd = get_model("OR16s")
+    mix = synth_mix(spec, 2, 1600)
+    tgt = synth_mix(spec, 2, 1600, seed=77)
+    out = model.enhance(mix[:, None, :].cuda(), n_steps=16, target=tgt[:, None, :].cuda(), fake_score_snr=60.0,
+                        rng=torch.Generator(device="cuda").manual_seed(0)).cpu()
+    t = tgt[:, None, :] - tgt[:, None, :].mean(dim=-1, keepdim=True)
+    assert O.si_sdr(t, out) > 25
+
+
+def test_c_abi_error_codes():
+    """Status codes, never exceptions across the ABI: too-small workspace, T not a multiple of tot_ds, bad n_steps."""
+    import ctypes
+    from open_universe_amd import _lib
+
+    model, spec, sd = get_model("PP16s")
+    L = model._L
+    x = torch.zeros(1, 1, spec.tot_ds * 4, device="cuda")
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = L.ou_condition(model._handle, ctypes.c_void_p(x.data_ptr()), 1, x.shape[-1], ctypes.c_void_p(ws.data_ptr()),
+                        ws.numel(), st)
+    assert rc == _lib.OU_ENOMEM
+    rc = L.ou_condition(model._handle, ctypes.c_void_p(x.data_ptr()), 1, spec.tot_ds * 4 - 1,
+                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), st)
+    assert rc == _lib.OU_EINVAL
+    with pytest.raises(ValueError):
+        model.enhance(x[0, 0], n_steps=1)
+    with pytest.raises(ValueError):
+        model.enhance(x[0, 0], n_steps=5, warm_start=7)
+    torch.cuda.synchronize()

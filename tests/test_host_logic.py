@@ -1,0 +1,125 @@
+"""CPU: host-side logic -- config parsing, checkpoint / EMA resolution, loader error behaviour, CLI flag
+derivation, C-ABI schedule, sharding."""
+import argparse
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from helpers import get_spec
+from open_universe_amd import _lib, inference_utils
+from open_universe_amd import config as C
+from open_universe_amd import distributed as D
+from open_universe_amd import state_dict as S
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_config_yaml_roundtrip_and_float_coercion(tmp_path):
+    cfg = C.builtin_config("OR16")
+    cfg["model"]["diffusion"]["sigma_min"] = "5e-4"  # PyYAML reads 5e-4 as a string
+    cfg["model"]["condition_model"]["rate_factors"] = "${model.score_model.rate_factors}"
+    p = tmp_path / "config.yaml"
+    yaml.safe_dump(cfg, open(p, "w"))
+    spec = C.spec_from_config(C.load_config(p))
+    assert spec.sigma_min == 5e-4 and spec.cond.rate_factors == [2, 4, 4, 5] and spec.kind == "universe"
+    assert spec.diff_kwargs.n_steps == 8 and spec.diff_kwargs.get("epsilon") == 1.3
+    with pytest.raises(ValueError):
+        C.spec_from_config({"model": dict(cfg["model"], _target_="foo.Bar")})
+
+
+def test_inference_state_dict_uses_ema_and_ignores_loss_keys():
+    spec = get_spec("PP16s")
+    sd = S.synthetic_state_dict(spec, seed=0)
+    ckpt = S.checkpoint_from_state_dict(spec, sd, with_ema=True, ema_jitter=0.01)
+    ckpt["state_dict"]["loss_mpd.foo"] = torch.zeros(3)
+    out = S.inference_state_dict(spec, ckpt)
+    names = S.parameter_names(spec)
+    assert torch.equal(out[names[5]], ckpt["ema"]["shadow_params"][5])
+    assert not torch.equal(out[names[5]], sd[names[5]])
+    buf = "condition_model.input_mel.mel_spec.mel_scale.fb"
+    assert torch.equal(out[buf], sd[buf]) and "loss_mpd.foo" not in out
+    bad = dict(ckpt)
+    bad["ema"] = dict(ckpt["ema"], shadow_params=ckpt["ema"]["shadow_params"][:-1])
+    with pytest.raises(ValueError):
+        S.inference_state_dict(spec, bad)
+    miss = {"state_dict": {k: v for k, v in sd.items() if "output_conv" not in k}}
+    with pytest.raises(KeyError):
+        S.inference_state_dict(spec, miss)
+
+
+def test_load_model_error_behaviour(tmp_path):
+    spec = get_spec("PP16s")
+    sd = S.synthetic_state_dict(spec, seed=0)
+    d = tmp_path / "exp" / "checkpoints"
+    d.mkdir(parents=True)
+    torch.save(S.checkpoint_from_state_dict(spec, sd), d / "weights.ckpt")
+    with pytest.raises(ValueError, match="Could not find the configuration"):  # model_loader.py:45-47
+        inference_utils.load_model(d / "weights.ckpt")
+    yaml.safe_dump(C.builtin_config("PP16", **{"score_model.n_channels": 8}), open(d / "config.yaml", "w"))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no HIP device|HIP"):  # loud failure, no CPU fallback
+            inference_utils.load_model(d / "weights.ckpt")
+        with pytest.raises(RuntimeError):
+            inference_utils.load_model(d / "weights.ckpt", device="cpu")
+    with pytest.raises(Exception):  # neither a file nor a reachable HF repo (no network)
+        inference_utils.load_model("no-such-org/no-such-model:rev")
+
+
+def test_add_enhance_arguments_mirrors_signature():
+    from open_universe_amd.universe import Universe
+
+    class Dummy:
+        enhance = Universe.enhance
+        diff_kwargs = get_spec("PP16").diff_kwargs
+
+    parser = inference_utils.add_enhance_arguments(Dummy(), argparse.ArgumentParser())
+    args = parser.parse_args(["--n_steps", "16", "--ensemble_stat", "mean"])
+    assert args.n_steps == 16 and args.epsilon == 1.3 and args.ensemble_stat == "mean" and args.keep_rms is None
+    for k in ("target", "fake_score_snr", "rng", "use_aux_signal", "ensemble", "warm_start"):
+        assert hasattr(args, k)
+    with pytest.raises(ValueError):
+        inference_utils.add_enhance_arguments(object(), argparse.ArgumentParser())
+
+
+def test_c_abi_schedule_matches_reference_constants(built_lib):
+    gold = np.load(os.path.join(G, "schedule.npz"))
+    cfg = _lib.make_config(get_spec("PP16"))
+    for N in (2, 8, 32, 64):
+        sig = (ctypes.c_float * N)()
+        eta, beta = ctypes.c_double(), ctypes.c_double()
+        assert built_lib.ou_schedule(ctypes.byref(cfg), N, 1.3, sig, ctypes.byref(eta), ctypes.byref(beta)) == 0
+        np.testing.assert_allclose(np.array(sig[:]), gold[f"sigma_{N}"], rtol=2e-6)
+        assert abs(eta.value - float(gold[f"eta_{N}"])) < 1e-14 and abs(beta.value - float(gold[f"beta_{N}"])) < 1e-14
+    assert built_lib.ou_schedule(ctypes.byref(cfg), 1, 1.3, sig, ctypes.byref(eta), ctypes.byref(beta)) == _lib.OU_EINVAL
+
+
+def test_c_abi_rejects_unsupported_configs(built_lib):
+    spec = get_spec("PP16s")
+    spec.score.n_channels = 6  # GRU hidden size 48: not a multiple of 64
+    spec.cond.n_channels = 6
+    n = ctypes.c_size_t()
+    cfg = _lib.make_config(spec)
+    assert built_lib.ou_packed_bytes(ctypes.byref(cfg), ctypes.byref(n)) == _lib.OU_ENOTIMPL
+    with pytest.raises(NotImplementedError):
+        _lib.check(_lib.OU_ENOTIMPL)
+    cfg = _lib.make_config(get_spec("PP16s"))
+    h = ctypes.c_void_p()
+    # without a HIP device ou_create must fail loudly (no CPU path)
+    if not torch.cuda.is_available():
+        dummy = (ctypes.c_float * 4)()
+        assert built_lib.ou_packed_bytes(ctypes.byref(cfg), ctypes.byref(n)) == 0
+        rc = built_lib.ou_create(ctypes.byref(cfg), dummy, n.value, 0, ctypes.byref(h))
+        assert rc == _lib.OU_EHIP
+
+
+def test_shard_utterances_lpt():
+    lengths = [50, 10, 40, 30, 20, 60, 15]
+    sh = D.shard_utterances(lengths, 3)
+    assert sorted(i for s in sh for i in s) == list(range(7))
+    assert sh[0][0] == 5 and sh[1][0] == 0 and sh[2][0] == 2  # longest first, dealt round-robin
+    loads = [sum(lengths[i] for i in s) for s in sh]
+    assert max(loads) - min(loads) <= max(lengths)

@@ -1,0 +1,52 @@
+"""CPU, build container only: the oracle and the key schema against the live imported reference.
+Skipped where /root/reference does not exist (e.g. on the GPU box) -- the committed goldens cover that case."""
+import pytest
+import torch
+
+import ref_import as R
+import restatement as O
+from helpers import get_spec, synth_mix
+from open_universe_amd import config as C
+from open_universe_amd import state_dict as S
+
+pytestmark = pytest.mark.skipif(not R.reference_available(), reason="reference checkout not present")
+
+
+def _ref(name, ref_cfg, width):
+    ov = {"score_model.n_channels": width, "condition_model.n_channels": width}
+    m, cfg = R.build_reference_model(ref_cfg, ov)
+    spec = C.spec_from_config(C.builtin_config(name, **{"score_model.n_channels": width}))
+    assert spec.to_dict() == C.spec_from_config({"model": cfg}).to_dict()
+    sd = S.synthetic_state_dict(spec, seed=5)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("loss_") for k in missing)
+    if m.ema is not None:
+        m.ema.shadow_params = [p.clone().detach() for p in m.model_parameters()]
+    m.eval()
+    return m, spec, sd
+
+
+@pytest.mark.parametrize("name,ref_cfg", [("PP16", "default"), ("OR16", "universe_original"), ("PP24", "universepp_24k")])
+def test_oracle_enhance_matches_live_reference(name, ref_cfg):
+    m, spec, sd = _ref(name, ref_cfg, 8)
+    mix = synth_mix(spec, 2, spec.tot_ds * 10 + 13)
+    with torch.no_grad():
+        ref = m.enhance(mix, n_steps=3, rng=torch.Generator().manual_seed(3))
+    out = O.enhance(sd, spec.to_dict(), mix, n_steps=3, rng=torch.Generator().manual_seed(3))
+    assert O.si_sdr(ref, out) > 100
+    # oracle-score diagnostic mode bypasses the network: bit-exact
+    tgt = 0.5 * mix[:, None, :]
+    with torch.no_grad():
+        ref = m.enhance(mix[:, None, :], n_steps=3, target=tgt, fake_score_snr=10.0, rng=torch.Generator().manual_seed(3))
+    out = O.enhance(sd, spec.to_dict(), mix[:, None, :], n_steps=3, target=tgt, fake_score_snr=10.0,
+                    rng=torch.Generator().manual_seed(3))
+    assert torch.equal(ref, out)
+
+
+def test_buffers_bit_exact_vs_reference():
+    m, cfg = R.build_reference_model("default")
+    sd = m.state_dict()
+    spec = get_spec("PP16")
+    for k, shape, is_p in S.model_schema(spec):
+        if not is_p:
+            assert torch.equal(sd[k], S.buffer_value(k, shape)), k
