@@ -162,6 +162,10 @@ int ou_set_debug(ou_handle* h, int32_t keep_intermediates);
  * by HIP events on the caller's stream.  ou_profile_read() synchronises them and returns, per launch, the
  * elapsed ms, the layer's algorithmic FLOPs / bytes (reference, un-folded accounting) and the tile config. */
 int ou_profile_enable(ou_handle* h, int32_t on);
+/* Tuning aid: time ONE packed conv layer (by its reference state-dict prefix) on synthetic data, optionally forcing
+ * the tile configuration / chunks-per-stage; ms per launch from HIP events. */
+int ou_bench_conv(ou_handle* h, const char* layer, int32_t B, int32_t Tin, int32_t cfg, int32_t sc, int32_t with_res,
+                  int32_t iters, void* ws, size_t ws_bytes, ou_stream_t stream, float* ms_per_iter, int32_t* cfg_used);
 int ou_profile_read(ou_handle* h, int32_t max_records, float* ms, double* flops, double* bytes, int32_t* cfg,
                     int32_t* n_records);
 

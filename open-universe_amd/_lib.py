@@ -99,6 +99,7 @@ def load():
         "ou_launch_stats": (i32, [vp, POINTER(i32), POINTER(i32)]),
         "ou_set_debug": (i32, [vp, i32]),
         "ou_profile_enable": (i32, [vp, i32]),
+        "ou_bench_conv": (i32, [vp, c_char_p, i32, i32, i32, i32, i32, i32, vp, sz, vp, POINTER(c_float), POINTER(i32)]),
         "ou_profile_read": (i32, [vp, i32, POINTER(c_float), POINTER(c_double), POINTER(c_double), POINTER(i32), POINTER(i32)]),
     }
     for name, (res, args) in sig.items():
@@ -113,7 +114,7 @@ EXPORTED_SYMBOLS = [
     "ou_version", "ou_last_error", "ou_packer_last_error", "ou_packer_create", "ou_packer_set", "ou_packer_finish",
     "ou_packer_destroy", "ou_packed_bytes", "ou_create", "ou_destroy", "ou_workspace_bytes", "ou_schedule",
     "ou_condition", "ou_score", "ou_aux_to_wav", "ou_enhance", "ou_check_device_status", "ou_plan_json",
-    "ou_packer_plan_json", "ou_tensor", "ou_launch_stats", "ou_set_debug", "ou_profile_enable", "ou_profile_read",
+    "ou_packer_plan_json", "ou_tensor", "ou_launch_stats", "ou_set_debug", "ou_profile_enable", "ou_profile_read", "ou_bench_conv",
 ]
 
 _EXC = {OU_EINVAL: ValueError, OU_ENOTIMPL: NotImplementedError, OU_EMISSING: KeyError, OU_ESHAPE: ValueError,

@@ -46,6 +46,10 @@ struct ou_handle {
   // geometry of the last ou_condition (consumed by ou_score)
   int cond_B = 0, cond_T = 0;
   bool trace = false;
+  int last_cfg = -1;
+  long long* tstamps = nullptr;
+  std::map<size_t, float> alphas;  // host copies of the PReLU slopes (blob offset -> value)
+  int force_cfg = -1, force_sc = 0;  // micro-benchmark overrides (ou_bench_conv)
   // per-launch HIP-event profiling of the generic conv kernel (bench.py roofline)
   bool profile = false;
   struct ProfRec { hipEvent_t a, b; double flops, bytes; int cfg; };
@@ -118,21 +122,25 @@ struct Runner {
     bool act = true;  // apply the layer's PReLU prologue (if it has one)
   };
 
-  Tensor conv(const ConvL& L, const Tensor& in, const std::string& name, const Epi& e) {
+  Tensor conv(const ConvL& L, const Tensor& in, const std::string& name, const Epi& e, const Tensor* dst = nullptr) {
     int Nq, Tout;
     if (L.stride > 1) { Nq = in.T / L.stride; Tout = Nq; }
     else { Nq = in.T; Tout = in.T * L.up; }
-    Tensor out = alloc(name, L.Cout, Tout);
+    Tensor out = dst ? *dst : alloc(name, L.Cout, Tout);
     if (dry || !ok()) return out;
     ConvArgs a;
     a.x = in.p; a.w = W(L.w_off); a.bias = W(L.b_off); a.y = out.p;
     a.in_scale = e.in_scale;
-    a.alpha = (L.act && e.act) ? W(L.a_off) : nullptr;
+    a.act = (L.act && e.act) ? 1 : 0;
+    a.alpha_val = a.act ? h->alphas[L.a_off] : 0.f;
     a.add = e.add; a.add_scale = e.add_scale;
     a.film = e.film; a.film_bstride = e.film_bstride;
     a.res = e.res; a.res_scale = e.res_scale;
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
+    a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
+    { const char* d = std::getenv("OU_DBG"); a.dbg = d ? std::atoi(d) : 0; }
+    a.tstamps = h->tstamps;
     int cfg = -1;
     ou_handle::ProfRec* pr = nullptr;
     if (h->profile) {
@@ -151,6 +159,7 @@ struct Runner {
     }
     chk(launch_conv(a, h->num_cu, st, &cfg), L.name.c_str());
     if (pr) { pr->cfg = cfg; (void)hipEventRecord(pr->b, st); }
+    h->last_cfg = cfg;
     if (h->trace)
       std::fprintf(stderr, "OU_TRACE conv %-64s cfg=%d M=%d Nq=%d K=%d(Cin=%d KW=%d CK=%d) stride=%d up=%d B=%d MFLOP=%.1f\n",
                    name.c_str(), cfg, L.M, Nq, L.Cin * L.KW, L.Cin, L.KW, L.CK, L.stride, L.up, B,
@@ -306,14 +315,10 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
     if (!r.dry && r.ok())
       r.chk(hipMemcpyAsync(P.cond[j].p, bo.c1.p, (size_t)r.B * bo.c1.C * bo.c1.T * 4, hipMemcpyDeviceToDevice, r.st), "cond copy");
     // score.py:208  sc = signal_cond_proj_j(cond_j): independent of x and sigma -> computed once here
-    if (!r.dry && r.ok()) {
-      const ConvL& S = m.s_sig[j];
-      ConvArgs a;
-      a.x = bo.c1.p; a.w = r.W(S.w_off); a.bias = r.W(S.b_off); a.y = P.sc[j].p;
-      a.B = r.B; a.Cin = S.Cin; a.Tin = bo.c1.T; a.Cout = S.Cout; a.M = S.M; a.Mp = S.Mp; a.KW = 1; a.stride = 1;
-      a.pad = 0; a.up = 1; a.CK = S.CK; a.Nq = bo.c1.T; a.Tout = bo.c1.T;
-      r.chk(launch_conv(a, r.h->num_cu, r.st), S.name.c_str());
-      r.h->n_conv++;
+    {
+      Runner::Epi es;
+      es.act = false;
+      r.conv(m.s_sig[j], bo.c1, "cond.sc" + std::to_string(j), es, &P.sc[j]);
     }
   }
   if (!r.dry && r.ok())
@@ -490,6 +495,25 @@ int ou_create(const ou_config* cfg, const void* weights_dev, size_t nbytes, int3
   h->device = device;
   h->W = (const float*)weights_dev;
   (void)hipSetDevice(device);
+  {  // host copies of the conv PReLU slopes: passed to the kernels by value
+    std::vector<const ConvL*> all;
+    auto addb = [&](const BlockL& b) { if (b.dir) all.push_back(&b.rc); all.push_back(&b.c1); all.push_back(&b.c2); all.push_back(&b.c3); };
+    const Model& m = h->m;
+    for (auto& b : m.s_enc) addb(b);
+    for (auto& b : m.s_dec) addb(b);
+    addb(m.c_melblock);
+    for (auto& b : m.c_enc) addb(b);
+    for (auto& l : m.c_st) all.push_back(&l);
+    addb(m.c_cb1); addb(m.c_cb2); addb(m.c_decin);
+    for (auto& b : m.c_dec) addb(b);
+    for (auto* l : all) {
+      if (!l->act) continue;
+      float v = 0.f;
+      he = hipMemcpy(&v, h->W + l->a_off, sizeof(float), hipMemcpyDeviceToHost);
+      if (he != hipSuccess) { delete h; return fail(nullptr, OU_EHIP, hipGetErrorString(he)); }
+      h->alphas[l->a_off] = v;
+    }
+  }
   he = init_conv_kernels();
   if (he != hipSuccess) { delete h; return fail(nullptr, OU_EHIP, hipGetErrorString(he)); }
   *out = h;
@@ -686,6 +710,59 @@ int ou_launch_stats(const ou_handle* h, int32_t* n_launches, int32_t* n_conv_lau
 }
 
 int ou_set_debug(ou_handle* h, int32_t keep) { (void)keep; return h ? OU_OK : OU_EINVAL; }
+
+// Micro-benchmark of ONE packed conv layer (measurement / tuning only): runs it `iters` times on random-ish data in
+// the caller's workspace with HIP events around the batch; cfg/sc < 0: the launcher's own choice.
+int ou_bench_conv(ou_handle* h, const char* layer, int32_t B, int32_t Tin, int32_t cfg, int32_t sc, int32_t with_res,
+                  int32_t iters, void* ws, size_t ws_bytes, ou_stream_t stream, float* ms_per_iter, int32_t* cfg_used) {
+  if (!h || !layer || !ws || !ms_per_iter) return fail(h, OU_EINVAL, "bad argument");
+  const Model& m = h->m;
+  std::vector<const ConvL*> all;
+  auto addb = [&](const BlockL& b) { if (b.dir) all.push_back(&b.rc); all.push_back(&b.c1); all.push_back(&b.c2); all.push_back(&b.c3); };
+  for (auto& b : m.s_enc) addb(b);
+  for (auto& b : m.s_dec) addb(b);
+  for (auto& l : m.s_sig) all.push_back(&l);
+  all.push_back(&m.s_gru.proj); all.push_back(&m.c_melconv); addb(m.c_melblock);
+  for (auto& b : m.c_enc) addb(b);
+  for (auto& l : m.c_st) all.push_back(&l);
+  all.push_back(&m.c_gru0.proj); all.push_back(&m.c_gru1.proj);
+  addb(m.c_cb1); addb(m.c_cb2); addb(m.c_decin);
+  for (auto& b : m.c_dec) addb(b);
+  const ConvL* L = nullptr;
+  for (auto* l : all) if (l->name == layer) L = l;
+  if (!L) return fail(h, OU_EMISSING, std::string("no such conv layer: ") + layer);
+  hipStream_t st = (hipStream_t)stream;
+  Runner r(h, ws, ws_bytes, false, st, B);
+  auto keep = h->tensors;
+  Tensor in = r.alloc("", L->Cin, Tin);
+  if (r.oom) return finish(h, r);
+  r.chk(hipMemsetAsync(in.p, 0x3c, (size_t)B * L->Cin * Tin * 4, st), "fill");
+  h->force_cfg = cfg; h->force_sc = sc < 0 ? 0 : sc;
+  if (std::getenv("OU_TS")) h->tstamps = (long long*)((char*)ws + ws_bytes - (16u << 20));
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  size_t mark = r.off;
+  Runner::Epi e;
+  Tensor out = r.conv(*L, in, "", e);  // warm-up + output allocation
+  if (with_res) e.res = out.p;
+  for (int w = 0; w < 2 && r.ok(); w++) { r.off = mark; r.conv(*L, in, "", e); }
+  (void)hipEventRecord(e0, st);
+  for (int i = 0; i < iters && r.ok(); i++) { r.off = mark; r.conv(*L, in, "", e); }
+  (void)hipEventRecord(e1, st);
+  h->force_cfg = -1; h->force_sc = 0;
+  h->tstamps = nullptr;
+  h->tensors = keep;
+  int rc = finish(h, r);
+  if (rc == OU_OK) {
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *ms_per_iter = ms / (iters > 0 ? iters : 1);
+    if (cfg_used) *cfg_used = h->last_cfg;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
+}
 
 int ou_profile_enable(ou_handle* h, int32_t on) {
   if (!h) return OU_EINVAL;

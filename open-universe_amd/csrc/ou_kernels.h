@@ -16,7 +16,8 @@ struct ConvArgs {
   const float* bias = nullptr;    // [Cout]
   float* y = nullptr;             // (B, Cout, Tout)
   const float* in_scale = nullptr;  // [B] or null
-  const float* alpha = nullptr;     // PReLU slope (device scalar) or null
+  int act = 0;                      // PReLU prologue on/off
+  float alpha_val = 0.f;            // its slope (by value: no dependent scalar load at kernel entry)
   const float* add = nullptr;       // (B, Cout, Tout) or null
   const float* film = nullptr;      // gamma at film[b*film_bstride + co], beta at [.. + Cout + co]
   const float* res = nullptr;       // (B, Cout, Tout) or null
@@ -27,6 +28,10 @@ struct ConvArgs {
   int Tout = 0;  // output length (<= Nq*up)
   unsigned magic_span[3] = {0, 0, 0};  // filled by launch_conv: 2^32/span + 1 for BN = 128 / 64 / 32
   unsigned magic_up = 0;               // 2^32/up + 1 (0 when up == 1)
+  int SC = 1;                          // filled by launch_conv: packed chunks per pipeline stage
+  int force_cfg = -1, force_sc = 0;    // tuning overrides (ou_bench_conv)
+  int dbg = 0;                         // phase ablation switches (tuning only)
+  long long* tstamps = nullptr;        // per-wave phase cycle counts (tuning only)
 };
 // returns hipSuccess or the launch error; `cfg_out` (optional) receives the tile configuration index used
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out = nullptr);

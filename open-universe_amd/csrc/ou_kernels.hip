@@ -22,35 +22,51 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   Register-prefetched double-buffered LDS staging: one barrier per channel chunk.
 // =========================================================================================================
 constexpr int CONV_NT = 256;
-constexpr int CONV_MAXX = 16;  // X-tile floats per thread  (CK*span <= 4096)
-constexpr int CONV_MAXW = 6;   // W-tile float4 per thread  (CK*KW*BM <= 6144)
+constexpr int CONV_MAXX = 16;  // X-tile floats per thread  (SC*CK*span <= 4096)
 
-template <int TM, int TN, int WM, int WN, int WK>
+// Pipeline stage = SC consecutive packed chunks = SCK = SC*CK input channels.
+// LDS images of a stage:
+//   Xs[SCK][span]            activations incl. halo (PReLU / input scale applied while staging)
+//   Ws[KW][SCK][BM]          weights, re-ordered tap-major while staging (global order is [chunk][tap][CK])
+// so that for a fixed tap both MFMA operands advance by a constant stride from one channel pair to the next:
+//   A(tap, I) = Ws[(tap*SCK + 2I + half)*BM + m],  B(tap, I) = Xs[(2I + half)*span + n*stride + tap]
+// The k-loop is tap-outer / channel-pair-inner; the WK waves of a split-K block take pairs I = kw, kw+WK, ...
+// Fragment groups of U steps are software-pipelined (reads of group g+1 issued before the MFMAs of group g).
+template <int TM, int TN, int WM, int WN, int WK, int CONV_MAXW, int U>
 __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
   static_assert(WM * WN * WK == 4, "4 waves per block");
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar step math
   const int kw = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, b = blockIdx.z;
 
-  const int KW = p.KW, CK = p.CK, stride = p.stride;
+  const int KW = p.KW, CK = p.CK, stride = p.stride, SC = p.SC;
   const int span = (BN - 1) * stride + KW;
-  const int xt = CK * span;               // X tile elements
+  const int SCK = SC * CK;                // input channels per stage (power of two)
+  const int lck = 31 - __clz(CK), lsck = 31 - __clz(SCK);
+  const int xt = SCK * span;              // X tile elements
   const int xt_al = (xt + 3) & ~3;        // keep the W tile 16-B aligned
-  const int KC = CK * KW;                 // reduction rows per chunk
-  const int wt4 = KC * (BM / 4);          // W tile float4 count
+  const int KCs = SCK * KW;               // weight rows per stage
+  const int wt4 = KCs * (BM / 4);         // W tile float4 count
   float* Xs = smem;                       // [2][xt_al]
-  float* Ws = smem + 2 * xt_al;           // [2][KC*BM]
-  const int nchunks = p.Cin / CK;
+  float* Ws = smem + 2 * xt_al;           // [2][KCs*BM]
+  float* Zs = Ws + 2 * (size_t)KCs * BM;  // [2*BM] zeros: the A operand of k-steps past the end
+  for (int i = tid; i < 2 * BM; i += CONV_NT) Zs[i] = 0.f;
+  const int nstages = p.Cin / SCK;
+
+  long long tsv[8];
+  const bool ts_on = p.tstamps != nullptr;
+  if (ts_on) tsv[0] = __builtin_readcyclecounter();
+  long long t_mma = 0, t_wait = 0;
 
   const float* xb = p.x + (size_t)b * p.Cin * p.Tin;
-  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
-  const bool act = p.alpha != nullptr;
-  const float alpha = act ? *p.alpha : 0.f;
+  const bool act = p.act != 0;
+  const float alpha = p.alpha_val;
 
-  // chunk-invariant gather offsets of this thread's X-tile elements (-1: zero padding)
+  // stage-invariant gather offsets of this thread's X-tile elements (-1: zero padding)
   int goff[CONV_MAXX];
 #pragma unroll
   for (int i = 0; i < CONV_MAXX; i++) {
@@ -64,28 +80,36 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
     }
     goff[i] = g;
   }
+  // ... and of its W-tile float4s: LDS row (tap, cl) <- packed row (sub*KW + tap)*CK + l,  cl = sub*CK + l
+  int woff[CONV_MAXW];
+#pragma unroll
+  for (int i = 0; i < CONV_MAXW; i++) {
+    int f = tid + i * CONV_NT;
+    int row = f / (BM / 4), c4 = f % (BM / 4);
+    int tap = row >> lsck, cl = row & (SCK - 1);
+    int sub = cl >> lck, l = cl & (CK - 1);
+    woff[i] = ((sub * KW + tap) * CK + l) * p.Mp + c4 * 4;
+  }
 
   float xr[CONV_MAXX];
   f32x4 wr[CONV_MAXW];
+  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
 
-  auto load_chunk = [&](int c) {
-    const float* xc = xb + (size_t)c * CK * p.Tin;
+  auto load_stage = [&](int c) {
+    const float* xc = xb + (size_t)c * SCK * p.Tin;
 #pragma unroll
     for (int i = 0; i < CONV_MAXX; i++) {
       int g = goff[i];
       xr[i] = (g >= 0) ? xc[g] : 0.f;
     }
-    const float* wc = p.w + ((size_t)c * KC) * p.Mp + m0;
+    const float* wc = p.w + ((size_t)c * KCs) * p.Mp + m0;
 #pragma unroll
     for (int i = 0; i < CONV_MAXW; i++) {
       int f = tid + i * CONV_NT;
-      if (f < wt4) {
-        int row = f / (BM / 4), c4 = f % (BM / 4);
-        wr[i] = *reinterpret_cast<const f32x4*>(wc + (size_t)row * p.Mp + c4 * 4);
-      }
+      if (f < wt4) wr[i] = *reinterpret_cast<const f32x4*>(wc + woff[i]);
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_stage = [&](int buf) {
     float* xd = Xs + buf * xt_al;
 #pragma unroll
     for (int i = 0; i < CONV_MAXX; i++) {
@@ -96,7 +120,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
         xd[e] = v;
       }
     }
-    f32x4* wd = reinterpret_cast<f32x4*>(Ws + (size_t)buf * KC * BM);
+    f32x4* wd = reinterpret_cast<f32x4*>(Ws + (size_t)buf * KCs * BM);
 #pragma unroll
     for (int i = 0; i < CONV_MAXW; i++) {
       int f = tid + i * CONV_NT;
@@ -112,61 +136,79 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  const int hk = CK >> 1;           // K-pairs per tap (power of two)
-  const int lhk = 31 - __clz(hk);
-  const int nsteps = KW * hk;       // MFMA k-steps per chunk
   const int lhalf = lane >> 5, l31 = lane & 31;
   const int a_col = wm * (32 * TM) + l31;
   const int b_col = (wn * (32 * TN) + l31) * stride;
-  constexpr int U = (WK == 1) ? 4 : 2;  // k-steps issued back to back (LDS reads of a group precede its MFMAs)
+  const int nI = SCK >> 1;                             // channel pairs per stage
+  const int my_steps = nI > kw ? (nI - kw + WK - 1) / WK : 0;  // pairs of this wave per tap
+  const int gpt = (my_steps + U - 1) / U;              // fragment groups per tap
+  const int ngroups = gpt * KW;
+  const int a_step = 2 * WK * BM, b_step = 2 * WK * span;  // operand strides between consecutive pairs of a wave
+  const float* zrow = Zs + lhalf * BM + a_col;
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  for (int c = 0; c < nchunks; c++) {
-    const int buf = c & 1;
-    if (c + 1 < nchunks) load_chunk(c + 1);
-    const float* xsb = Xs + buf * xt_al + lhalf * span + b_col;
-    const float* wsb = Ws + (size_t)buf * KC * BM + lhalf * BM + a_col;
-    int s = kw;
-    for (; s + (U - 1) * WK < nsteps; s += U * WK) {
-      float av[U][TM], bv[U][TN];
+  // group cursor (tap, jg) advanced by every load_group call, in program order
+  int cur_tap = 0, cur_jg = 0;
+  auto load_group = [&](const float* wsb, const float* xsb, float (&av)[U][TM], float (&bv)[U][TN]) {
+    const float* wt = wsb + cur_tap * (SCK * BM) + cur_jg * (U * a_step);
+    const float* xq = xsb + cur_tap + cur_jg * (U * b_step);
+    const int j0 = cur_jg * U;
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int ss = s + u * WK;
-        const int tap = ss >> lhk, i2 = ss & (hk - 1);
-        const float* wrow = wsb + (tap * CK + 2 * i2) * BM;
-        const float* xrow = xsb + (2 * i2) * span + tap;
+    for (int u = 0; u < U; u++) {
+      const bool ok = j0 + u < my_steps;
+      const float* wrow = ok ? wt + u * a_step : zrow;
+      const float* xrow = ok ? xq + u * b_step : xq;
 #pragma unroll
-        for (int i = 0; i < TM; i++) av[u][i] = wrow[32 * i];
+      for (int i = 0; i < TM; i++) av[u][i] = wrow[32 * i];
 #pragma unroll
-        for (int j = 0; j < TN; j++) bv[u][j] = xrow[32 * j * stride];
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++)
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-          for (int j = 0; j < TN; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN; j++) bv[u][j] = xrow[32 * j * stride];
     }
-    for (; s < nsteps; s += WK) {
-      const int tap = s >> lhk, i2 = s & (hk - 1);
-      const float* wrow = wsb + (tap * CK + 2 * i2) * BM;
-      const float* xrow = xsb + (2 * i2) * span + tap;
-      float av[TM], bv[TN];
+    if (++cur_jg == gpt) { cur_jg = 0; ++cur_tap; }
+  };
+  auto mma_group = [&](float (&av)[U][TM], float (&bv)[U][TN]) {
 #pragma unroll
-      for (int i = 0; i < TM; i++) av[i] = wrow[32 * i];
-#pragma unroll
-      for (int j = 0; j < TN; j++) bv[j] = xrow[32 * j * stride];
+    for (int u = 0; u < U; u++)
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+  };
+
+  load_stage(0);
+  if (ts_on) tsv[1] = __builtin_readcyclecounter();
+  store_stage(0);
+  __syncthreads();
+  if (ts_on) tsv[2] = __builtin_readcyclecounter();
+  for (int c = 0; c < nstages; c++) {
+    const int buf = c & 1;
+    long long ta = 0;
+    if (ts_on) ta = __builtin_readcyclecounter();
+    if (c + 1 < nstages && !(p.dbg & 1)) load_stage(c + 1);
+    if (!(p.dbg & 2)) {
+      const float* xsb = Xs + buf * xt_al + (2 * kw + lhalf) * span + b_col;
+      const float* wsb = Ws + ((size_t)buf * KCs + 2 * kw + lhalf) * BM + a_col;
+      cur_tap = 0;
+      cur_jg = 0;
+      // software-pipelined: the LDS reads of group g+1 are issued before the MFMAs of group g
+      float a0[U][TM], b0[U][TN], a1[U][TM], b1[U][TN];
+      if (ngroups > 0) load_group(wsb, xsb, a0, b0);
+      for (int g = 0; g < ngroups; g += 2) {
+        if (g + 1 < ngroups) load_group(wsb, xsb, a1, b1);
+        mma_group(a0, b0);
+        if (g + 1 < ngroups) {
+          if (g + 2 < ngroups) load_group(wsb, xsb, a0, b0);
+          mma_group(a1, b1);
+        }
+      }
     }
-    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    long long tb = 0;
+    if (ts_on) { tb = __builtin_readcyclecounter(); t_mma += tb - ta; }
+    if (c + 1 < nstages && !(p.dbg & 8)) store_stage(buf ^ 1);
     __syncthreads();
+    if (ts_on) t_wait += __builtin_readcyclecounter() - tb;
   }
+  if (ts_on) tsv[3] = __builtin_readcyclecounter();
+  if (p.dbg & 4) { if (acc[0][0][0] == 12345.f) p.y[0] = 1.f; return; }
 
   // ---- epilogue: accumulators -> LDS (sum over the WK split on read) -> coalesced fused store ----------
   constexpr int EP = BN + 4;  // keeps rows 16-B aligned for the float4 read-back
@@ -182,6 +224,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
         Es[(kw * BM + row) * EP + col] = acc[i][j][r];
       }
   __syncthreads();
+  if (ts_on) tsv[4] = __builtin_readcyclecounter();
 
   const int up = p.up, Cout = p.Cout, Tout = p.Tout;
   const size_t ybase = (size_t)b * Cout * Tout;
@@ -190,77 +233,100 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
   if (m_hi > p.M - 1) m_hi = p.M - 1;
 
   if (up == 1 && (Tout & 3) == 0) {
-    // fast path: one float4 of consecutive time samples per thread and pass, shift-only indexing
-    constexpr int C4 = BN / 4, RPP = CONV_NT / C4;
-    const int c4 = tid % C4, q = c4 * 4;
+    // fast path: one float4 of consecutive time samples per thread and pass, shift-only indexing;
+    // every global read of all passes is issued before the first use
+    constexpr int C4 = BN / 4, RPP = CONV_NT / C4, NP = BM / RPP;
+    const int c4 = tid % C4, q = c4 * 4, r0 = tid / C4;
     if (n0 + q < p.Nq) {
-      for (int row = tid / C4; row < BM; row += RPP) {
-        const int m = m0 + row;
+      f32x4 addv[NP], resv[NP];
+      float bi[NP], ga[NP], be[NP];
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+        const int m = m0 + r0 + k * RPP;
+        const bool ok = m <= m_hi;
+        const size_t idx = ybase + (size_t)(ok ? m : m0) * Tout + n0 + q;
+        bi[k] = p.bias[ok ? m : m0];
+        if (p.add) addv[k] = *reinterpret_cast<const f32x4*>(p.add + idx);
+        if (p.res) resv[k] = *reinterpret_cast<const f32x4*>(p.res + idx);
+        if (filmb) { ga[k] = filmb[ok ? m : m0]; be[k] = filmb[Cout + (ok ? m : m0)]; }
+      }
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+        const int row = r0 + k * RPP, m = m0 + row;
         if (m > m_hi) break;
         f32x4 v = *reinterpret_cast<const f32x4*>(&Es[row * EP + q]);
 #pragma unroll
-        for (int k = 1; k < WK; k++) v += *reinterpret_cast<const f32x4*>(&Es[(k * BM + row) * EP + q]);
-        v += p.bias[m];
-        const size_t idx = ybase + (size_t)m * Tout + n0 + q;
-        if (p.add) v = (v + *reinterpret_cast<const f32x4*>(p.add + idx)) * p.add_scale;
-        if (filmb) v = filmb[m] * v + filmb[Cout + m];
-        if (p.res) v = (v + *reinterpret_cast<const f32x4*>(p.res + idx)) * p.res_scale;
-        *reinterpret_cast<f32x4*>(p.y + idx) = v;
+        for (int kk = 1; kk < WK; kk++) v += *reinterpret_cast<const f32x4*>(&Es[(kk * BM + row) * EP + q]);
+        v += bi[k];
+        if (p.add) v = (v + addv[k]) * p.add_scale;
+        if (filmb) v = ga[k] * v + be[k];
+        if (p.res) v = (v + resv[k]) * p.res_scale;
+        *reinterpret_cast<f32x4*>(p.y + ybase + (size_t)m * Tout + n0 + q) = v;
       }
     }
-    return;
-  }
-  // general path (transposed-conv phase interleave, or rows that are not 16-B aligned):
-  //   e -> (co, q, ph) with the output sample t = (n0 + q)*up + ph fastest across threads
-  constexpr int LBN = (BN == 128) ? 7 : (BN == 64 ? 6 : 5);
-  const int co_first = up == 1 ? m0 : (int)__umulhi((unsigned)m0, p.magic_up);
-  const int nco = (up == 1 ? m_hi : (int)__umulhi((unsigned)m_hi, p.magic_up)) - co_first + 1;
-  const int total = nco * BN * up;
-  for (int e = tid; e < total; e += CONV_NT) {
-    const int rest = up == 1 ? e : (int)__umulhi((unsigned)e, p.magic_up);  // e / up
-    const int ph = e - rest * up;
-    const int q = rest & (BN - 1);
-    const int co = co_first + (rest >> LBN);
-    const int m = co * up + ph;
-    const int t = (n0 + q) * up + ph;
-    if (m < m0 || m > m_hi || (n0 + q) >= p.Nq || t >= Tout) continue;
-    float v = Es[(m - m0) * EP + q];
+  } else {
+    // general path (transposed-conv phase interleave, or rows that are not 16-B aligned):
+    //   e -> (co, q, ph) with the output sample t = (n0 + q)*up + ph fastest across threads
+    constexpr int LBN = (BN == 128) ? 7 : (BN == 64 ? 6 : 5);
+    const int co_first = up == 1 ? m0 : (int)__umulhi((unsigned)m0, p.magic_up);
+    const int nco = (up == 1 ? m_hi : (int)__umulhi((unsigned)m_hi, p.magic_up)) - co_first + 1;
+    const int total = nco * BN * up;
+    for (int e = tid; e < total; e += CONV_NT) {
+      const int rest = up == 1 ? e : (int)__umulhi((unsigned)e, p.magic_up);  // e / up
+      const int ph = e - rest * up;
+      const int q = rest & (BN - 1);
+      const int co = co_first + (rest >> LBN);
+      const int m = co * up + ph;
+      const int t = (n0 + q) * up + ph;
+      if (m < m0 || m > m_hi || (n0 + q) >= p.Nq || t >= Tout) continue;
+      float v = Es[(m - m0) * EP + q];
 #pragma unroll
-    for (int k = 1; k < WK; k++) v += Es[(k * BM + (m - m0)) * EP + q];
-    v += p.bias[co];
-    const size_t idx = ybase + (size_t)co * Tout + t;
-    if (p.add) v = (v + p.add[idx]) * p.add_scale;
-    if (filmb) v = filmb[co] * v + filmb[Cout + co];
-    if (p.res) v = (v + p.res[idx]) * p.res_scale;
-    p.y[idx] = v;
+      for (int k = 1; k < WK; k++) v += Es[(k * BM + (m - m0)) * EP + q];
+      v += p.bias[co];
+      const size_t idx = ybase + (size_t)co * Tout + t;
+      if (p.add) v = (v + p.add[idx]) * p.add_scale;
+      if (filmb) v = filmb[co] * v + filmb[Cout + co];
+      if (p.res) v = (v + p.res[idx]) * p.res_scale;
+      p.y[idx] = v;
+    }
+  }
+  if (ts_on && lane == 0) {
+    long long* o = p.tstamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    o[0] = tsv[1] - tsv[0]; o[1] = tsv[2] - tsv[1]; o[2] = tsv[3] - tsv[2]; o[3] = tsv[4] - tsv[3];
+    o[4] = __builtin_readcyclecounter() - tsv[4]; o[5] = t_mma; o[6] = t_wait; o[7] = tsv[0];
   }
 }
 
 struct ConvCfg {
-  int BM, BN, WK;
-  void (*kern)(ConvArgs);
+  int BM, BN, WK, MAXW;
+  void (*kern4)(ConvArgs);  // fragment groups of 4 k-steps
+  void (*kern2)(ConvArgs);  // ... of 2 (few channel pairs per wave and tap)
 };
 static const ConvCfg kConvCfgs[] = {
-    {64, 128, 1, conv_mfma_kernel<1, 2, 2, 2, 1>},
-    {32, 128, 1, conv_mfma_kernel<1, 1, 1, 4, 1>},
-    {64, 64, 1, conv_mfma_kernel<1, 1, 2, 2, 1>},
-    {32, 64, 4, conv_mfma_kernel<1, 2, 1, 1, 4>},
-    {32, 32, 4, conv_mfma_kernel<1, 1, 1, 1, 4>},
+    {64, 128, 1, 6, conv_mfma_kernel<1, 2, 2, 2, 1, 6, 4>, conv_mfma_kernel<1, 2, 2, 2, 1, 6, 2>},
+    {32, 128, 1, 6, conv_mfma_kernel<1, 1, 1, 4, 1, 6, 4>, conv_mfma_kernel<1, 1, 1, 4, 1, 6, 2>},
+    {64, 64, 1, 6, conv_mfma_kernel<1, 1, 2, 2, 1, 6, 4>, conv_mfma_kernel<1, 1, 2, 2, 1, 6, 2>},
+    // small-T levels: reduction split over the 4 waves, up to 4 packed chunks per pipeline stage
+    {32, 64, 4, 12, conv_mfma_kernel<1, 2, 1, 1, 4, 12, 4>, conv_mfma_kernel<1, 2, 1, 1, 4, 12, 2>},
+    {32, 32, 4, 12, conv_mfma_kernel<1, 1, 1, 1, 4, 12, 4>, conv_mfma_kernel<1, 1, 1, 1, 4, 12, 2>},
 };
 constexpr int kNumConvCfgs = sizeof(kConvCfgs) / sizeof(kConvCfgs[0]);
 
 static size_t conv_smem_bytes(const ConvCfg& c, const ConvArgs& a) {
   int span = (c.BN - 1) * a.stride + a.KW;
-  size_t xt_al = ((size_t)a.CK * span + 3) & ~size_t(3);
-  size_t stage = 2 * (xt_al + (size_t)a.CK * a.KW * c.BM);
+  size_t xt_al = ((size_t)a.SC * a.CK * span + 3) & ~size_t(3);
+  size_t stage = 2 * (xt_al + (size_t)a.SC * a.CK * a.KW * c.BM) + 2 * c.BM;
   size_t epi = (size_t)c.WK * c.BM * (c.BN + 4);
   return 4 * (stage > epi ? stage : epi);
 }
 
 hipError_t init_conv_kernels() {
   for (int i = 0; i < kNumConvCfgs; i++) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kConvCfgs[i].kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kConvCfgs[i].kern4),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kConvCfgs[i].kern2),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
@@ -272,10 +338,11 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   const long want = (long)num_cu * 15 / 16;
   for (int i = 0; i < kNumConvCfgs; i++) {
     const ConvCfg& c = kConvCfgs[i];
+    if (a.force_cfg >= 0 && i != a.force_cfg) continue;
     if (c.BM == 64 && a.M <= 32) continue;
     int span = (c.BN - 1) * a.stride + a.KW;
     if ((long)a.CK * span > CONV_MAXX * CONV_NT) continue;
-    if ((long)a.CK * a.KW * c.BM > CONV_MAXW * CONV_NT * 4) continue;
+    if ((long)a.CK * a.KW * c.BM > c.MAXW * CONV_NT * 4) continue;
     pick = i;
     long blocks = (long)((a.M + c.BM - 1) / c.BM) * ((a.Nq + c.BN - 1) / c.BN) * a.B;
     if (blocks >= want) break;
@@ -284,13 +351,29 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   const ConvCfg& c = kConvCfgs[pick];
   if (cfg_out) *cfg_out = pick;
   ConvArgs aa = a;
+  {  // chunks per pipeline stage: as many as the per-thread staging registers and 128 KB of LDS allow
+    const int span = (c.BN - 1) * a.stride + a.KW;
+    const int nch = a.Cin / a.CK;
+    int sc = 1;
+    for (int cand = 4; cand >= 2; cand >>= 1) {
+      if (a.force_sc > 0 && cand > a.force_sc) continue;
+      if (nch % cand) continue;
+      if ((long)cand * a.CK * span > CONV_MAXX * CONV_NT) continue;
+      if ((long)cand * a.CK * a.KW * c.BM > (long)c.MAXW * CONV_NT * 4) continue;
+      sc = cand;
+      break;
+    }
+    aa.SC = sc;
+  }
   // exact for the index ranges used (e < 2^13, divisor < 2^11): floor(e/d) == umulhi(e, 2^32/d + 1)
   const int bns[3] = {128, 64, 32};
   for (int i = 0; i < 3; i++) aa.magic_span[i] = (unsigned)(0x100000000ull / (unsigned)((bns[i] - 1) * a.stride + a.KW)) + 1u;
   aa.magic_up = a.up == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.up) + 1u;
   dim3 grid((a.Nq + c.BN - 1) / c.BN, (a.M + c.BM - 1) / c.BM, a.B);
-  size_t smem = conv_smem_bytes(c, a);
-  hipLaunchKernelGGL(c.kern, grid, dim3(CONV_NT), smem, stream, aa);
+  size_t smem = conv_smem_bytes(c, aa);
+  // channel pairs of one wave per tap: groups of 4 when that divides, else groups of 2
+  const int pairs = aa.SC * a.CK / 2, per_wave = (pairs + c.WK - 1) / c.WK;
+  hipLaunchKernelGGL((per_wave % 4 == 0 ? c.kern4 : c.kern2), grid, dim3(CONV_NT), smem, stream, aa);
   return hipGetLastError();
 }
 

@@ -145,6 +145,15 @@ class Universe:
         _lib.check(self._L.ou_profile_read(self._handle, max_records, ms, fl, by, cf, byref(n)), self._handle)
         return [(ms[i], fl[i], by[i], cf[i]) for i in range(n.value)]
 
+    def bench_conv(self, layer, B, Tin, cfg=-1, sc=-1, with_res=False, iters=20):
+        """Tuning aid: ms per launch of one packed conv layer (see ou_bench_conv)."""
+        ws = torch.empty(max(1 << 28, 64 * B * Tin * 4 * 64), dtype=torch.uint8, device=self.device)
+        ms, used = c_float(), c_int32()
+        _lib.check(self._L.ou_bench_conv(self._handle, layer.encode(), B, Tin, cfg, sc, int(with_res), iters,
+                                         c_void_p(ws.data_ptr()), c_size_t(ws.numel()), self._stream(), byref(ms),
+                                         byref(used)), self._handle)
+        return ms.value, used.value
+
     def pad(self, x, pad=None):
         """universe.py:219-223."""
         if pad is None:

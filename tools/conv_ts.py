@@ -1,0 +1,26 @@
+import os, sys
+os.environ["OU_TS"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch, ctypes
+from ctypes import byref, c_float, c_int32, c_size_t, c_void_p
+from helpers import get_spec
+from open_universe_amd import Universe, state_dict as S, _lib
+spec = get_spec("PP16")
+model = Universe(spec, state_dict=S.synthetic_state_dict(spec, 0), device="cuda:0")
+p = "_edm_model"
+layers = [(p + ".encoder.ds_modules.0.conv1", 64160, 502 * 1), (p + ".encoder.ds_modules.1.conv1", 32080, 251),
+          (p + ".encoder.ds_modules.3.conv1", 2005, 256), (p + ".encoder.ds_modules.4.conv1", 401, 208)]
+ws = torch.zeros(1 << 29, dtype=torch.uint8, device="cuda")
+for name, Tin, nblk in layers:
+    ms, used = c_float(), c_int32()
+    _lib.check(model._L.ou_bench_conv(model._handle, name.encode(), 1, Tin, -1, -1, 1, 3, c_void_p(ws.data_ptr()),
+                                      c_size_t(ws.numel()), model._stream(), byref(ms), byref(used)), model._handle)
+    torch.cuda.synchronize()
+    ts = ws[ws.numel() - (16 << 20):].view(torch.int64)[: nblk * 4 * 8].view(nblk, 4, 8).cpu().double(); ws[ws.numel() - (16 << 20):].zero_()
+    t0 = ts[..., 7]
+    start_spread = (t0.max() - t0.min()).item()
+    m = ts.mean(dim=(0, 1))
+    tot = m[:5].sum().item()
+    print(f"{name[-26:]} cfg{used.value} {ms.value*1e3:.1f}us | cycles/wave: goff+ld0 {m[0]:.0f} st0+bar {m[1]:.0f} mainloop {m[2]:.0f} (mma {m[5]:.0f} wait {m[6]:.0f}) epi-lds {m[3]:.0f} epi-out {m[4]:.0f} total {tot:.0f} | start spread {start_spread:.0f}")
