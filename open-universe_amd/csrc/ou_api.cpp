@@ -151,7 +151,7 @@ struct Runner {
       if (h->prof_used < h->prof.size()) {
         pr = &h->prof[h->prof_used++];
         // algorithmic (reference, un-folded) work of this layer: dense FLOPs, activations once, weights once
-        const int kref = L.kind == CK_DOWN ? L.rate : (L.kind == CK_UP ? 1 : L.KW);
+        const int kref = L.KW;  // the packed layers now carry the reference's own kernel sizes
         pr->flops = 2.0 * L.M * (double)Nq * L.Cin * kref * B;
         pr->bytes = 4.0 * ((double)B * ((double)L.Cin * in.T + (double)L.Cout * Tout) + (double)L.M * L.Cin * kref);
         (void)hipEventRecord(pr->a, st);
@@ -174,9 +174,18 @@ struct Runner {
                  const float* input_cond, const float* res) {
     Tensor hu = hin;
     if (Bk.dir == 2) {
-      Epi e;
-      e.res = res; e.res_scale = kInvSqrt2;  // blocks.py:374-376 fused into the up-conv epilogue
-      hu = conv(Bk.rc, hin, nm + ".up", e);
+      if (Bk.rc.fir_mode == 2) {
+        // PReLU -> transposed conv (r phase GEMMs) ; then FIR + bias + residual add as one bandwidth pass
+        Tensor u = conv(Bk.rc, hin, nm + ".upc", Epi());
+        hu = alloc(nm + ".up", u.C, u.T);
+        if (!dry && ok())
+          chk(launch_fir(u.p, W(Bk.rc.fir_off), Bk.rc.fir_len, 0.f, 0, W(Bk.rc.fbias_off), res, kInvSqrt2, hu.p, B, u.C,
+                         u.T, st), "fir(up)");
+      } else {
+        Epi e;
+        e.res = res; e.res_scale = kInvSqrt2;  // blocks.py:374-376 fused into the up-conv epilogue
+        hu = conv(Bk.rc, hin, nm + ".up", e);
+      }
     }
     Epi e1;
     if (input_cond) { e1.add = input_cond; e1.add_scale = kInvSqrt2; }  // blocks.py:384-386
@@ -189,7 +198,19 @@ struct Runner {
     Tensor v = conv(Bk.c3, c2, nm + ".v", e3);
     BlockOut o;
     o.v = v; o.c1 = c1; o.h_next = v;
-    if (Bk.dir == 1) o.h_next = conv(Bk.rc, v, nm + ".h", Epi());  // blocks.py:401-410
+    if (Bk.dir == 1) {  // blocks.py:401-410
+      if (Bk.rc.fir_mode == 1) {
+        Tensor xf = alloc(nm + ".fir", v.C, v.T);
+        if (!dry && ok())
+          chk(launch_fir(v.p, W(Bk.rc.fir_off), Bk.rc.fir_len, h->alphas[Bk.rc.a_off], 1, nullptr, nullptr, 1.f, xf.p, B,
+                         v.C, v.T, st), "fir(down)");
+        Epi e;
+        e.act = false;  // PReLU applied by the FIR pass
+        o.h_next = conv(Bk.rc, xf, nm + ".h", e);
+      } else {
+        o.h_next = conv(Bk.rc, v, nm + ".h", Epi());
+      }
+    }
     return o;
   }
 
@@ -204,6 +225,7 @@ struct Runner {
     GruArgs a;
     a.gx = gx.p; a.whh = W(G.whh_off); a.bhn = W(G.bhn_off); a.out = out.p; a.res = res; a.res_scale = res_scale;
     a.xchg = xchg; a.err = errw; a.B = B; a.T = in.T; a.H = G.H;
+    if (std::getenv("OU_GRU_TS")) a.tstamps = (long long*)(base + cap - (1u << 20));
     chk(launch_gru(a, h->num_cu, st), G.name.c_str());
     return out;
   }

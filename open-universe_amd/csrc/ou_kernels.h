@@ -81,6 +81,11 @@ hipError_t launch_mel_scale(const float* esum, float* scale, int B, int L, hipSt
 
 // space-to-depth + PReLU for the conditioner's strided "st" convs: y[b][ci*R + k][q] = prelu(x[b][ci][q*R + k])
 hipError_t launch_s2d(const float* x, const float* alpha, float* y, int B, int C, int T, int R, hipStream_t st);
+// Binomial anti-alias FIR (blocks.py:119-130, depthwise 'same' conv with 2r+1 taps), bandwidth-bound:
+//   pre  (down path): y = FIR(prelu(x))                       blocks.py:211-215
+//   post (up path)  : y = FIR(u) + bias[c] ; y = res ? (y + res)*res_scale : y     blocks.py:219-225, 374-376
+hipError_t launch_fir(const float* x, const float* taps, int ntaps, float alpha, int act, const float* bias,
+                      const float* res, float res_scale, float* y, int B, int C, int T, hipStream_t st);
 // y = (a + b + c + d + e) * scale   (nulls skipped)   condition.py:202-206
 hipError_t launch_sum(const float* a, const float* b, const float* c, const float* d, const float* e, float scale,
                       float* y, size_t n, hipStream_t st);
@@ -96,6 +101,7 @@ struct GruArgs {
   float res_scale = 1.f;
   unsigned long long* xchg = nullptr;  // B*2*2*H granules, zeroed by the launcher
   unsigned* err = nullptr;             // device status word
+  long long* tstamps = nullptr;        // per-wave cycle breakdown (tuning only)
   int B = 1, T = 0, H = 0;
 };
 hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st);

@@ -335,7 +335,6 @@ hipError_t init_conv_kernels() {
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
   if (a.Cin % a.CK || a.CK < 2 || (a.CK & (a.CK - 1)) || a.Mp % 64 || a.Nq <= 0) return hipErrorInvalidValue;
   int pick = -1;
-  const long want = (long)num_cu * 15 / 16;
   for (int i = 0; i < kNumConvCfgs; i++) {
     const ConvCfg& c = kConvCfgs[i];
     if (a.force_cfg >= 0 && i != a.force_cfg) continue;
@@ -344,6 +343,9 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
     if ((long)a.CK * span > CONV_MAXX * CONV_NT) continue;
     if ((long)a.CK * a.KW * c.BM > c.MAXW * CONV_NT * 4) continue;
     pick = i;
+    // measured on MI355X (tools/conv_sweep.py): the one-tile-per-wave configs want >= 1.5 blocks per CU before
+    // they beat the next smaller tile; the 32x64 split-K config is still ahead of 32x32 at one block per CU
+    const long want = c.WK == 1 ? (long)num_cu * 3 / 2 : (long)num_cu * 15 / 16;
     long blocks = (long)((a.M + c.BM - 1) / c.BM) * ((a.Nq + c.BN - 1) / c.BN) * a.B;
     if (blocks >= want) break;
   }
@@ -776,6 +778,45 @@ hipError_t launch_s2d(const float* x, const float* alpha, float* y, int B, int C
   return hipGetLastError();
 }
 
+// ---- binomial anti-alias FIR ------------------------------------------------------------------------------------
+constexpr int FIR_TILE = 1024;
+__global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, const float* __restrict__ taps, int ntaps,
+                                                  float alpha, int act, const float* __restrict__ bias,
+                                                  const float* res, float res_scale, float* __restrict__ y, int C,
+                                                  int T) {
+  __shared__ float tile[FIR_TILE + 40];
+  __shared__ float tp[40];
+  const int c = blockIdx.y, b = blockIdx.z, t0 = blockIdx.x * FIR_TILE, tid = threadIdx.x;
+  const int r = ntaps >> 1;
+  const size_t row = ((size_t)b * C + c) * T;
+  if (tid < ntaps) tp[tid] = taps[tid];
+  for (int i = tid; i < FIR_TILE + 2 * r; i += 256) {
+    int t = t0 + i - r;
+    float v = (t >= 0 && t < T) ? x[row + t] : 0.f;
+    if (act) v = v >= 0.f ? v : alpha * v;
+    tile[i] = v;
+  }
+  __syncthreads();
+  const float bb = bias ? bias[c] : 0.f;
+#pragma unroll
+  for (int k = 0; k < FIR_TILE / 256; k++) {
+    const int i = tid + k * 256, t = t0 + i;
+    if (t >= T) break;
+    float acc = 0.f;
+    for (int j = 0; j < ntaps; j++) acc = fmaf(tp[j], tile[i + j], acc);
+    acc += bb;
+    if (res) acc = (acc + res[row + t]) * res_scale;
+    y[row + t] = acc;
+  }
+}
+hipError_t launch_fir(const float* x, const float* taps, int ntaps, float alpha, int act, const float* bias,
+                      const float* res, float res_scale, float* y, int B, int C, int T, hipStream_t st) {
+  if (ntaps > 39 || !(ntaps & 1)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fir_kernel, dim3((T + FIR_TILE - 1) / FIR_TILE, C, B), dim3(256), 0, st, x, taps, ntaps, alpha, act,
+                     bias, res, res_scale, y, C, T);
+  return hipGetLastError();
+}
+
 __global__ void sum_kernel(const float* a, const float* b, const float* c, const float* d, const float* e, float scale,
                            float* __restrict__ y, size_t n) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -809,20 +850,34 @@ __device__ __forceinline__ float dpp_add(float v) {
   int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
   return v + __int_as_float(t);
 }
-__device__ __forceinline__ float row16_sum(float v) {
+// sum over the 8 lanes of an aligned 8-lane group (every lane ends with the total)
+__device__ __forceinline__ float row8_sum(float v) {
   v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
   v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);  // row_half_mirror
-  v = dpp_add<0x140>(v);  // row_mirror
+  v = dpp_add<0x141>(v);  // row_half_mirror: lane i <-> 7-i within each 8
   return v;
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): the gate math is
+// a serial chain on the critical path of every GRU time step, libm-grade expf/tanhf/division cost ~100 dependent
+// instructions there.  Absolute error ~2e-7, two orders of magnitude inside the parity gate.
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+  // tanh(x) = 1 - 2/(1 + e^{2x});  e^{2x} -> inf gives 1, -> 0 gives -1
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr unsigned GRU_SPIN_LIMIT = 4000000u;
 
+// Thread mapping: workgroup g owns hidden units [64g, 64g+64); thread (u, cg) = (tid/8, tid%8) holds, for unit
+// 64g+u, the three gate rows (r, z, n) x columns {4cg + 32i + 0..3, i < H/32} = 3*H/8 weights in registers.
+// Per step: H/32 ds_read_b128 of h, 3*H/16 v_pk_fma_f32, a 3-stage DPP reduction of the 3 gate sums over the 8
+// lanes of the unit, the gate math in lane cg == 0, publish.
 template <int HB>
 __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int nclusters) {
-  constexpr int H = 64 * HB, NR = 24 * HB;
+  constexpr int H = 64 * HB, NI = 2 * HB, NR = 12 * NI;  // NI column blocks of 32; NR weights per thread
   __shared__ __attribute__((aligned(16))) float hbuf[2][H];
   __shared__ int abort_flag;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -835,21 +890,23 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int ncluste
   const int g = slot % HB;
   if (cluster >= nclusters) return;
   const int dir = cluster & 1, b = cluster >> 1;
-  const int rg = tid >> 4, cg = tid & 15;
+  const int ul = tid >> 3, cg = tid & 7;
   const int T = p.T;
 
-  float w[NR];
+  f32x2 w[NR / 2];
   {
     const float* wp = p.whh + ((size_t)(dir * HB + g) * NR) * 512 + tid;
 #pragma unroll
-    for (int r = 0; r < NR; r++) w[r] = wp[(size_t)r * 512];
+    for (int r = 0; r < NR / 2; r++) {
+      w[r].x = wp[(size_t)(2 * r) * 512];
+      w[r].y = wp[(size_t)(2 * r + 1) * 512];
+    }
   }
   for (int i = tid; i < 2 * H; i += 512) (&hbuf[0][0])[i] = 0.f;
   if (tid == 0) abort_flag = 0;
 
-  // lanes cg = 0,1 of each 16-lane row finish one hidden unit each
-  const int unit = g * 64 + 2 * rg + (cg & 1);
-  const bool fin = cg < 2;
+  const int unit = g * 64 + ul;
+  const bool fin = cg == 0;
   const float bhn = p.bhn[dir * H + unit];
   const float* gxb = p.gx + ((size_t)b * 6 * H + (size_t)dir * 3 * H) * T;
   const float* gx_r = gxb + (size_t)unit * T;
@@ -868,25 +925,29 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int ncluste
   }
   __syncthreads();
 
+  long long c_comp = 0, c_poll = 0, c_bar = 0;
+  const bool ts_on = p.tstamps != nullptr;
   for (int step = 0; step < T; step++, t += dt) {
     const int cur = step & 1;
-    float acc[6];
+    long long q0 = 0, q1 = 0, q2 = 0;
+    if (ts_on) q0 = __builtin_readcyclecounter();
+    f32x2 acc[3][2];
 #pragma unroll
-    for (int i = 0; i < 6; i++) acc[i] = 0.f;
+    for (int gt = 0; gt < 3; gt++) { acc[gt][0] = 0.f; acc[gt][1] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < HB; i++) {
-      const float4 hv = *reinterpret_cast<const float4*>(&hbuf[cur][cg * 4 + 64 * i]);
+    for (int i = 0; i < NI; i++) {
+      const float4 hv = *reinterpret_cast<const float4*>(&hbuf[cur][cg * 4 + 32 * i]);
+      const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
 #pragma unroll
-      for (int ug = 0; ug < 6; ug++) {
-        const int r = (ug * HB + i) * 4;
-        acc[ug] = fmaf(w[r + 0], hv.x, acc[ug]);
-        acc[ug] = fmaf(w[r + 1], hv.y, acc[ug]);
-        acc[ug] = fmaf(w[r + 2], hv.z, acc[ug]);
-        acc[ug] = fmaf(w[r + 3], hv.w, acc[ug]);
+      for (int gt = 0; gt < 3; gt++) {
+        const int r = (gt * NI + i) * 2;
+        acc[gt][0] = __builtin_elementwise_fma(w[r], h01, acc[gt][0]);
+        acc[gt][1] = __builtin_elementwise_fma(w[r + 1], h23, acc[gt][1]);
       }
     }
+    float hs[3];
 #pragma unroll
-    for (int i = 0; i < 6; i++) acc[i] = row16_sum(acc[i]);
+    for (int gt = 0; gt < 3; gt++) hs[gt] = row8_sum((acc[gt][0].x + acc[gt][0].y) + (acc[gt][1].x + acc[gt][1].y));
 
     // next step's input-projection / residual values: issued now, consumed one iteration later, so that no
     // global-load latency ever sits between the gate math and the publish below
@@ -897,11 +958,9 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int ncluste
     }
 
     if (fin) {
-      const bool hi = (cg & 1) != 0;
-      const float hr = hi ? acc[3] : acc[0], hz = hi ? acc[4] : acc[1], hn = hi ? acc[5] : acc[2];
-      const float r = sigmoidf_(xr + hr);
-      const float z = sigmoidf_(xz + hz);
-      const float n = tanhf(xn + r * (hn + bhn));
+      const float r = sigmoidf_(xr + hs[0]);
+      const float z = sigmoidf_(xz + hs[1]);
+      const float n = tanhf_(xn + r * (hs[2] + bhn));
       const float hp = hbuf[cur][unit];
       const float hnew = (hp - n) * z + n;
       if (HB > 1) {  // publish first: the other workgroups are waiting on this
@@ -912,6 +971,7 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int ncluste
       p.out[orow + t] = has_res ? (hnew + rs) * p.res_scale : hnew;
     }
     xr = nxr; xz = nxz; xn = nxn; rs = nrs;
+    if (ts_on) q1 = __builtin_readcyclecounter();
 
     if (HB > 1 && tid < 64) {
       // gather the other workgroups' slices: each lane owns H/64 granules; all polls in flight together
@@ -934,11 +994,17 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int ncluste
       for (int k = 0; k < HB; k++)
         if (k != g) hbuf[cur ^ 1][k * 64 + lane] = __int_as_float((int)(unsigned)v[k]);
     }
+    if (ts_on) q2 = __builtin_readcyclecounter();
     __syncthreads();
+    if (ts_on) { long long q3 = __builtin_readcyclecounter(); c_comp += q1 - q0; c_poll += q2 - q1; c_bar += q3 - q2; }
     if (HB > 1 && abort_flag) {
       if (tid == 0) atomicOr(p.err, 1u);
       break;
     }
+  }
+  if (ts_on && lane == 0) {
+    long long* o = p.tstamps + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 4;
+    o[0] = c_comp; o[1] = c_poll; o[2] = c_bar; o[3] = T;
   }
 }
 

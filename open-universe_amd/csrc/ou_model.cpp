@@ -37,6 +37,7 @@ std::string finish_conv(ConvL& L, Alloc& a) {
   L.w_off = a.take(L.w_floats());
   L.b_off = a.take(L.Cout);
   L.a_off = a.take(1);
+  if (L.fir_mode) { L.fir_off = a.take(L.fir_len); L.fbias_off = a.take(L.Cout); }
   return "";
 }
 
@@ -53,12 +54,12 @@ std::string make_conv(ConvL& L, Alloc& a, const std::string& name, int kind, int
       if (k % 2 == 0) return "even 'same' kernel not supported: " + name;
       break;
     case CK_DOWN:
-      L.Cin = cin; L.Cout = cout; L.stride = rate; L.up = 1;
-      if (aa) { L.KW = 3 * rate; L.pad = rate; } else { L.KW = rate; L.pad = 0; }
+      L.Cin = cin; L.Cout = cout; L.stride = rate; L.up = 1; L.KW = rate; L.pad = 0;
+      if (aa) { L.fir_mode = 1; L.fir_len = 2 * rate + 1; }
       break;
     case CK_UP:
-      L.Cin = cin; L.Cout = cout; L.stride = 1; L.up = rate;
-      if (aa) { L.KW = 3; L.pad = 1; } else { L.KW = 1; L.pad = 0; }
+      L.Cin = cin; L.Cout = cout; L.stride = 1; L.up = rate; L.KW = 1; L.pad = 0;
+      if (aa) { L.fir_mode = 2; L.fir_len = 2 * rate + 1; }
       break;
     case CK_ST:
       L.Cin = cin * rate; L.Cout = cout; L.KW = 1; L.stride = 1; L.pad = 0; L.up = 1;
@@ -100,7 +101,9 @@ void json_conv(std::ostringstream& os, const ConvL& L, bool& first) {
   os << "  {\"name\":\"" << L.name << "\",\"kind\":" << L.kind << ",\"Cin\":" << L.Cin << ",\"Cout\":" << L.Cout
      << ",\"KW\":" << L.KW << ",\"stride\":" << L.stride << ",\"pad\":" << L.pad << ",\"up\":" << L.up
      << ",\"M\":" << L.M << ",\"Mp\":" << L.Mp << ",\"CK\":" << L.CK << ",\"rate\":" << L.rate << ",\"act\":" << L.act
-     << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"a_off\":" << L.a_off << "}";
+     << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"a_off\":" << L.a_off
+     << ",\"fir_mode\":" << L.fir_mode << ",\"fir_len\":" << L.fir_len << ",\"fir_off\":" << L.fir_off
+     << ",\"fbias_off\":" << L.fbias_off << "}";
 }
 void json_block(std::ostringstream& os, const BlockL& B, bool& first) {
   if (B.dir) json_conv(os, B.rc, first);
@@ -370,58 +373,40 @@ struct Packer {
         break;
       }
       case CK_DOWN: {
+        // blocks.py:213-217: y = conv_{k=s=r}(FIR(prelu(x))) + bias.  The FIR (+PReLU) runs as its own
+        // bandwidth-bound pass (fir_mode 1); the conv keeps its native k = stride = r.
         const int r = L.rate;
-        if (!eff_weight(p + ".conv", {L.Cout, L.Cin, r}, w)) return;
+        if (!eff_weight(p + ".conv", {L.Cout, L.Cin, r}, W)) return;
         bool aa = has(p + ".low_pass_filter.weights");
-        if ((L.KW == 3 * r) != aa) { if (err.empty()) { err = "anti-aliasing config/checkpoint mismatch at " + p; code = OU_ESHAPE; } return; }
+        if ((L.fir_mode == 1) != aa) { if (err.empty()) { err = "anti-aliasing config/checkpoint mismatch at " + p; code = OU_ESHAPE; } return; }
+        const HostTensor* b = get(aa ? p + ".bias" : p + ".conv.bias", {L.Cout});
+        if (!b) return;
+        for (int i = 0; i < L.Cout; i++) bias[i] = b->data[i];
         if (aa) {
-          // blocks.py:213-217: y = conv_s(FIR(prelu(x))); FIR 'same' zero padding r each side.
-          // composed kernel W'[j] = sum_k w[k] f[j-k], j in [0,3r), stride r, pad r
           const HostTensor* f = get(p + ".low_pass_filter.weights", {2 * r + 1});
-          const HostTensor* b = get(p + ".bias", {L.Cout});
-          if (!f || !b) return;
-          W.assign((size_t)L.Cout * L.Cin * L.KW, 0.0);
-          for (int co = 0; co < L.Cout; co++)
-            for (int ci = 0; ci < L.Cin; ci++)
-              for (int k = 0; k < r; k++) {
-                double wk = w[((size_t)co * L.Cin + ci) * r + k];
-                for (int i = 0; i <= 2 * r; i++) W[((size_t)co * L.Cin + ci) * L.KW + k + i] += wk * (double)f->data[i];
-              }
-          for (int i = 0; i < L.Cout; i++) bias[i] = b->data[i];
-        } else {
-          W = w;
-          const HostTensor* b = get(p + ".conv.bias", {L.Cout});
-          if (!b) return;
-          for (int i = 0; i < L.Cout; i++) bias[i] = b->data[i];
+          if (!f) return;
+          putf(L.fir_off, f->data.data(), 2 * r + 1);
         }
         break;
       }
       case CK_UP: {
-        // ConvTranspose1d weight (in, out, k); weight-norm over dim 0 = in-channels
+        // blocks.py:217-225: y = FIR(convT_{k=s=r}(prelu(x))) + bias.  ConvTranspose1d weight is (in, out, k) with
+        // weight-norm over dim 0 = in-channels; lowered to r phase-GEMMs: row m = co*r + ph, y[q*r + ph].
         const int r = L.rate;
         if (!eff_weight(p + ".conv", {L.Cin, L.Cout, r}, w)) return;
         bool aa = has(p + ".low_pass_filter.weights");
-        if ((L.KW == 3) != aa) { if (err.empty()) { err = "anti-aliasing config/checkpoint mismatch at " + p; code = OU_ESHAPE; } return; }
-        W.assign((size_t)L.M * L.Cin * L.KW, 0.0);
+        if ((L.fir_mode == 2) != aa) { if (err.empty()) { err = "anti-aliasing config/checkpoint mismatch at " + p; code = OU_ESHAPE; } return; }
+        W.assign((size_t)L.M * L.Cin, 0.0);
+        for (int co = 0; co < L.Cout; co++)
+          for (int ph = 0; ph < r; ph++)
+            for (int ci = 0; ci < L.Cin; ci++) W[(size_t)(co * r + ph) * L.Cin + ci] = w[((size_t)ci * L.Cout + co) * r + ph];
         if (aa) {
-          // blocks.py:217-221: y = FIR(convT_s(prelu(x))).  With t = q*r + ph:
-          // y[t] = sum_{i=0..2r} f[i] u[t+i-r], u[tau] = sum_ci wt[ci][co][tau%r] x[ci][tau/r]
-          //  -> frame q-1+d, d = (ph+i)/r, tap (ph+i)%r.
           const HostTensor* f = get(p + ".low_pass_filter.weights", {2 * r + 1});
           const HostTensor* b = get(p + ".bias", {L.Cout});
           if (!f || !b) return;
-          for (int co = 0; co < L.Cout; co++)
-            for (int ph = 0; ph < r; ph++)
-              for (int ci = 0; ci < L.Cin; ci++)
-                for (int i = 0; i <= 2 * r; i++) {
-                  int d = (ph + i) / r, tap = (ph + i) % r;
-                  W[((size_t)(co * r + ph) * L.Cin + ci) * 3 + d] += (double)f->data[i] * w[((size_t)ci * L.Cout + co) * r + tap];
-                }
-          for (int i = 0; i < L.Cout; i++) bias[i] = b->data[i];
+          putf(L.fir_off, f->data.data(), 2 * r + 1);
+          putf(L.fbias_off, b->data.data(), L.Cout);  // added after the FIR; the conv's own bias stays 0
         } else {
-          for (int co = 0; co < L.Cout; co++)
-            for (int ph = 0; ph < r; ph++)
-              for (int ci = 0; ci < L.Cin; ci++) W[(size_t)(co * r + ph) * L.Cin + ci] = w[((size_t)ci * L.Cout + co) * r + ph];
           const HostTensor* b = get(p + ".conv.bias", {L.Cout});
           if (!b) return;
           for (int i = 0; i < L.Cout; i++) bias[i] = b->data[i];
@@ -469,11 +454,11 @@ struct Packer {
   }
 
   // Recurrent weights for the cluster kernel (ou_kernels.hip, gru_cluster_kernel):
-  //   [dir][wg g][reg r][tid]  with tid = rg*16 + cg, r = ((uu*3 + gate)*HB + i)*4 + c,
-  //   unit = g*64 + 2*rg + uu, row = gate*H + unit, col = cg*4 + 64*i + c
+  //   [dir][wg g][reg r][tid]  with tid = u*8 + cg, r = ((gate*NI + i)*4 + c), NI = H/32,
+  //   row = gate*H + 64g + u, col = 4cg + 32i + c
   void pack_gru(const GruL& G) {
     pack_conv(G.proj);
-    const int H = G.H, HB = H / 64, NR = 24 * HB;
+    const int H = G.H, HB = H / 64, NI = H / 32, NR = 12 * NI;
     for (int d = 0; d < 2; d++) {
       std::string sfx = "_l" + std::to_string(G.layer) + (d ? "_reverse" : "");
       const HostTensor* whh = get(G.name + ".weight_hh" + sfx, {3 * H, H});
@@ -481,10 +466,10 @@ struct Packer {
       if (!whh || !bhh) return;
       for (int g = 0; g < HB; g++)
         for (int r = 0; r < NR; r++) {
-          int c = r & 3, i = (r >> 2) % HB, ug = (r >> 2) / HB, gate = ug % 3, uu = ug / 3;
+          int c = r & 3, i = (r >> 2) % NI, gate = (r >> 2) / NI;
           for (int tid = 0; tid < 512; tid++) {
-            int rg = tid >> 4, cg = tid & 15;
-            int unit = g * 64 + 2 * rg + uu, row = gate * H + unit, col = cg * 4 + 64 * i + c;
+            int u = tid >> 3, cg = tid & 7;
+            int row = gate * H + g * 64 + u, col = cg * 4 + 32 * i + c;
             blob[G.whh_off + (((size_t)d * HB + g) * NR + r) * 512 + tid] = whh->data[(size_t)row * H + col];
           }
         }

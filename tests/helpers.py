@@ -53,6 +53,9 @@ def emulate_conv(blob, L, x, act=True):
     W, bias, alpha = unpack_conv(blob, L)
     if L["act"] and act:
         x = F.prelu(x, alpha)
+    if L.get("fir_mode") == 1:  # anti-alias FIR before the strided conv (separate bandwidth pass on the GPU)
+        taps = blob[L["fir_off"]: L["fir_off"] + L["fir_len"]]
+        x = F.conv1d(x, taps[None, None, :].expand(x.shape[1], 1, -1), padding="same", groups=x.shape[1])
     stride, pad, up, KW = L["stride"], L["pad"], L["up"], L["KW"]
     Nq = x.shape[-1] // stride if stride > 1 else x.shape[-1]
     need = (Nq - 1) * stride + KW
@@ -60,7 +63,12 @@ def emulate_conv(blob, L, x, act=True):
     y = F.conv1d(xp, W, None, stride=stride)[..., :Nq]
     B = x.shape[0]
     y = y.view(B, L["Cout"], up, Nq).permute(0, 1, 3, 2).reshape(B, L["Cout"], Nq * up)
-    return y + bias.view(1, -1, 1)
+    y = y + bias.view(1, -1, 1)
+    if L.get("fir_mode") == 2:  # FIR + manual bias after the transposed conv
+        taps = blob[L["fir_off"]: L["fir_off"] + L["fir_len"]]
+        y = F.conv1d(y, taps[None, None, :].expand(y.shape[1], 1, -1), padding="same", groups=y.shape[1])
+        y = y + blob[L["fbias_off"]: L["fbias_off"] + L["Cout"]].view(1, -1, 1)
+    return y
 
 
 def plan_convs(plan_json):

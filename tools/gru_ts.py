@@ -1,0 +1,19 @@
+import os, sys
+os.environ["OU_GRU_TS"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+from helpers import get_spec, synth_mix
+from open_universe_amd import Universe, state_dict as S
+spec = get_spec("PP16")
+model = Universe(spec, state_dict=S.synthetic_state_dict(spec, 0), device="cuda:0")
+mix = synth_mix(spec, 1, 64000).cuda()
+for _ in range(2):
+    model.enhance(mix, n_steps=2, rng=torch.Generator(device="cuda").manual_seed(0))
+torch.cuda.synchronize()
+ws = model._ws
+ts = ws[ws.numel() - (1 << 20):].view(torch.int64)[: 64 * 8 * 4].view(64, 8, 4).cpu().double()
+for blk in (0, 1, 8, 9):
+    print("block", blk, "per-step cycles [compute, poll(wave0)/idle, barrier]:",
+          [[round(float(v) / 401) for v in ts[blk, w, :3]] for w in (0, 1, 7)])
