@@ -21,8 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   Block = 4 waves arranged WM x WN x WK (WK = intra-block split of the reduction for the small-T levels).
 //   Register-prefetched double-buffered LDS staging: one barrier per channel chunk.
 // =========================================================================================================
-constexpr int CONV_NT = 256;
-constexpr int CONV_MAXX = 16;  // X-tile floats per thread  (SC*CK*span <= 4096)
+constexpr int CONV_XCAP = 4096;  // X-tile floats per stage (SC*CK*span), spread over the block's threads
 
 // Pipeline stage = SC consecutive packed chunks = SCK = SC*CK input channels.
 // LDS images of a stage:
@@ -33,8 +32,10 @@ constexpr int CONV_MAXX = 16;  // X-tile floats per thread  (SC*CK*span <= 4096)
 // The k-loop is tap-outer / channel-pair-inner; the WK waves of a split-K block take pairs I = kw, kw+WK, ...
 // Fragment groups of U steps are software-pipelined (reads of group g+1 issued before the MFMAs of group g).
 template <int TM, int TN, int WM, int WN, int WK, int CONV_MAXW, int U>
-__global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
-  static_assert(WM * WN * WK == 4, "4 waves per block");
+__global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p) {
+  constexpr int CONV_NT = 64 * WM * WN * WK;      // 4 or 8 waves
+  constexpr int CONV_MAXX = CONV_XCAP / CONV_NT;  // X-tile floats per thread
+  static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "4 or 8 waves per block");
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
   if (up == 1 && (Tout & 3) == 0) {
     // fast path: one float4 of consecutive time samples per thread and pass, shift-only indexing;
     // every global read of all passes is issued before the first use
-    constexpr int C4 = BN / 4, RPP = CONV_NT / C4, NP = BM / RPP;
+    constexpr int C4 = BN / 4, RPP = CONV_NT / C4, NP = (BM + RPP - 1) / RPP;
     const int c4 = tid % C4, q = c4 * 4, r0 = tid / C4;
     if (n0 + q < p.Nq) {
       f32x4 addv[NP], resv[NP];
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
       for (int k = 0; k < NP; k++) {
         const int m = m0 + r0 + k * RPP;
-        const bool ok = m <= m_hi;
+        const bool ok = m <= m_hi && r0 + k * RPP < BM;
         const size_t idx = ybase + (size_t)(ok ? m : m0) * Tout + n0 + q;
         bi[k] = p.bias[ok ? m : m0];
         if (p.add) addv[k] = *reinterpret_cast<const f32x4*>(p.add + idx);
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
       for (int k = 0; k < NP; k++) {
         const int row = r0 + k * RPP, m = m0 + row;
-        if (m > m_hi) break;
+        if (m > m_hi || row >= BM) break;
         f32x4 v = *reinterpret_cast<const f32x4*>(&Es[row * EP + q]);
 #pragma unroll
         for (int kk = 1; kk < WK; kk++) v += *reinterpret_cast<const f32x4*>(&Es[(kk * BM + row) * EP + q]);
@@ -291,24 +292,27 @@ __global__ __launch_bounds__(CONV_NT) void conv_mfma_kernel(ConvArgs p) {
     }
   }
   if (ts_on && lane == 0) {
-    long long* o = p.tstamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    long long* o = p.tstamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (CONV_NT / 64) + wave) * 8;
     o[0] = tsv[1] - tsv[0]; o[1] = tsv[2] - tsv[1]; o[2] = tsv[3] - tsv[2]; o[3] = tsv[4] - tsv[3];
     o[4] = __builtin_readcyclecounter() - tsv[4]; o[5] = t_mma; o[6] = t_wait; o[7] = tsv[0];
   }
 }
 
 struct ConvCfg {
-  int BM, BN, WK, MAXW;
+  int BM, BN, WK, MAXW, NT;
   void (*kern4)(ConvArgs);  // fragment groups of 4 k-steps
   void (*kern2)(ConvArgs);  // ... of 2 (few channel pairs per wave and tap)
 };
 static const ConvCfg kConvCfgs[] = {
-    {64, 128, 1, 6, conv_mfma_kernel<1, 2, 2, 2, 1, 6, 4>, conv_mfma_kernel<1, 2, 2, 2, 1, 6, 2>},
-    {32, 128, 1, 6, conv_mfma_kernel<1, 1, 1, 4, 1, 6, 4>, conv_mfma_kernel<1, 1, 1, 4, 1, 6, 2>},
-    {64, 64, 1, 6, conv_mfma_kernel<1, 1, 2, 2, 1, 6, 4>, conv_mfma_kernel<1, 1, 2, 2, 1, 6, 2>},
+    {64, 128, 1, 6, 256, conv_mfma_kernel<1, 2, 2, 2, 1, 6, 4>, conv_mfma_kernel<1, 2, 2, 2, 1, 6, 2>},
+    {32, 128, 1, 6, 256, conv_mfma_kernel<1, 1, 1, 4, 1, 6, 4>, conv_mfma_kernel<1, 1, 1, 4, 1, 6, 2>},
+    {64, 64, 1, 6, 256, conv_mfma_kernel<1, 1, 2, 2, 1, 6, 4>, conv_mfma_kernel<1, 1, 2, 2, 1, 6, 2>},
     // small-T levels: reduction split over the 4 waves, up to 4 packed chunks per pipeline stage
-    {32, 64, 4, 12, conv_mfma_kernel<1, 2, 1, 1, 4, 12, 4>, conv_mfma_kernel<1, 2, 1, 1, 4, 12, 2>},
-    {32, 32, 4, 12, conv_mfma_kernel<1, 1, 1, 1, 4, 12, 4>, conv_mfma_kernel<1, 1, 1, 1, 4, 12, 2>},
+    {32, 64, 4, 12, 256, conv_mfma_kernel<1, 2, 1, 1, 4, 12, 4>, conv_mfma_kernel<1, 2, 1, 1, 4, 12, 2>},
+    {32, 32, 4, 12, 256, conv_mfma_kernel<1, 1, 1, 1, 4, 12, 4>, conv_mfma_kernel<1, 1, 1, 1, 4, 12, 2>},
+    // 8 waves (two per SIMD), reduction split 8 ways
+    {32, 64, 8, 6, 512, conv_mfma_kernel<1, 2, 1, 1, 8, 6, 4>, conv_mfma_kernel<1, 2, 1, 1, 8, 6, 2>},
+    {32, 32, 8, 6, 512, conv_mfma_kernel<1, 1, 1, 1, 8, 6, 4>, conv_mfma_kernel<1, 1, 1, 1, 8, 6, 2>},
 };
 constexpr int kNumConvCfgs = sizeof(kConvCfgs) / sizeof(kConvCfgs[0]);
 
@@ -340,8 +344,9 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
     if (a.force_cfg >= 0 && i != a.force_cfg) continue;
     if (c.BM == 64 && a.M <= 32) continue;
     int span = (c.BN - 1) * a.stride + a.KW;
-    if ((long)a.CK * span > CONV_MAXX * CONV_NT) continue;
-    if ((long)a.CK * a.KW * c.BM > c.MAXW * CONV_NT * 4) continue;
+    if ((long)a.CK * span > CONV_XCAP) continue;
+    if ((long)a.CK * a.KW * c.BM > (long)c.MAXW * c.NT * 4) continue;
+    if (a.force_cfg < 0 && c.WK == 4) continue;  // superseded by the 8-wave split-K variants (tools/conv_sweep.py)
     pick = i;
     // measured on MI355X (tools/conv_sweep.py): the one-tile-per-wave configs want >= 1.5 blocks per CU before
     // they beat the next smaller tile; the 32x64 split-K config is still ahead of 32x32 at one block per CU
@@ -360,8 +365,8 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
     for (int cand = 4; cand >= 2; cand >>= 1) {
       if (a.force_sc > 0 && cand > a.force_sc) continue;
       if (nch % cand) continue;
-      if ((long)cand * a.CK * span > CONV_MAXX * CONV_NT) continue;
-      if ((long)cand * a.CK * a.KW * c.BM > (long)c.MAXW * CONV_NT * 4) continue;
+      if ((long)cand * a.CK * span > CONV_XCAP) continue;
+      if ((long)cand * a.CK * a.KW * c.BM > (long)c.MAXW * c.NT * 4) continue;
       sc = cand;
       break;
     }
@@ -375,7 +380,7 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   size_t smem = conv_smem_bytes(c, aa);
   // channel pairs of one wave per tap: groups of 4 when that divides, else groups of 2
   const int pairs = aa.SC * a.CK / 2, per_wave = (pairs + c.WK - 1) / c.WK;
-  hipLaunchKernelGGL((per_wave % 4 == 0 ? c.kern4 : c.kern2), grid, dim3(CONV_NT), smem, stream, aa);
+  hipLaunchKernelGGL((per_wave % 4 == 0 ? c.kern4 : c.kern2), grid, dim3(c.NT), smem, stream, aa);
   return hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ layers = [  # (prefix, Tin, MFLOP per batch element (reference accounting))
 ]
 for name, Tin, mflop in layers:
     res = []
-    for cfg in range(5):
+    for cfg in range(7):
         for sc in (1, 2, 4):
             try:
                 ms, used = model.bench_conv(name, B, Tin, cfg=cfg, sc=sc, with_res=True, iters=10)
