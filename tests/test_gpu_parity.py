@@ -211,3 +211,35 @@ def test_c_abi_error_codes():
     with pytest.raises(ValueError):
         model.enhance(x[0, 0], n_steps=5, warm_start=7)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("name,T,n_steps", [("OR16", 64000, 8), ("PP24", 48000, 4)])
+def test_other_baseline_configs_full_width(name, T, n_steps):
+    """BASELINE.json configs[3] / [4] topologies at FULL width (original UNIVERSE; UNIVERSE++ 24 kHz: C0 = 48,
+    rates 2-3-5-8, 128 mels, 6-workgroup GRU clusters) against the oracle on the same seeded inputs."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, 1, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(11, n_steps, 1, Tp)
+    ref = O.enhance(sd, spec.to_dict(), mix, n_steps=n_steps, noise=nz)
+    out = run_enhance(model, mix, nz, n_steps=n_steps)
+    assert O.si_sdr(ref, out) >= GATE_DB, O.si_sdr(ref, out)
+
+
+def test_variable_length_batch_is_padded_batch_semantics():
+    """configs[4]: a variable-length batch is right-zero-padded to its longest member (datasets/datamodule.py:24-42);
+    the reference has no mask, so parity is defined on the padded batch.  Also checks that every utterance of the
+    padded batch equals the same zero-padded signal enhanced alone (what the per-rank sharding relies on)."""
+    model, spec, sd = get_model("PP24s")
+    lens = [4100, 2900, 3555]
+    Tm = max(lens)
+    sigs = [synth_mix(spec, 1, L, seed=40 + i)[0] for i, L in enumerate(lens)]
+    batch = torch.stack([torch.nn.functional.pad(s, (0, Tm - s.numel())) for s in sigs])
+    Tp = Tm + (spec.tot_ds - Tm % spec.tot_ds)
+    nz = noise_list(5, 3, len(lens), Tp)
+    ref = O.enhance(sd, spec.to_dict(), batch, n_steps=3, noise=nz)
+    out = run_enhance(model, batch, nz, n_steps=3)
+    assert O.si_sdr(ref, out) >= GATE_DB
+    for b in range(len(lens)):
+        one = run_enhance(model, batch[b], [z[b:b + 1] for z in nz], n_steps=3)
+        assert O.si_sdr(out[b], one) > 100
