@@ -200,7 +200,7 @@ def main():
             "conv_ms_per_enhance": ms / max(1, args.profile_steps),
             "hbm_view": {"achieved_GBs": gbs, "peak_GBs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_GB_per_enhance": by / max(1, args.profile_steps) / 1e9},
-            "method": f"HIP events around every launch on the launch stream, profiled pass of {args.profile_steps} "
+            "method": f"device-side per-launch timing (first block start .. last block end on the 100 MHz s_memrealtime clock) of every conv launch, profiled pass of {args.profile_steps} "
                       "enhance calls right after the timed region; algorithmic FLOPs/bytes = reference (un-folded) "
                       "layer-granular accounting, SURVEY.md 8(d)",
         }

@@ -158,9 +158,11 @@ int ou_tensor(const ou_handle* h, const char* name, size_t* byte_offset, int32_t
 int ou_launch_stats(const ou_handle* h, int32_t* n_launches, int32_t* n_conv_launches);
 /* Reserved (intermediates are never aliased in this version, so ou_tensor() can return any of them). */
 int ou_set_debug(ou_handle* h, int32_t keep_intermediates);
-/* Measurement: when enabled, every launch of the generic conv kernel in subsequent forward calls is bracketed
- * by HIP events on the caller's stream.  ou_profile_read() synchronises them and returns, per launch, the
- * elapsed ms, the layer's algorithmic FLOPs / bytes (reference, un-folded accounting) and the tile config. */
+/* Measurement: when enabled, every launch of the generic conv kernel in subsequent forward calls records its own
+ * duration on the device (first block start .. last block end, constant 100 MHz clock -- HIP events around single
+ * launches also count the command-processor gaps and over-read by ~4 us).  ou_profile_read() synchronises the
+ * device and returns, per launch, the ms, the layer's algorithmic FLOPs / bytes (reference, un-folded
+ * accounting) and the tile config. */
 int ou_profile_enable(ou_handle* h, int32_t on);
 /* Tuning aid: time ONE packed conv layer (by its reference state-dict prefix) on synthetic data, optionally forcing
  * the tile configuration / chunks-per-stage; ms per launch from HIP events. */

@@ -20,6 +20,7 @@ using namespace ou;
 namespace {
 thread_local std::string g_last_error;
 constexpr int kMaxSteps = 256;
+constexpr size_t kProfSlots = 32768;
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 
 struct TensorRef {
@@ -52,9 +53,10 @@ struct ou_handle {
   int force_cfg = -1, force_sc = 0;  // micro-benchmark overrides (ou_bench_conv)
   // per-launch HIP-event profiling of the generic conv kernel (bench.py roofline)
   bool profile = false;
-  struct ProfRec { hipEvent_t a, b; double flops, bytes; int cfg; };
+  struct ProfRec { double flops, bytes; int cfg; };
   std::vector<ProfRec> prof;
   size_t prof_used = 0;
+  unsigned long long* prof_dev = nullptr;  // [kProfSlots][2] device-side {min start, ~max end} ticks
 };
 
 namespace {
@@ -142,23 +144,19 @@ struct Runner {
     { const char* d = std::getenv("OU_DBG"); a.dbg = d ? std::atoi(d) : 0; }
     a.tstamps = h->tstamps;
     int cfg = -1;
-    ou_handle::ProfRec* pr = nullptr;
-    if (h->profile) {
-      if (h->prof_used == h->prof.size()) {
-        ou_handle::ProfRec r{};
-        if (hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess) h->prof.push_back(r);
-      }
-      if (h->prof_used < h->prof.size()) {
-        pr = &h->prof[h->prof_used++];
-        // algorithmic (reference, un-folded) work of this layer: dense FLOPs, activations once, weights once
-        const int kref = L.KW;  // the packed layers now carry the reference's own kernel sizes
-        pr->flops = 2.0 * L.M * (double)Nq * L.Cin * kref * B;
-        pr->bytes = 4.0 * ((double)B * ((double)L.Cin * in.T + (double)L.Cout * Tout) + (double)L.M * L.Cin * kref);
-        (void)hipEventRecord(pr->a, st);
-      }
+    if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {
+      ou_handle::ProfRec rec;
+      // algorithmic (reference, un-folded) work of this layer: dense FLOPs, activations once, weights once
+      const int kref = L.KW;  // the packed layers carry the reference's own kernel sizes
+      rec.flops = 2.0 * L.M * (double)Nq * L.Cin * kref * B;
+      rec.bytes = 4.0 * ((double)B * ((double)L.Cin * in.T + (double)L.Cout * Tout) + (double)L.M * L.Cin * kref);
+      rec.cfg = -1;
+      a.prof = h->prof_dev + 2 * h->prof_used;
+      h->prof.push_back(rec);
+      h->prof_used++;
     }
     chk(launch_conv(a, h->num_cu, st, &cfg), L.name.c_str());
-    if (pr) { pr->cfg = cfg; (void)hipEventRecord(pr->b, st); }
+    if (a.prof) h->prof.back().cfg = cfg;
     h->last_cfg = cfg;
     if (h->trace)
       std::fprintf(stderr, "OU_TRACE conv %-64s cfg=%d M=%d Nq=%d K=%d(Cin=%d KW=%d CK=%d) stride=%d up=%d B=%d MFLOP=%.1f\n",
@@ -544,7 +542,7 @@ int ou_create(const ou_config* cfg, const void* weights_dev, size_t nbytes, int3
 
 void ou_destroy(ou_handle* h) {
   if (!h) return;
-  for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  if (h->prof_dev) (void)hipFree(h->prof_dev);
   delete h;
 }
 
@@ -790,6 +788,13 @@ int ou_profile_enable(ou_handle* h, int32_t on) {
   if (!h) return OU_EINVAL;
   h->profile = on != 0;
   h->prof_used = 0;
+  h->prof.clear();
+  if (on) {
+    // measurement buffer: owned by the library, allocated outside any forward call
+    if (!h->prof_dev && hipMalloc((void**)&h->prof_dev, kProfSlots * 16) != hipSuccess)
+      return fail(h, OU_EHIP, "hipMalloc(profile buffer) failed");
+    if (hipMemset(h->prof_dev, 0xFF, kProfSlots * 16) != hipSuccess) return fail(h, OU_EHIP, "hipMemset failed");
+  }
   return OU_OK;
 }
 
@@ -798,16 +803,18 @@ int ou_profile_read(ou_handle* h, int32_t max_records, float* ms, double* flops,
   if (!h || !n_records) return OU_EINVAL;
   int n = (int)h->prof_used;
   if (n > max_records) n = max_records;
-  for (int i = 0; i < n; i++) {
-    auto& r = h->prof[i];
-    hipError_t e = hipEventSynchronize(r.b);
-    float t = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&t, r.a, r.b);
+  std::vector<unsigned long long> host((size_t)2 * (n > 0 ? n : 1));
+  if (n > 0) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(host.data(), h->prof_dev, (size_t)n * 16, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(h, OU_EHIP, hipGetErrorString(e));
-    if (ms) ms[i] = t;
-    if (flops) flops[i] = r.flops;
-    if (bytes) bytes[i] = r.bytes;
-    if (cfg) cfg[i] = r.cfg;
+  }
+  for (int i = 0; i < n; i++) {
+    const unsigned long long t0 = host[2 * i], t1 = ~host[2 * i + 1];
+    if (ms) ms[i] = (t1 >= t0) ? (float)((double)(t1 - t0) * 1e-5) : 0.f;  // 100 MHz constant clock: 10 ns ticks
+    if (flops) flops[i] = h->prof[i].flops;
+    if (bytes) bytes[i] = h->prof[i].bytes;
+    if (cfg) cfg[i] = h->prof[i].cfg;
   }
   *n_records = n;
   return OU_OK;

@@ -32,6 +32,7 @@ struct ConvArgs {
   int force_cfg = -1, force_sc = 0;    // tuning overrides (ou_bench_conv)
   int dbg = 0;                         // phase ablation switches (tuning only)
   long long* tstamps = nullptr;        // per-wave phase cycle counts (tuning only)
+  unsigned long long* prof = nullptr;  // measurement: {min block start, ~max block end} in s_memrealtime ticks (10 ns)
 };
 // returns hipSuccess or the launch error; `cfg_out` (optional) receives the tile configuration index used
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out = nullptr);

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   for (int i = tid; i < 2 * BM; i += CONV_NT) Zs[i] = 0.f;
   const int nstages = p.Cin / SCK;
 
+  if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   long long tsv[8];
   const bool ts_on = p.tstamps != nullptr;
   if (ts_on) tsv[0] = __builtin_readcyclecounter();
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
       p.y[idx] = v;
     }
   }
+  if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
   if (ts_on && lane == 0) {
     long long* o = p.tstamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (CONV_NT / 64) + wave) * 8;
     o[0] = tsv[1] - tsv[0]; o[1] = tsv[2] - tsv[1]; o[2] = tsv[3] - tsv[2]; o[3] = tsv[4] - tsv[3];
