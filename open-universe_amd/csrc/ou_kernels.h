@@ -29,6 +29,7 @@ struct ConvArgs {
   unsigned magic_span[3] = {0, 0, 0};  // filled by launch_conv: 2^32/span + 1 for BN = 128 / 64 / 32
   unsigned magic_up = 0;               // 2^32/up + 1 (0 when up == 1)
   int SC = 1;                          // filled by launch_conv: packed chunks per pipeline stage
+  int grid_n = 1, grid_m = 1;          // filled by launch_conv: tile counts (1-D grid, XCD-aware mapping)
   int force_cfg = -1, force_sc = 0;    // tuning overrides (ou_bench_conv)
   int dbg = 0;                         // phase ablation switches (tuning only)
   long long* tstamps = nullptr;        // per-wave phase cycle counts (tuning only)

@@ -42,7 +42,22 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar step math
   const int kw = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, b = blockIdx.z;
+  // XCD-aware tile mapping: block i runs on XCD i % 8 (observed; speed only).  When there are >= 8 weight slabs
+  // (m-tiles), all time tiles of slab m go to XCD m % 8, so each slab is fetched into ONE L2 instead of eight.
+  int tile_m, tile_n;
+  {
+    const int L = blockIdx.x, gx = p.grid_n, gy = p.grid_m;
+    if ((gy & 7) == 0) {
+      const int q = L >> 3;
+      const int mg = q / gx;
+      tile_n = q - mg * gx;
+      tile_m = mg * 8 + (L & 7);
+    } else {
+      tile_m = L / gx;
+      tile_n = L - tile_m * gx;
+    }
+  }
+  const int n0 = tile_n * BN, m0 = tile_m * BM, b = blockIdx.z;
 
   const int KW = p.KW, CK = p.CK, stride = p.stride, SC = p.SC;
   const int span = (BN - 1) * stride + KW;
@@ -294,7 +309,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   }
   if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
   if (ts_on && lane == 0) {
-    long long* o = p.tstamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (CONV_NT / 64) + wave) * 8;
+    long long* o = p.tstamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * (CONV_NT / 64) + wave) * 8;
     o[0] = tsv[1] - tsv[0]; o[1] = tsv[2] - tsv[1]; o[2] = tsv[3] - tsv[2]; o[3] = tsv[4] - tsv[3];
     o[4] = __builtin_readcyclecounter() - tsv[4]; o[5] = t_mma; o[6] = t_wait; o[7] = tsv[0];
   }
@@ -349,6 +364,7 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
     if ((long)a.CK * span > CONV_XCAP) continue;
     if ((long)a.CK * a.KW * c.BM > (long)c.MAXW * c.NT * 4) continue;
     if (a.force_cfg < 0 && c.WK == 4) continue;  // superseded by the 8-wave split-K variants (tools/conv_sweep.py)
+    if (a.force_cfg < 0 && c.WK == 8 && c.BN == 64 && a.KW == 1 && a.Nq < 1024) continue;  // 1x1, tiny T: 32x32 wins
     pick = i;
     // measured on MI355X (tools/conv_sweep.py): the one-tile-per-wave configs want >= 1.5 blocks per CU before
     // they beat the next smaller tile; the 32x64 split-K config is still ahead of 32x32 at one block per CU
@@ -378,7 +394,9 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   const int bns[3] = {128, 64, 32};
   for (int i = 0; i < 3; i++) aa.magic_span[i] = (unsigned)(0x100000000ull / (unsigned)((bns[i] - 1) * a.stride + a.KW)) + 1u;
   aa.magic_up = a.up == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.up) + 1u;
-  dim3 grid((a.Nq + c.BN - 1) / c.BN, (a.M + c.BM - 1) / c.BM, a.B);
+  aa.grid_n = (a.Nq + c.BN - 1) / c.BN;
+  aa.grid_m = (a.M + c.BM - 1) / c.BM;
+  dim3 grid(aa.grid_n * aa.grid_m, 1, a.B);
   size_t smem = conv_smem_bytes(c, aa);
   // channel pairs of one wave per tap: groups of 4 when that divides, else groups of 2
   const int pairs = aa.SC * a.CK / 2, per_wave = (pairs + c.WK - 1) / c.WK;
@@ -427,28 +445,62 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const float* __restrict__
                                                        const float* x, const float* noise, float* out,
                                                        const StepCoef* coef, int coef_bstride, int edm, int mode, int C,
                                                        int T, int KW) {
+  // block = 64 time quads x 4 channel groups (one wave each); 4 consecutive output samples per thread from one
+  // aligned float4 + the halo scalars per channel row; the 4 partial sums meet in LDS
+  __shared__ float part[4][64][4];
   const int b = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= T) return;
+  const int tq = threadIdx.x & 63, cgp = threadIdx.x >> 6;
+  const int t0 = (blockIdx.x * 64 + tq) * 4;
   const float a1 = alphas[0], a2 = alphas[1];
-  const int pad = (KW - 1) / 2;
-  float acc = 0.f;
-  for (int c = 0; c < C; c++) {
-    const float* sr = s + ((size_t)b * C + c) * T;
+  const int pad = (KW - 1) / 2;  // <= 3
+  const bool vec = (T & 3) == 0;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int cpg = (C + 3) / 4;
+  if (t0 < T) {
+#pragma unroll 4
+    for (int cc = 0; cc < cpg; cc++) {
+      const int c = cgp * cpg + cc;
+      if (c >= C) break;
+      const float* sr = s + ((size_t)b * C + c) * T;
+      float v[10];  // samples t0-3 .. t0+6
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-      if (k < KW) {
-        int tt = t + k - pad;
-        float v = (tt >= 0 && tt < T) ? sr[tt] : 0.f;
-        v = prelu(prelu(v, a1), a2);
-        acc = fmaf(w[c * KW + k], v, acc);
+      for (int i = 0; i < 10; i++) v[i] = 0.f;
+      if (vec) {
+        const f32x4 m = *reinterpret_cast<const f32x4*>(sr + t0);
+        v[3] = m.x; v[4] = m.y; v[5] = m.z; v[6] = m.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[3 + i] = (t0 + i < T) ? sr[t0 + i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 1; i <= 3; i++) {
+        if (i <= pad) {
+          v[3 - i] = (t0 - i >= 0) ? sr[t0 - i] : 0.f;
+          v[6 + i] = (t0 + 3 + i < T) ? sr[t0 + 3 + i] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 10; i++) v[i] = prelu(prelu(v[i], a1), a2);
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        if (k < KW) {
+          const float wk = w[c * KW + k];
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[j] = fmaf(wk, v[3 + j + k - pad], acc[j]);
+        }
       }
     }
   }
-  float net = acc + bias[0];
+#pragma unroll
+  for (int j = 0; j < 4; j++) part[cgp][tq][j] = acc[j];
+  __syncthreads();
+  // thread (tq, j = cgp) finishes sample t0 + j
+  const int j = cgp, t = t0 + j;
+  if (t >= T) return;
+  const float net = ((part[0][tq][j] + part[1][tq][j]) + (part[2][tq][j] + part[3][tq][j])) + bias[0];
   const StepCoef cf = coef[(size_t)b * coef_bstride];
   const size_t i = (size_t)b * T + t;
-  float xv = x ? x[i] : 0.f;
+  const float xv = x ? x[i] : 0.f;
   float score = net;
   if (edm) {
     float est = cf.w_skip * xv + cf.w_out * net;  // universe.py:203
