@@ -50,6 +50,12 @@ struct ou_handle {
   int last_cfg = -1;
   long long* tstamps = nullptr;
   std::map<size_t, float> alphas;  // host copies of the PReLU slopes (blob offset -> value)
+  // side streams for independent branches (mel front-end, st convs, first score-encoder pass), fork/joined to the
+  // caller's stream with events: still no host synchronisation, still graph-capturable
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> events;
+  size_t ev_used = 0;
+  bool overlap = true;
   int force_cfg = -1, force_sc = 0;  // micro-benchmark overrides (ou_bench_conv)
   // per-launch HIP-event profiling of the generic conv kernel (bench.py roofline)
   bool profile = false;
@@ -88,7 +94,7 @@ struct Runner {
   const char* where = "";
 
   Runner(ou_handle* h_, void* ws, size_t cap_, bool dry_, hipStream_t st_, int B_)
-      : h(h_), base((char*)ws), cap(cap_), dry(dry_), st(st_), B(B_) {}
+      : h(h_), base((char*)ws), cap(cap_), dry(dry_), st(st_), B(B_), main_st(st_) {}
 
   float* alloc_raw(size_t floats) {
     size_t bytes = (floats * 4 + 255) & ~size_t(255);
@@ -105,6 +111,31 @@ struct Runner {
     t.T = T;
     if (!name.empty()) h->tensors[name] = TensorRef{o, C, T};
     return t;
+  }
+  hipStream_t main_st = nullptr;
+  hipEvent_t next_event() {
+    if (h->ev_used == h->events.size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      h->events.push_back(e);
+    }
+    return h->events[h->ev_used++];
+  }
+  // make side stream k wait for everything enqueued so far on `from`
+  void fork(hipStream_t from, int k) {
+    if (dry) return;
+    hipEvent_t e = next_event();
+    if (!e) { herr = hipErrorOutOfMemory; where = "event"; return; }
+    chk(hipEventRecord(e, from), "fork record");
+    chk(hipStreamWaitEvent(h->aux[k], e, 0), "fork wait");
+  }
+  // make `to` wait for everything enqueued so far on side stream k
+  void join(int k, hipStream_t to) {
+    if (dry) return;
+    hipEvent_t e = next_event();
+    if (!e) { herr = hipErrorOutOfMemory; where = "event"; return; }
+    chk(hipEventRecord(e, h->aux[k]), "join record");
+    chk(hipStreamWaitEvent(to, e, 0), "join wait");
   }
   bool ok() const { return herr == hipSuccess && !oom; }
   void chk(hipError_t e, const char* w) {
@@ -224,6 +255,7 @@ struct Runner {
     a.gx = gx.p; a.whh = W(G.whh_off); a.bhn = W(G.bhn_off); a.out = out.p; a.res = res; a.res_scale = res_scale;
     a.xchg = xchg; a.err = errw; a.B = B; a.T = in.T; a.H = G.H;
     if (std::getenv("OU_GRU_TS")) a.tstamps = (long long*)(base + cap - (1u << 20));
+    { const char* f = std::getenv("OU_GRU_UPW"); a.force_upw = f ? std::atoi(f) : 0; }
     chk(launch_gru(a, h->num_cu, st), G.name.c_str());
     return out;
   }
@@ -234,7 +266,8 @@ struct Persist {
   unsigned* status;
   StepCoef* coef;             // [kMaxSteps] or [B]
   float* stats;               // [B][4]
-  unsigned long long* xchg;   // GRU granules
+  unsigned long long* xchg;   // GRU granules (conditioner)
+  unsigned long long* xchg2;  // GRU granules (score net; may run concurrently with the conditioner)
   float* mel_scale;           // [B]
   float* g;                   // [kMaxSteps][D]
   float* film;                // [kMaxSteps][rows]
@@ -252,6 +285,7 @@ Persist layout_persist(Runner& r, int T) {
   P.coef = (StepCoef*)r.alloc_raw((size_t)ncoef * 8);
   P.stats = r.alloc_raw((size_t)r.B * 4);
   P.xchg = (unsigned long long*)r.alloc_raw((size_t)r.B * 4 * (m.OC / 2) * 2);
+  P.xchg2 = (unsigned long long*)r.alloc_raw((size_t)r.B * 4 * (m.OC / 2) * 2);
   P.mel_scale = r.alloc_raw(r.B);
   P.g = r.alloc_raw((size_t)ncoef * m.film.D);
   P.film = r.alloc_raw((size_t)ncoef * m.film.rows);
@@ -278,7 +312,10 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
   const Model& m = r.h->m;
   const int L = T / m.tot_ds;
   const int n = m.n_levels - 1;
-  // --- MelAdapter  condition.py:110-114
+  hipStream_t main = r.st;
+  const bool ov = r.h->overlap && !r.dry;
+  // --- MelAdapter  condition.py:110-114 (independent of the encoder chain: side stream 0)
+  if (ov) { r.fork(main, 0); r.st = r.h->aux[0]; }
   Tensor mel = r.alloc("cond.mel", m.mel.n_mels, L);
   float* esum = r.alloc_raw((size_t)r.B * L);
   if (!r.dry && r.ok()) {
@@ -291,6 +328,7 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
   em.act = false;
   Tensor m0 = r.conv(m.c_melconv, mel, "cond.melconv", em);
   Tensor x_mel = r.block(m.c_melblock, m0, "cond.melblock", nullptr, 0, nullptr, nullptr).v;
+  r.st = main;
   // --- input conv + encoder  condition.py:360, 189-206
   Tensor e0 = r.alloc("cond.in", m.C0, T);
   if (!r.dry && r.ok())
@@ -300,6 +338,8 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
   for (int i = 0; i < m.n_blocks; i++) {
     auto bo = r.block(m.c_enc[i], hcur, "cond.enc" + std::to_string(i), nullptr, 0, nullptr, nullptr);
     if (i < n - 1) {
+      // strided "st" conv of this block's output: off the critical path (side stream 1)
+      if (ov) { r.fork(main, 1); r.st = r.h->aux[1]; }
       const ConvL& S = m.c_st[i];
       const int R = S.rate, C = S.Cin / R;
       Tensor sd = r.alloc("cond.s2d" + std::to_string(i), S.Cin, bo.v.T / R);
@@ -307,10 +347,12 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
       Runner::Epi es;
       es.act = false;  // PReLU already applied by the space-to-depth pass
       outs.push_back(r.conv(S, sd, "cond.st" + std::to_string(i), es));
+      r.st = main;
     }
     hcur = bo.h_next;
   }
   outs.push_back(hcur);
+  if (ov) { r.join(0, main); r.join(1, main); }
   Tensor sum = r.alloc("cond.enc_sum", m.OC, L);
   if (!r.dry && r.ok()) {
     const float* q[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -347,37 +389,54 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
 
 // ScoreNetwork.forward + EDM wrapper + sampler update for the coefficient rows at `coef`
 //   film_row: pointer to this step's FiLM table row(s); film_bs / coef_bs: per-batch strides (0 = shared)
-void run_score(Runner& r, Persist& P, const float* x, const float* noise, float* out, int mode,
-               const StepCoef* coef, int coef_bs, const float* film_row, int film_bs, int T) {
+// Split in two halves: the encoder + GRU half does not depend on the conditioner (cond enters the decoder only),
+// so the first step's encoder can run concurrently with it.
+struct ScoreEnc {
+  std::vector<Tensor> residuals;
+  Tensor hg;
+  bool fuse_res = false;
+};
+ScoreEnc run_score_enc(Runner& r, Persist& P, const float* x, const StepCoef* coef, int coef_bs,
+                       const float* film_row, int film_bs, int T) {
   const Model& m = r.h->m;
+  ScoreEnc E;
   Tensor e0 = r.alloc("score.in", m.C0, T);
   // the w_in scaling of the EDM wrapper (universe.py:199,202) rides on the input conv
   if (!r.dry && r.ok())
     r.chk(launch_in_conv(x, r.W(m.s_in.w_off), r.W(m.s_in.b_off), coef, coef_bs, e0.p, r.B, m.C0, T, m.s_in.KW, r.st),
           "score.in");
   Tensor hcur = e0;
-  std::vector<Tensor> residuals;
   for (int i = 0; i < m.n_blocks; i++) {
     const float* fr = film_row ? film_row + m.film.enc_off[i] : nullptr;
     auto bo = r.block(m.s_enc[i], hcur, "score.enc" + std::to_string(i), fr, film_bs, nullptr, nullptr);
-    residuals.push_back(bo.v);
+    E.residuals.push_back(bo.v);
     hcur = bo.h_next;
   }
   // GRU bottleneck; when decoder block 0 has no rate change its residual add (blocks.py:374-376) is fused here
-  const bool fuse_res = m.s_dec[0].dir == 0;
-  Tensor hg = r.gru(m.s_gru, hcur, "score.gru", P.xchg, P.status,
-                    fuse_res && !r.dry ? residuals[m.n_blocks - 1].p : nullptr, kInvSqrt2);
-  Tensor y = hg;
+  E.fuse_res = m.s_dec[0].dir == 0;
+  E.hg = r.gru(m.s_gru, hcur, "score.gru", P.xchg2, P.status,
+               E.fuse_res && !r.dry ? E.residuals[m.n_blocks - 1].p : nullptr, kInvSqrt2);
+  return E;
+}
+void run_score_dec(Runner& r, Persist& P, const ScoreEnc& E, const float* x, const float* noise, float* out, int mode,
+                   const StepCoef* coef, int coef_bs, const float* film_row, int film_bs, int T) {
+  const Model& m = r.h->m;
+  Tensor y = E.hg;
   for (int j = 0; j < m.n_blocks; j++) {
     const float* fr = film_row ? film_row + m.film.dec_off[j] : nullptr;
-    const Tensor& res = residuals[m.n_blocks - 1 - j];
-    const float* resp = (j == 0 && fuse_res) ? nullptr : res.p;
+    const Tensor& res = E.residuals[m.n_blocks - 1 - j];
+    const float* resp = (j == 0 && E.fuse_res) ? nullptr : res.p;
     auto bo = r.block(m.s_dec[j], y, "score.dec" + std::to_string(j), fr, film_bs, P.sc[j].p, resp);
     y = bo.v;
   }
   if (!r.dry && r.ok())
     r.chk(launch_out_conv(y.p, r.W(m.s_out.w_off), r.W(m.s_out.b_off), r.W(m.s_out.a_off), x, noise, out, coef,
                           coef_bs, m.cfg.has_edm, mode, r.B, m.C0, T, m.s_out.KW, r.st), "score.out");
+}
+void run_score(Runner& r, Persist& P, const float* x, const float* noise, float* out, int mode,
+               const StepCoef* coef, int coef_bs, const float* film_row, int film_bs, int T) {
+  ScoreEnc E = run_score_enc(r, P, x, coef, coef_bs, film_row, film_bs, T);
+  run_score_dec(r, P, E, x, noise, out, mode, coef, coef_bs, film_row, film_bs, T);
 }
 
 // universe.py:175-189, 197-209, 333-343 scalars for one sigma, computed in fp32 like the reference's tensors
@@ -536,6 +595,11 @@ int ou_create(const ou_config* cfg, const void* weights_dev, size_t nbytes, int3
   }
   he = init_conv_kernels();
   if (he != hipSuccess) { delete h; return fail(nullptr, OU_EHIP, hipGetErrorString(he)); }
+  for (int i = 0; i < 3; i++) {
+    he = hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking);
+    if (he != hipSuccess) { delete h; return fail(nullptr, OU_EHIP, hipGetErrorString(he)); }
+  }
+  h->overlap = std::getenv("OU_NO_OVERLAP") == nullptr;
   *out = h;
   return OU_OK;
 }
@@ -543,6 +607,8 @@ int ou_create(const ou_config* cfg, const void* weights_dev, size_t nbytes, int3
 void ou_destroy(ou_handle* h) {
   if (!h) return;
   if (h->prof_dev) (void)hipFree(h->prof_dev);
+  for (auto& e : h->events) (void)hipEventDestroy(e);
+  for (int i = 0; i < 3; i++) if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
   delete h;
 }
 
@@ -575,6 +641,7 @@ int ou_condition(ou_handle* h, const float* mix_norm, int32_t B, int32_t T, void
   if (T % h->m.tot_ds || T <= 0) return fail(h, OU_EINVAL, "T must be a positive multiple of the total down-sampling factor");
   h->tensors.clear();
   h->n_launch = h->n_conv = 0;
+  h->ev_used = 0;
   Runner r(h, ws, ws_bytes, false, (hipStream_t)stream, B);
   Persist P = layout_persist(r, T);
   if (r.oom) return finish(h, r);
@@ -647,6 +714,7 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
   const int T = T_raw + pad;
   h->tensors.clear();
   h->n_launch = h->n_conv = 0;
+  h->ev_used = 0;
   hipStream_t st = (hipStream_t)stream;
   Runner r(h, ws, ws_bytes, false, st, B);
   Persist P = layout_persist(r, T);
@@ -664,17 +732,53 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
 
   const float level = (float)std::pow(10.0, (double)m.cfg.level_db / 20.0);
   r.chk(launch_pad_normalize(mix, P.mixn.p, P.stats, B, T_raw, T, pad_left, level, st), "normalize");
-  run_condition(r, P, P.mixn.p, T);
-  h->cond_B = B;
-  h->cond_T = T;
   const size_t nBT = (size_t)B * T;
   const int keep_rms = (flags & OU_ENH_KEEP_RMS) ? 1 : 0;
   const int peak = (flags & OU_ENH_NO_PEAK_GUARD) ? 0 : 1;
+  const bool need_wav = use_aux || warm_start >= 0;
+  if (need_wav && (!m.dec.present || m.dec.act != OU_ACT_SNAKE))
+    return fail(h, OU_ENOTIMPL, "aux_to_wav needs the snake signal-decoupling layer (UNIVERSE++)");
+  const int n_start = warm_start >= 0 ? warm_start : 0;
 
-  bool need_wav = use_aux || warm_start >= 0;
+  // Where the conditioner's scratch ends (= where the per-step score scratch starts): layout is a pure function of
+  // (config, B, T), so a dry walk gives it before anything is launched.
+  size_t mark;
+  {
+    auto keep = h->tensors;
+    Runner d(h, nullptr, 0, true, nullptr, B);
+    Persist Pd = layout_persist(d, T);
+    run_condition(d, Pd, nullptr, T);
+    mark = d.off;
+    h->tensors = keep;
+  }
+
+  // The first score-encoder pass (+ its GRU) does not depend on the conditioner: run it on side stream 2 while
+  // the conditioner runs on the caller's stream (at batch 1 most CUs idle during the GRU passes of either).
+  ScoreEnc E0;
+  bool have_e0 = false;
+  size_t off_after_enc = 0;
+  if (!use_aux) {
+    r.chk(launch_sigma_embed(P.coef, n_steps, r.W(m.sigma.p_off), m.sigma.simple, m.sigma.n_rff, m.film.D, P.g, st), "sigma");
+    r.chk(launch_film(P.g, r.W(m.film.w_off), r.W(m.film.b_off), P.film, n_steps, m.film.rows, m.film.D, st), "film");
+    if (warm_start < 0 && h->overlap) {
+      r.chk(launch_init_x(noise, nullptr, sigma[n_start], P.x.p, nBT, st), "init x");  // universe.py:325-327
+      const size_t save = r.off;
+      r.fork(st, 2);
+      r.st = h->aux[2];
+      r.off = mark;
+      E0 = run_score_enc(r, P, P.x.p, P.coef + n_start, 0, P.film + (size_t)n_start * m.film.rows, 0, T);
+      off_after_enc = r.off;
+      r.st = st;
+      r.off = save;
+      have_e0 = true;
+    }
+  }
+  run_condition(r, P, P.mixn.p, T);
+  if (!r.dry && r.ok() && r.off != mark) return fail(h, OU_EINVAL, "internal: workspace layout mismatch");
+  h->cond_B = B;
+  h->cond_T = T;
+
   if (need_wav) {
-    if (!m.dec.present || m.dec.act != OU_ACT_SNAKE)
-      return fail(h, OU_ENOTIMPL, "aux_to_wav needs the snake signal-decoupling layer (UNIVERSE++)");
     float* tmp = r.alloc_raw((size_t)B * m.C0 * 2 * T);
     if (r.ok())
       r.chk(launch_decoupling(P.aux.p, r.W(m.dec.alpha_off), r.W(m.dec.up_off), r.W(m.dec.down_off),
@@ -684,19 +788,23 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
     if (r.ok()) r.chk(launch_post(P.wav.p, P.stats, out, B, T_raw, T, pad_left, keep_rms, peak, st), "post");
     return finish(h, r);
   }
-  r.chk(launch_sigma_embed(P.coef, n_steps, r.W(m.sigma.p_off), m.sigma.simple, m.sigma.n_rff, m.film.D, P.g, st), "sigma");
-  r.chk(launch_film(P.g, r.W(m.film.w_off), r.W(m.film.b_off), P.film, n_steps, m.film.rows, m.film.D, st), "film");
-
-  const int n_start = warm_start >= 0 ? warm_start : 0;
   // universe.py:325-331
-  r.chk(launch_init_x(noise, warm_start >= 0 ? P.wav.p : nullptr, sigma[n_start], P.x.p, nBT, st), "init x");
-  const size_t mark = r.off;
-  auto mark_tensors = h->tensors;
+  if (!have_e0)
+    r.chk(launch_init_x(noise, warm_start >= 0 ? P.wav.p : nullptr, sigma[n_start], P.x.p, nBT, st), "init x");
+  const size_t step_mark = r.off;
   for (int n = n_start; n < n_steps; n++) {
-    r.off = mark;  // every step re-uses the same scratch
     const bool last = n == n_steps - 1;
     const float* z = last ? nullptr : noise + (size_t)(n - n_start + 1) * nBT;
-    run_score(r, P, P.x.p, z, P.x.p, OUT_UPDATE, P.coef + n, 0, P.film + (size_t)n * m.film.rows, 0, T);
+    const StepCoef* cf = P.coef + n;
+    const float* fr = P.film + (size_t)n * m.film.rows;
+    if (n == n_start && have_e0) {
+      r.join(2, st);
+      r.off = off_after_enc;
+      run_score_dec(r, P, E0, P.x.p, z, P.x.p, OUT_UPDATE, cf, 0, fr, 0, T);
+    } else {
+      r.off = step_mark;  // every step re-uses the same scratch
+      run_score(r, P, P.x.p, z, P.x.p, OUT_UPDATE, cf, 0, fr, 0, T);
+    }
     if (!r.ok()) break;
   }
   if (r.ok()) r.chk(launch_post(P.x.p, P.stats, out, B, T_raw, T, pad_left, keep_rms, peak, st), "post");

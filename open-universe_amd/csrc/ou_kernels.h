@@ -96,7 +96,7 @@ hipError_t launch_sum(const float* a, const float* b, const float* c, const floa
 //   gx : (B, 6H, T) input projection incl. biases ; out: (B, 2H, T) ; out = res ? (h + res)*scale : h
 struct GruArgs {
   const float* gx = nullptr;
-  const float* whh = nullptr;
+  const float* whh = nullptr;  // canonical [dir][3H][H] row-major
   const float* bhn = nullptr;
   float* out = nullptr;
   const float* res = nullptr;
@@ -105,6 +105,7 @@ struct GruArgs {
   unsigned* err = nullptr;             // device status word
   long long* tstamps = nullptr;        // per-wave cycle breakdown (tuning only)
   int B = 1, T = 0, H = 0;
+  int force_upw = 0;  // tuning: 16 / 32 / 64 hidden units per workgroup (0: chosen from the batch size)
 };
 hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st);
 

@@ -916,6 +916,12 @@ __device__ __forceinline__ float row8_sum(float v) {
   v = dpp_add<0x141>(v);  // row_half_mirror: lane i <-> 7-i within each 8
   return v;
 }
+// sum over the 16 lanes of a DPP row (every lane ends with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+  v = row8_sum(v);
+  v = dpp_add<0x140>(v);  // row_mirror: lane i <-> 15-i
+  return v;
+}
 // Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): the gate math is
 // a serial chain on the critical path of every GRU time step, libm-grade expf/tanhf/division cost ~100 dependent
 // instructions there.  Absolute error ~2e-7, two orders of magnitude inside the parity gate.
@@ -930,41 +936,49 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr unsigned GRU_SPIN_LIMIT = 4000000u;
 
-// Thread mapping: workgroup g owns hidden units [64g, 64g+64); thread (u, cg) = (tid/8, tid%8) holds, for unit
-// 64g+u, the three gate rows (r, z, n) x columns {4cg + 32i + 0..3, i < H/32} = 3*H/8 weights in registers.
-// Per step: H/32 ds_read_b128 of h, 3*H/16 v_pk_fma_f32, a 3-stage DPP reduction of the 3 gate sums over the 8
-// lanes of the unit, the gate math in lane cg == 0, publish.
-template <int HB>
-__global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int nclusters) {
-  constexpr int H = 64 * HB, NI = 2 * HB, NR = 12 * NI;  // NI column blocks of 32; NR weights per thread
+// Thread mapping: a direction's H hidden units are split over NWG = H/UPW workgroups of NT threads;
+// LPU = NT/UPW lanes share one unit: thread (u, cg) = (tid/LPU, tid%LPU) holds, for unit UPW*g + u, the three gate
+// rows (r, z, n) x columns {4cg + 4*LPU*i + 0..3, i < NI = H/(4*LPU)} in registers (gathered from the canonical
+// row-major W_hh at kernel start).  Per step: NI ds_read_b128 of h, 6*NI v_pk_fma_f32, a DPP reduction of the 3 gate
+// sums over the LPU lanes of the unit, the gate math in lane cg == 0, publish.
+// Variants (chosen by launch_gru from the batch size): <64 units, 512 thr> = 4 workgroups per direction at H = 256
+// (throughput: 8 CUs per utterance), <32, 512> = 8, <16, 256> = 16 (latency: one wave per SIMD, least work per step).
+template <int HB, int UPW, int NT>
+__global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int nclusters) {
+  constexpr int H = 64 * HB, LPU = NT / UPW, NI = H / (4 * LPU), NR = 12 * NI, NWG = H / UPW;
+  static_assert(LPU == 8 || LPU == 16, "8 or 16 lanes per hidden unit");
+  static_assert(H % (4 * LPU) == 0, "column blocks");
   __shared__ __attribute__((aligned(16))) float hbuf[2][H];
   __shared__ int abort_flag;
   const int tid = threadIdx.x, lane = tid & 63;
   // Workgroup -> (cluster, member): the dispatcher places block i on XCD i % 8 (observed, speed only), so the
-  // HB members of a cluster are given ids that are congruent mod 8 and share one L2.  Correctness does not
+  // NWG members of a cluster are given ids that are congruent mod 8 and share one L2.  Correctness does not
   // depend on it: the exchange below is agent-scope.
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
-  const int cluster = xcd + 8 * (slot / HB);
-  const int g = slot % HB;
+  const int cluster = xcd + 8 * (slot / NWG);
+  const int g = slot % NWG;
   if (cluster >= nclusters) return;
   const int dir = cluster & 1, b = cluster >> 1;
-  const int ul = tid >> 3, cg = tid & 7;
+  const int ul = tid / LPU, cg = tid % LPU;
+  const int unit = g * UPW + ul;
   const int T = p.T;
 
   f32x2 w[NR / 2];
   {
-    const float* wp = p.whh + ((size_t)(dir * HB + g) * NR) * 512 + tid;
+    const float* wd = p.whh + (size_t)dir * 3 * H * H;
 #pragma unroll
-    for (int r = 0; r < NR / 2; r++) {
-      w[r].x = wp[(size_t)(2 * r) * 512];
-      w[r].y = wp[(size_t)(2 * r + 1) * 512];
-    }
+    for (int gt = 0; gt < 3; gt++)
+#pragma unroll
+      for (int i = 0; i < NI; i++) {
+        const float4 v = *reinterpret_cast<const float4*>(wd + (size_t)(gt * H + unit) * H + cg * 4 + 4 * LPU * i);
+        w[(gt * NI + i) * 2] = f32x2{v.x, v.y};
+        w[(gt * NI + i) * 2 + 1] = f32x2{v.z, v.w};
+      }
   }
-  for (int i = tid; i < 2 * H; i += 512) (&hbuf[0][0])[i] = 0.f;
+  for (int i = tid; i < 2 * H; i += NT) (&hbuf[0][0])[i] = 0.f;
   if (tid == 0) abort_flag = 0;
 
-  const int unit = g * 64 + ul;
   const bool fin = cg == 0;
   const float bhn = p.bhn[dir * H + unit];
   const float* gxb = p.gx + ((size_t)b * 6 * H + (size_t)dir * 3 * H) * T;
@@ -995,7 +1009,7 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int ncluste
     for (int gt = 0; gt < 3; gt++) { acc[gt][0] = 0.f; acc[gt][1] = 0.f; }
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-      const float4 hv = *reinterpret_cast<const float4*>(&hbuf[cur][cg * 4 + 32 * i]);
+      const float4 hv = *reinterpret_cast<const float4*>(&hbuf[cur][cg * 4 + 4 * LPU * i]);
       const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
 #pragma unroll
       for (int gt = 0; gt < 3; gt++) {
@@ -1006,7 +1020,10 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int ncluste
     }
     float hs[3];
 #pragma unroll
-    for (int gt = 0; gt < 3; gt++) hs[gt] = row8_sum((acc[gt][0].x + acc[gt][0].y) + (acc[gt][1].x + acc[gt][1].y));
+    for (int gt = 0; gt < 3; gt++) {
+      const float part = (acc[gt][0].x + acc[gt][0].y) + (acc[gt][1].x + acc[gt][1].y);
+      hs[gt] = LPU == 8 ? row8_sum(part) : row16_sum(part);
+    }
 
     // next step's input-projection / residual values: issued now, consumed one iteration later, so that no
     // global-load latency ever sits between the gate math and the publish below
@@ -1022,7 +1039,7 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int ncluste
       const float n = tanhf_(xn + r * (hs[2] + bhn));
       const float hp = hbuf[cur][unit];
       const float hnew = (hp - n) * z + n;
-      if (HB > 1) {  // publish first: the other workgroups are waiting on this
+      if (NWG > 1) {  // publish first: the other workgroups are waiting on this
         unsigned long long gran = ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned)__float_as_int(hnew);
         __hip_atomic_store(xq + (size_t)(cur ^ 1) * H + unit, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1032,8 +1049,8 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int ncluste
     xr = nxr; xz = nxz; xn = nxn; rs = nrs;
     if (ts_on) q1 = __builtin_readcyclecounter();
 
-    if (HB > 1 && tid < 64) {
-      // gather the other workgroups' slices: each lane owns H/64 granules; all polls in flight together
+    if (NWG > 1 && tid < 64) {
+      // gather the other workgroups' slices: lane l polls granules l, l+64, ...; all polls in flight together
       const unsigned tag = (unsigned)(step + 1);
       unsigned long long* src = xq + (size_t)(cur ^ 1) * H + lane;
       unsigned long long v[HB];
@@ -1042,8 +1059,9 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int ncluste
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < HB; k++) {
-          v[k] = (k == g) ? ((unsigned long long)tag << 32)
-                          : __hip_atomic_load(src + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool own = (k * 64 + lane) / UPW == g;
+          v[k] = own ? ((unsigned long long)tag << 32)
+                     : __hip_atomic_load(src + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok = ok && ((unsigned)(v[k] >> 32) == tag);
         }
         if (ok) break;
@@ -1051,12 +1069,12 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int ncluste
       }
 #pragma unroll
       for (int k = 0; k < HB; k++)
-        if (k != g) hbuf[cur ^ 1][k * 64 + lane] = __int_as_float((int)(unsigned)v[k]);
+        if ((k * 64 + lane) / UPW != g) hbuf[cur ^ 1][k * 64 + lane] = __int_as_float((int)(unsigned)v[k]);
     }
     if (ts_on) q2 = __builtin_readcyclecounter();
     __syncthreads();
     if (ts_on) { long long q3 = __builtin_readcyclecounter(); c_comp += q1 - q0; c_poll += q2 - q1; c_bar += q3 - q2; }
-    if (HB > 1 && abort_flag) {
+    if (NWG > 1 && abort_flag) {
       if (tid == 0) atomicOr(p.err, 1u);
       break;
     }
@@ -1067,11 +1085,28 @@ __global__ __launch_bounds__(512) void gru_cluster_kernel(GruArgs p, int ncluste
   }
 }
 
+template <int HB>
+static hipError_t launch_gru_variant(const GruArgs& c, int upw, int nclusters, hipStream_t st) {
+  constexpr int H = 64 * HB;
+  const int nwg = H / upw;
+  dim3 grid(8 * nwg * ((nclusters + 7) / 8));
+  if (upw == 64) hipLaunchKernelGGL((gru_cluster_kernel<HB, 64, 512>), grid, dim3(512), 0, st, c, nclusters);
+  else if (upw == 32) hipLaunchKernelGGL((gru_cluster_kernel<HB, 32, 512>), grid, dim3(512), 0, st, c, nclusters);
+  else hipLaunchKernelGGL((gru_cluster_kernel<HB, 16, 256>), grid, dim3(256), 0, st, c, nclusters);
+  return hipGetLastError();
+}
+
 hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
   if (a.H % 64) return hipErrorInvalidValue;
   const int HB = a.H / 64;
-  // every workgroup of a cluster must be resident at once: one 512-thread workgroup per CU
-  int bmax = (num_cu / (8 * HB)) * 8 / 2;  // clusters are dealt to XCDs in groups of 8
+  // every workgroup of a cluster must be resident at once (one workgroup per CU); clusters are dealt to XCDs in
+  // groups of 8.  Take the finest split (least work per time step) that still runs the whole batch in ONE launch.
+  // Measured (tools/gru_ts.py): 16 / 32 / 64 units per workgroup all end at ~3200 cycles per step -- what the
+  // finer splits save in compute they lose in exchange (more pollers on the L2) -- so the default is the split
+  // that needs the fewest CUs.
+  const int upw = a.force_upw ? a.force_upw : 64;
+  const int nwg = a.H / upw;
+  const int bmax = (num_cu / (8 * nwg)) * 8 / 2;
   if (bmax < 1) return hipErrorInvalidConfiguration;
   for (int b0 = 0; b0 < a.B; b0 += bmax) {
     GruArgs c = a;
@@ -1079,20 +1114,18 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
     c.gx = a.gx + (size_t)b0 * 6 * a.H * a.T;
     c.out = a.out + (size_t)b0 * 2 * a.H * a.T;
     if (a.res) c.res = a.res + (size_t)b0 * 2 * a.H * a.T;
-    if (HB > 1) {
+    if (nwg > 1) {
       hipError_t e = hipMemsetAsync(c.xchg, 0, (size_t)c.B * 4 * a.H * sizeof(unsigned long long), st);
       if (e != hipSuccess) return e;
     }
-    const int nclusters = 2 * c.B;
-    dim3 grid(8 * HB * ((nclusters + 7) / 8));
+    hipError_t e;
     switch (HB) {
-      case 1: hipLaunchKernelGGL(gru_cluster_kernel<1>, grid, dim3(512), 0, st, c, nclusters); break;
-      case 2: hipLaunchKernelGGL(gru_cluster_kernel<2>, grid, dim3(512), 0, st, c, nclusters); break;
-      case 4: hipLaunchKernelGGL(gru_cluster_kernel<4>, grid, dim3(512), 0, st, c, nclusters); break;
-      case 6: hipLaunchKernelGGL(gru_cluster_kernel<6>, grid, dim3(512), 0, st, c, nclusters); break;
+      case 1: e = launch_gru_variant<1>(c, upw, 2 * c.B, st); break;
+      case 2: e = launch_gru_variant<2>(c, upw, 2 * c.B, st); break;
+      case 4: e = launch_gru_variant<4>(c, upw, 2 * c.B, st); break;
+      case 6: e = launch_gru_variant<6>(c, upw, 2 * c.B, st); break;
       default: return hipErrorInvalidConfiguration;
     }
-    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   return hipSuccess;

@@ -453,26 +453,17 @@ struct Packer {
     pack_conv(B.c3);
   }
 
-  // Recurrent weights for the cluster kernel (ou_kernels.hip, gru_cluster_kernel):
-  //   [dir][wg g][reg r][tid]  with tid = u*8 + cg, r = ((gate*NI + i)*4 + c), NI = H/32,
-  //   row = gate*H + 64g + u, col = 4cg + 32i + c
+  // Recurrent weights: canonical [dir][3H][H] row-major (each gru_cluster_kernel variant gathers its own register
+  // image from it at kernel start), plus b_hn [dir][H].
   void pack_gru(const GruL& G) {
     pack_conv(G.proj);
-    const int H = G.H, HB = H / 64, NI = H / 32, NR = 12 * NI;
+    const int H = G.H;
     for (int d = 0; d < 2; d++) {
       std::string sfx = "_l" + std::to_string(G.layer) + (d ? "_reverse" : "");
       const HostTensor* whh = get(G.name + ".weight_hh" + sfx, {3 * H, H});
       const HostTensor* bhh = get(G.name + ".bias_hh" + sfx, {3 * H});
       if (!whh || !bhh) return;
-      for (int g = 0; g < HB; g++)
-        for (int r = 0; r < NR; r++) {
-          int c = r & 3, i = (r >> 2) % NI, gate = (r >> 2) / NI;
-          for (int tid = 0; tid < 512; tid++) {
-            int u = tid >> 3, cg = tid & 7;
-            int row = gate * H + g * 64 + u, col = cg * 4 + 32 * i + c;
-            blob[G.whh_off + (((size_t)d * HB + g) * NR + r) * 512 + tid] = whh->data[(size_t)row * H + col];
-          }
-        }
+      putf(G.whh_off + (size_t)d * 3 * H * H, whh->data.data(), (size_t)3 * H * H);
       for (int j = 0; j < H; j++) blob[G.bhn_off + (size_t)d * H + j] = bhh->data[2 * H + j];
     }
   }

@@ -10,15 +10,17 @@ from open_universe_amd import Universe, state_dict as S, _lib
 spec = get_spec("PP16")
 model = Universe(spec, state_dict=S.synthetic_state_dict(spec, 0), device="cuda:0")
 p = "_edm_model"
-layers = [(p + ".encoder.ds_modules.0.conv1", 64160, 502 * 1), (p + ".encoder.ds_modules.1.conv1", 32080, 251),
-          (p + ".encoder.ds_modules.3.conv1", 2005, 256), (p + ".encoder.ds_modules.4.conv1", 401, 208)]
+layers = [(p + ".encoder.ds_modules.0.conv1", 64160, 502, 4), (p + ".encoder.ds_modules.1.conv1", 32080, 502, 4),
+          (p + ".encoder.ds_modules.2.conv1", 8020, 504, 8),
+          (p + ".encoder.ds_modules.3.conv1", 2005, 256, 8), (p + ".encoder.ds_modules.4.conv1", 401, 208, 8),
+          (p + ".encoder.ds_modules.4.conv2", 401, 208, 8)]
 ws = torch.zeros(1 << 29, dtype=torch.uint8, device="cuda")
-for name, Tin, nblk in layers:
+for name, Tin, nblk, nw in layers:
     ms, used = c_float(), c_int32()
     _lib.check(model._L.ou_bench_conv(model._handle, name.encode(), 1, Tin, -1, -1, 1, 3, c_void_p(ws.data_ptr()),
                                       c_size_t(ws.numel()), model._stream(), byref(ms), byref(used)), model._handle)
     torch.cuda.synchronize()
-    ts = ws[ws.numel() - (16 << 20):].view(torch.int64)[: nblk * 4 * 8].view(nblk, 4, 8).cpu().double(); ws[ws.numel() - (16 << 20):].zero_()
+    ts = ws[ws.numel() - (16 << 20):].view(torch.int64)[: nblk * nw * 8].view(nblk, nw, 8).cpu().double(); ws[ws.numel() - (16 << 20):].zero_()
     t0 = ts[..., 7]
     start_spread = (t0.max() - t0.min()).item()
     m = ts.mean(dim=(0, 1))
