@@ -31,7 +31,7 @@ constexpr int CONV_XCAP = 4096;  // X-tile floats per stage (SC*CK*span), spread
 //   A(tap, I) = Ws[(tap*SCK + 2I + half)*BM + m],  B(tap, I) = Xs[(2I + half)*span + n*stride + tap]
 // The k-loop is tap-outer / channel-pair-inner; the WK waves of a split-K block take pairs I = kw, kw+WK, ...
 // Fragment groups of U steps are software-pipelined (reads of group g+1 issued before the MFMAs of group g).
-template <int TM, int TN, int WM, int WN, int WK, int CONV_MAXW, int U>
+template <int TM, int TN, int WM, int WN, int WK, int CONV_MAXW, int U, bool EXACT>
 __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p) {
   constexpr int CONV_NT = 64 * WM * WN * WK;      // 4 or 8 waves
   constexpr int CONV_MAXX = CONV_XCAP / CONV_NT;  // X-tile floats per thread
@@ -160,18 +160,21 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   const int my_steps = nI > kw ? (nI - kw + WK - 1) / WK : 0;  // pairs of this wave per tap
   const int gpt = (my_steps + U - 1) / U;              // fragment groups per tap
   const int ngroups = gpt * KW;
-  const int a_step = 2 * WK * BM, b_step = 2 * WK * span;  // operand strides between consecutive pairs of a wave
+  constexpr int a_step = 2 * WK * BM;  // operand strides between consecutive channel pairs of a wave
+  const int b_step = 2 * WK * span;
   const float* zrow = Zs + lhalf * BM + a_col;
 
   // group cursor (tap, jg) advanced by every load_group call, in program order
   int cur_tap = 0, cur_jg = 0;
+  // EXACT: every wave has a whole number of groups per tap (the launcher guarantees it) -> no guards, the A reads
+  // are immediate offsets from one base register
   auto load_group = [&](const float* wsb, const float* xsb, float (&av)[U][TM], float (&bv)[U][TN]) {
     const float* wt = wsb + cur_tap * (SCK * BM) + cur_jg * (U * a_step);
     const float* xq = xsb + cur_tap + cur_jg * (U * b_step);
     const int j0 = cur_jg * U;
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const bool ok = j0 + u < my_steps;
+      const bool ok = EXACT || (j0 + u < my_steps);
       const float* wrow = ok ? wt + u * a_step : zrow;
       const float* xrow = ok ? xq + u * b_step : xq;
 #pragma unroll
@@ -317,19 +320,23 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
 
 struct ConvCfg {
   int BM, BN, WK, MAXW, NT;
-  void (*kern4)(ConvArgs);  // fragment groups of 4 k-steps
-  void (*kern2)(ConvArgs);  // ... of 2 (few channel pairs per wave and tap)
+  void (*kern4)(ConvArgs);  // fragment groups of 4 k-steps, exact
+  void (*kern2)(ConvArgs);  // ... of 2, exact (few channel pairs per wave and tap)
+  void (*kern_g)(ConvArgs); // groups of 2 with guards (odd pair counts: tiny test models only)
 };
+#define OU_CONV_CFG(BM, BN, WK, MAXW, NT, TM, TN, WM, WN)                                             \
+  {BM, BN, WK, MAXW, NT, conv_mfma_kernel<TM, TN, WM, WN, WK, MAXW, 4, true>,                          \
+   conv_mfma_kernel<TM, TN, WM, WN, WK, MAXW, 2, true>, conv_mfma_kernel<TM, TN, WM, WN, WK, MAXW, 2, false>}
 static const ConvCfg kConvCfgs[] = {
-    {64, 128, 1, 6, 256, conv_mfma_kernel<1, 2, 2, 2, 1, 6, 4>, conv_mfma_kernel<1, 2, 2, 2, 1, 6, 2>},
-    {32, 128, 1, 6, 256, conv_mfma_kernel<1, 1, 1, 4, 1, 6, 4>, conv_mfma_kernel<1, 1, 1, 4, 1, 6, 2>},
-    {64, 64, 1, 6, 256, conv_mfma_kernel<1, 1, 2, 2, 1, 6, 4>, conv_mfma_kernel<1, 1, 2, 2, 1, 6, 2>},
-    // small-T levels: reduction split over the 4 waves, up to 4 packed chunks per pipeline stage
-    {32, 64, 4, 12, 256, conv_mfma_kernel<1, 2, 1, 1, 4, 12, 4>, conv_mfma_kernel<1, 2, 1, 1, 4, 12, 2>},
-    {32, 32, 4, 12, 256, conv_mfma_kernel<1, 1, 1, 1, 4, 12, 4>, conv_mfma_kernel<1, 1, 1, 1, 4, 12, 2>},
+    OU_CONV_CFG(64, 128, 1, 6, 256, 1, 2, 2, 2),
+    OU_CONV_CFG(32, 128, 1, 6, 256, 1, 1, 1, 4),
+    OU_CONV_CFG(64, 64, 1, 6, 256, 1, 1, 2, 2),
+    // small-T levels: reduction split over the waves, up to 4 packed chunks per pipeline stage
+    OU_CONV_CFG(32, 64, 4, 12, 256, 1, 2, 1, 1),
+    OU_CONV_CFG(32, 32, 4, 12, 256, 1, 1, 1, 1),
     // 8 waves (two per SIMD), reduction split 8 ways
-    {32, 64, 8, 6, 512, conv_mfma_kernel<1, 2, 1, 1, 8, 6, 4>, conv_mfma_kernel<1, 2, 1, 1, 8, 6, 2>},
-    {32, 32, 8, 6, 512, conv_mfma_kernel<1, 1, 1, 1, 8, 6, 4>, conv_mfma_kernel<1, 1, 1, 1, 8, 6, 2>},
+    OU_CONV_CFG(32, 64, 8, 6, 512, 1, 2, 1, 1),
+    OU_CONV_CFG(32, 32, 8, 6, 512, 1, 1, 1, 1),
 };
 constexpr int kNumConvCfgs = sizeof(kConvCfgs) / sizeof(kConvCfgs[0]);
 
@@ -347,6 +354,9 @@ hipError_t init_conv_kernels() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kConvCfgs[i].kern2),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kConvCfgs[i].kern_g),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) return e;
   }
@@ -398,9 +408,12 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   aa.grid_m = (a.M + c.BM - 1) / c.BM;
   dim3 grid(aa.grid_n * aa.grid_m, 1, a.B);
   size_t smem = conv_smem_bytes(c, aa);
-  // channel pairs of one wave per tap: groups of 4 when that divides, else groups of 2
-  const int pairs = aa.SC * a.CK / 2, per_wave = (pairs + c.WK - 1) / c.WK;
-  hipLaunchKernelGGL((per_wave % 4 == 0 ? c.kern4 : c.kern2), grid, dim3(c.NT), smem, stream, aa);
+  // channel pairs per wave and tap: exact groups of 4 or 2 when every wave gets the same whole number of them
+  const int pairs = aa.SC * a.CK / 2;
+  const bool even = pairs % c.WK == 0;
+  const int per_wave = pairs / c.WK;
+  auto kern = (even && per_wave % 4 == 0) ? c.kern4 : ((even && per_wave % 2 == 0) ? c.kern2 : c.kern_g);
+  hipLaunchKernelGGL(kern, grid, dim3(c.NT), smem, stream, aa);
   return hipGetLastError();
 }
 
@@ -1055,6 +1068,8 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
       unsigned long long* src = xq + (size_t)(cur ^ 1) * H + lane;
       unsigned long long v[HB];
       unsigned spins = 0;
+      if (p.poll_backoff > 0) __builtin_amdgcn_s_sleep(8);   // ~512 cycles: nothing can have arrived yet
+      if (p.poll_backoff > 1) __builtin_amdgcn_s_sleep(8);
       while (true) {
         bool ok = true;
 #pragma unroll
