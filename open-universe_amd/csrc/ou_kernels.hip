@@ -83,8 +83,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   const bool act = p.act != 0;
   const float alpha = p.alpha_val;
 
-  // stage-invariant gather offsets of this thread's X-tile elements (-1: zero padding)
+  // stage-invariant gather offsets of this thread's X-tile elements (-1: zero padding); the loads of stage 0 are
+  // issued as soon as each offset is known, so their latency overlaps the rest of the index math
   int goff[CONV_MAXX];
+  float xr[CONV_MAXX];
+  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
 #pragma unroll
   for (int i = 0; i < CONV_MAXX; i++) {
     int e = tid + i * CONV_NT;
@@ -96,9 +99,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
       if (t >= 0 && t < p.Tin) g = l * p.Tin + t;
     }
     goff[i] = g;
+    xr[i] = (g >= 0) ? xb[g] : 0.f;
   }
   // ... and of its W-tile float4s: LDS row (tap, cl) <- packed row (sub*KW + tap)*CK + l,  cl = sub*CK + l
   int woff[CONV_MAXW];
+  f32x4 wr[CONV_MAXW];
 #pragma unroll
   for (int i = 0; i < CONV_MAXW; i++) {
     int f = tid + i * CONV_NT;
@@ -106,11 +111,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
     int tap = row >> lsck, cl = row & (SCK - 1);
     int sub = cl >> lck, l = cl & (CK - 1);
     woff[i] = ((sub * KW + tap) * CK + l) * p.Mp + c4 * 4;
+    if (f < wt4) wr[i] = *reinterpret_cast<const f32x4*>(p.w + m0 + woff[i]);
   }
-
-  float xr[CONV_MAXX];
-  f32x4 wr[CONV_MAXW];
-  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
 
   auto load_stage = [&](int c) {
     const float* xc = xb + (size_t)c * SCK * p.Tin;
@@ -194,11 +196,38 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
   };
 
-  load_stage(0);
   if (ts_on) tsv[1] = __builtin_readcyclecounter();
   store_stage(0);
   __syncthreads();
   if (ts_on) tsv[2] = __builtin_readcyclecounter();
+  // Epilogue operands of the fast path (bias, FiLM, cond add, residual): fetched now, so that their latency hides
+  // behind the whole main loop (kept in registers; only for tiles with <= 4 epilogue passes per thread)
+  constexpr int C4e = BN / 4, RPPe = CONV_NT / C4e, NPe = (BM + RPPe - 1) / RPPe;
+  constexpr bool EARLY = NPe <= 4;
+  const bool fast_epi = p.up == 1 && (p.Tout & 3) == 0;
+  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+  int m_hi = m0 + BM - 1;
+  if (m_hi > p.M - 1) m_hi = p.M - 1;
+  const size_t ybase = (size_t)b * p.Cout * p.Tout;
+  f32x4 addv[NPe], resv[NPe];
+  float bi[NPe], ga[NPe], be[NPe];
+  auto fetch_epi = [&]() {
+    const int q = (tid % C4e) * 4, r0 = tid / C4e;
+    if (n0 + q < p.Nq) {
+#pragma unroll
+      for (int k = 0; k < NPe; k++) {
+        const int m = m0 + r0 + k * RPPe;
+        const bool ok = m <= m_hi && r0 + k * RPPe < BM;
+        const int mm = ok ? m : m0;
+        const size_t idx = ybase + (size_t)mm * p.Tout + n0 + q;
+        bi[k] = p.bias[mm];
+        if (p.add) addv[k] = *reinterpret_cast<const f32x4*>(p.add + idx);
+        if (p.res) resv[k] = *reinterpret_cast<const f32x4*>(p.res + idx);
+        if (filmb) { ga[k] = filmb[mm]; be[k] = filmb[p.Cout + mm]; }
+      }
+    }
+  };
+  if (EARLY && fast_epi) fetch_epi();
   for (int c = 0; c < nstages; c++) {
     const int buf = c & 1;
     long long ta = 0;
@@ -247,29 +276,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   if (ts_on) tsv[4] = __builtin_readcyclecounter();
 
   const int up = p.up, Cout = p.Cout, Tout = p.Tout;
-  const size_t ybase = (size_t)b * Cout * Tout;
-  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
-  int m_hi = m0 + BM - 1;
-  if (m_hi > p.M - 1) m_hi = p.M - 1;
-
-  if (up == 1 && (Tout & 3) == 0) {
-    // fast path: one float4 of consecutive time samples per thread and pass, shift-only indexing;
-    // every global read of all passes is issued before the first use
-    constexpr int C4 = BN / 4, RPP = CONV_NT / C4, NP = (BM + RPP - 1) / RPP;
+  if (fast_epi) {
+    // fast path: one float4 of consecutive time samples per thread and pass, shift-only indexing
+    constexpr int C4 = C4e, RPP = RPPe, NP = NPe;
     const int c4 = tid % C4, q = c4 * 4, r0 = tid / C4;
+    if (!EARLY) fetch_epi();
     if (n0 + q < p.Nq) {
-      f32x4 addv[NP], resv[NP];
-      float bi[NP], ga[NP], be[NP];
-#pragma unroll
-      for (int k = 0; k < NP; k++) {
-        const int m = m0 + r0 + k * RPP;
-        const bool ok = m <= m_hi && r0 + k * RPP < BM;
-        const size_t idx = ybase + (size_t)(ok ? m : m0) * Tout + n0 + q;
-        bi[k] = p.bias[ok ? m : m0];
-        if (p.add) addv[k] = *reinterpret_cast<const f32x4*>(p.add + idx);
-        if (p.res) resv[k] = *reinterpret_cast<const f32x4*>(p.res + idx);
-        if (filmb) { ga[k] = filmb[ok ? m : m0]; be[k] = filmb[Cout + (ok ? m : m0)]; }
-      }
 #pragma unroll
       for (int k = 0; k < NP; k++) {
         const int row = r0 + k * RPP, m = m0 + row;
