@@ -1021,9 +1021,13 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
     xr = gx_r[t]; xz = gx_z[t]; xn = gx_n[t];
     if (has_res) rs = p.res[orow + t];
   }
+  // Everything loaded so far (weights, bhn, first-step inputs) is first USED inside the loop; without this the
+  // compiler places a vmcnt(0) wait at that first use -- in every iteration, right behind the prefetch loads
+  // issued there, which exposes a full memory latency per time step.  vmcnt(0), expcnt/lgkmcnt untouched:
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
-  long long c_comp = 0, c_poll = 0, c_bar = 0;
+  long long c_comp = 0, c_poll = 0, c_bar = 0, c_mv = 0, c_red = 0, c_gate = 0;
   const bool ts_on = p.tstamps != nullptr;
   for (int step = 0; step < T; step++, t += dt) {
     const int cur = step & 1;
@@ -1043,6 +1047,8 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
         acc[gt][1] = __builtin_elementwise_fma(w[r + 1], h23, acc[gt][1]);
       }
     }
+    long long qa = 0, qb = 0;
+    if (ts_on) qa = __builtin_readcyclecounter();
     float hs[3];
 #pragma unroll
     for (int gt = 0; gt < 3; gt++) {
@@ -1050,6 +1056,7 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
       hs[gt] = LPU == 8 ? row8_sum(part) : row16_sum(part);
     }
 
+    if (ts_on) qb = __builtin_readcyclecounter();
     // next step's input-projection / residual values: issued now, consumed one iteration later, so that no
     // global-load latency ever sits between the gate math and the publish below
     float nxr = 0.f, nxz = 0.f, nxn = 0.f, nrs = 0.f;
@@ -1072,7 +1079,7 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
       p.out[orow + t] = has_res ? (hnew + rs) * p.res_scale : hnew;
     }
     xr = nxr; xz = nxz; xn = nxn; rs = nrs;
-    if (ts_on) q1 = __builtin_readcyclecounter();
+    if (ts_on) { q1 = __builtin_readcyclecounter(); c_mv += qa - q0; c_red += qb - qa; c_gate += q1 - qb; }
 
     if (NWG > 1 && tid < 64) {
       // gather the other workgroups' slices: lane l polls granules l, l+64, ...; all polls in flight together
@@ -1107,8 +1114,8 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
     }
   }
   if (ts_on && lane == 0) {
-    long long* o = p.tstamps + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 4;
-    o[0] = c_comp; o[1] = c_poll; o[2] = c_bar; o[3] = T;
+    long long* o = p.tstamps + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 8;
+    o[0] = c_comp; o[1] = c_poll; o[2] = c_bar; o[3] = T; o[4] = c_mv; o[5] = c_red; o[6] = c_gate;
   }
 }
 

@@ -13,7 +13,7 @@ for _ in range(2):
     model.enhance(mix, n_steps=2, rng=torch.Generator(device="cuda").manual_seed(0))
 torch.cuda.synchronize()
 ws = model._ws
-ts = ws[ws.numel() - (1 << 20):].view(torch.int64)[: 64 * 8 * 4].view(64, 8, 4).cpu().double()
+ts = ws[ws.numel() - (1 << 20):].view(torch.int64)[: 64 * 8 * 8].view(64, 8, 8).cpu().double()
 for blk in (0, 1, 8, 9):
-    print("block", blk, "per-step cycles [compute, poll(wave0)/idle, barrier]:",
-          [[round(float(v) / 401) for v in ts[blk, w, :3]] for w in (0, 1, 7)])
+    print("block", blk, "per-step cycles [compute, poll(wave0)/idle, barrier | matvec, reduce, gates+stores]:",
+          [[round(float(v) / 401) for v in ts[blk, w, [0, 1, 2, 4, 5, 6]]] for w in (0, 1, 7)])
