@@ -257,6 +257,7 @@ struct Runner {
     if (std::getenv("OU_GRU_TS")) a.tstamps = (long long*)(base + cap - (1u << 20));
     { const char* f = std::getenv("OU_GRU_UPW"); a.force_upw = f ? std::atoi(f) : 0; }
     { const char* f = std::getenv("OU_GRU_BACKOFF"); a.poll_backoff = f ? std::atoi(f) : 0; }
+    { const char* f = std::getenv("OU_GRU_AGENT_STORES"); a.agent_stores = f ? std::atoi(f) : 0; }
     chk(launch_gru(a, h->num_cu, st), G.name.c_str());
     return out;
   }

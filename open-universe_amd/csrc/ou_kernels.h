@@ -106,6 +106,7 @@ struct GruArgs {
   long long* tstamps = nullptr;        // per-wave cycle breakdown (tuning only)
   int B = 1, T = 0, H = 0;
   int poll_backoff = 0;  // tuning: 0/1/2 x ~512 cycles of sleep before the first poll
+  int agent_stores = 0;  // 1: publish with agent-scope stores even when the cluster shares one XCD
   int force_upw = 0;  // tuning: 16 / 32 / 64 hidden units per workgroup (0: chosen from the batch size)
 };
 hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st);

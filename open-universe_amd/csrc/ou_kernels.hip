@@ -1014,6 +1014,37 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
   unsigned long long* xq = p.xchg + ((size_t)(b * 2 + dir) * 2) * H;
   const bool has_res = p.res != nullptr;
 
+  // One-time rendezvous: every member posts the id of the XCD it runs on (granule g*UPW of buffer 0, which is not
+  // written again before all members have passed step 0).  When the whole cluster shares one XCD -- the normal case,
+  // see the block mapping above -- the per-step publishes can be ordinary stores: the vector L1 is write-through, so
+  // they land in the L2 that serves every poller's sc1 (agent-scope) load, without the write-through to the memory
+  // side that an agent-scope store adds (measured: -6 % per GRU launch, and finer splits stop losing to store
+  // traffic).  Anything else keeps agent-scope stores.
+  __shared__ int plain_flag;
+  if (NWG > 1 && tid < 64) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xFu;
+    constexpr unsigned RTAG = 0x80000000u;
+    if (lane == 0)
+      __hip_atomic_store(xq + (size_t)g * UPW, ((unsigned long long)RTAG << 32) | xcc, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    bool same = true, fail = false;
+    if (lane < NWG) {
+      unsigned spins = 0;
+      unsigned long long v;
+      while (true) {
+        v = __hip_atomic_load(xq + (size_t)lane * UPW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == RTAG) break;
+        if (++spins > GRU_SPIN_LIMIT) { fail = true; break; }
+      }
+      same = !fail && (unsigned)v == xcc;
+    }
+    const bool all_same = __builtin_amdgcn_ballot_w64(!same) == 0ull;
+    if (lane == 0) plain_flag = (all_same && !p.agent_stores) ? 1 : 0;
+    if (fail) atomicOr(p.err, 1u);
+  }
+
   int t = dir ? T - 1 : 0;
   const int dt = dir ? -1 : 1;
   float xr = 0.f, xz = 0.f, xn = 0.f, rs = 0.f;
@@ -1026,6 +1057,7 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
   // issued there, which exposes a full memory latency per time step.  vmcnt(0), expcnt/lgkmcnt untouched:
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
+  const bool plain = NWG > 1 && __builtin_amdgcn_readfirstlane(plain_flag) != 0;
 
   long long c_comp = 0, c_poll = 0, c_bar = 0, c_mv = 0, c_red = 0, c_gate = 0;
   const bool ts_on = p.tstamps != nullptr;
@@ -1073,7 +1105,9 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
       const float hnew = (hp - n) * z + n;
       if (NWG > 1) {  // publish first: the other workgroups are waiting on this
         unsigned long long gran = ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned)__float_as_int(hnew);
-        __hip_atomic_store(xq + (size_t)(cur ^ 1) * H + unit, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long* dst = xq + (size_t)(cur ^ 1) * H + unit;
+        if (plain) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
+        else __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       hbuf[cur ^ 1][unit] = hnew;
       p.out[orow + t] = has_res ? (hnew + rs) * p.res_scale : hnew;
@@ -1133,14 +1167,17 @@ static hipError_t launch_gru_variant(const GruArgs& c, int upw, int nclusters, h
 hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
   if (a.H % 64) return hipErrorInvalidValue;
   const int HB = a.H / 64;
-  // every workgroup of a cluster must be resident at once (one workgroup per CU); clusters are dealt to XCDs in
-  // groups of 8.  Take the finest split (least work per time step) that still runs the whole batch in ONE launch.
-  // Measured (tools/gru_ts.py): 16 / 32 / 64 units per workgroup all end at ~3200 cycles per step -- what the
-  // finer splits save in compute they lose in exchange (more pollers on the L2) -- so the default is the split
-  // that needs the fewest CUs.
-  const int upw = a.force_upw ? a.force_upw : 64;
+  // Every workgroup of a cluster has to be resident at once; clusters are dealt to XCDs in groups of 8 and a launch
+  // is sized to at most half the CUs (the conditioner's and the score net's GRUs may overlap).  Take the finest split
+  // -- least work per time step; measured 12.1 / 12.6 / 13.1 ms per PP16 enhance for 16 / 32 / 64 units per
+  // workgroup, the same order at B = 2, 4, 8 -- that still runs the whole batch in ONE launch.
+  auto batch_cap = [&](int u) { return (num_cu / (8 * (a.H / u))) * 8 / 2; };
+  int upw = 64;
+  if (a.force_upw) upw = a.force_upw;
+  else if (a.H % 16 == 0 && batch_cap(16) >= a.B) upw = 16;
+  else if (a.H % 32 == 0 && batch_cap(32) >= a.B) upw = 32;
   const int nwg = a.H / upw;
-  const int bmax = (num_cu / (8 * nwg)) * 8 / 2;
+  const int bmax = batch_cap(upw);
   if (bmax < 1) return hipErrorInvalidConfiguration;
   for (int b0 = 0; b0 < a.B; b0 += bmax) {
     GruArgs c = a;
