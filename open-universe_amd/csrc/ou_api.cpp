@@ -63,6 +63,8 @@ struct ou_handle {
   std::vector<ProfRec> prof;
   size_t prof_used = 0;
   unsigned long long* prof_dev = nullptr;  // [kProfSlots][2] device-side {min start, ~max end} ticks
+  int fuse_mode = -1;  // OU_FUSE: -1 auto (cost model), 0 never, 2 / 3 force that depth where the shape allows
+  int fuse_nc = 0;     // OU_FUSE_NC: force 128 / 256 columns per tile
 };
 
 namespace {
@@ -199,8 +201,45 @@ struct Runner {
 
   struct BlockOut { Tensor h_next, v, c1; };
   // ConvBlock.forward  (blocks.py:327-412).  `res` for dir==0 blocks must already be folded into `hin`.
+  // How the three body convs of a ConvBlock run: 0 = three generic launches, 3 = one fused launch, 2 = conv1 generic +
+  // fused (conv2, conv3).  Pure function of (layer shapes, B, T, device, OU_FUSE*) -- estimated cycles, see
+  // chain_cost(); the generic launches are priced at their measured ~45 TFLOP/s with a 12 us floor.
+  int plan_chain(const BlockL& Bk, int T) {
+    { const char* f = std::getenv("OU_FUSE"); h->fuse_mode = f ? std::atoi(f) : -1; }
+    { const char* f = std::getenv("OU_FUSE_NC"); h->fuse_nc = f ? std::atoi(f) : 0; }
+    if (h->fuse_mode == 0) return 0;
+    auto shape = [&](int depth) {
+      ChainArgs ca;
+      ca.depth = depth; ca.B = B; ca.C = Bk.C; ca.T = T; ca.Mp = Bk.c1.Mp; ca.force_nc = h->fuse_nc;
+      const ConvL* ls[3] = {&Bk.c1, &Bk.c2, &Bk.c3};
+      for (int s2 = 0; s2 < depth; s2++) {
+        const ConvL& L = *ls[3 - depth + s2];
+        if (!L.act || L.stride != 1 || L.up != 1 || L.Cin != Bk.C || L.Cout != Bk.C || L.pad != (L.KW - 1) / 2 ||
+            L.Mp != Bk.c1.Mp)
+          ca.depth = 0;
+        ca.cv[s2].KW = L.KW; ca.cv[s2].CK = L.CK;
+      }
+      return ca;
+    };
+    auto generic = [&](const ConvL& L) {
+      const double cyc = 2.0 * L.M * (double)T * L.Cin * L.KW * B / 45e12 * 2.3e9;
+      return cyc > 28000.0 ? cyc : 28000.0;
+    };
+    const double c3 = chain_cost(shape(3), h->num_cu, nullptr);
+    double c2 = chain_cost(shape(2), h->num_cu, nullptr);
+    if (c2 >= 0) c2 += generic(Bk.c1);
+    if (h->fuse_mode == 3) return c3 >= 0 ? 3 : 0;
+    if (h->fuse_mode == 2) return c2 >= 0 ? 2 : 0;
+    const double c0 = generic(Bk.c1) + generic(Bk.c2) + generic(Bk.c3);
+    int best = 0;
+    double bc = c0;
+    if (c3 >= 0 && c3 < bc) { best = 3; bc = c3; }
+    if (c2 >= 0 && c2 < bc) { best = 2; bc = c2; }
+    return best;
+  }
+
   BlockOut block(const BlockL& Bk, const Tensor& hin, const std::string& nm, const float* film, int film_bs,
-                 const float* input_cond, const float* res) {
+                 const float* input_cond, const float* res, bool need_c1 = false) {
     Tensor hu = hin;
     if (Bk.dir == 2) {
       if (Bk.rc.fir_mode == 2) {
@@ -219,12 +258,63 @@ struct Runner {
     Epi e1;
     if (input_cond) { e1.add = input_cond; e1.add_scale = kInvSqrt2; }  // blocks.py:384-386
     e1.film = film; e1.film_bstride = film_bs;                           // blocks.py:393-394
-    Tensor c1 = conv(Bk.c1, hu, nm + ".c1", e1);
-    Tensor c2 = conv(Bk.c2, c1, nm + ".c2", Epi());
-    Epi e3;
-    e3.res = hu.p; e3.res_scale = kInvSqrt2;  // blocks.py:399
-    if (dry) e3.res = nullptr;
-    Tensor v = conv(Bk.c3, c2, nm + ".v", e3);
+    Tensor c1 = alloc(nm + ".c1", Bk.c1.Cout, hu.T);
+    Tensor c2 = alloc(nm + ".c2", Bk.c2.Cout, hu.T);
+    Tensor v = alloc(nm + ".v", Bk.c3.Cout, hu.T);
+    // wide, shallow levels: the body runs as one fused launch (conv_chain_kernel), or conv1 + a fused (conv2, conv3)
+    const int depth = dry ? 0 : plan_chain(Bk, hu.T);
+    auto chain_conv = [&](const ConvL& L) {
+      ChainConv c;
+      c.w = W(L.w_off); c.bias = W(L.b_off); c.alpha = h->alphas[L.a_off]; c.KW = L.KW; c.CK = L.CK;
+      return c;
+    };
+    if (depth == 3 || depth == 2) {
+      if (depth == 2) conv(Bk.c1, hu, nm + ".c1", e1, &c1);
+      if (ok()) {
+        ChainArgs ca;
+        ca.depth = depth; ca.B = B; ca.C = Bk.C; ca.T = hu.T; ca.Mp = Bk.c1.Mp;
+        ca.x = depth == 3 ? hu.p : c1.p;
+        ca.y = v.p; ca.res = hu.p; ca.res_scale = kInvSqrt2;
+        if (depth == 3) {
+          ca.add = e1.add; ca.add_scale = e1.add_scale; ca.film = e1.film; ca.film_bstride = e1.film_bstride;
+          ca.c1_out = need_c1 ? c1.p : nullptr;
+          ca.cv[0] = chain_conv(Bk.c1); ca.cv[1] = chain_conv(Bk.c2); ca.cv[2] = chain_conv(Bk.c3);
+        } else {
+          ca.cv[0] = chain_conv(Bk.c2); ca.cv[1] = chain_conv(Bk.c3);
+        }
+        ca.force_nc = h->fuse_nc;
+        { const char* f = std::getenv("OU_CHAIN_TS"); if (f && nm == f) ca.tstamps = (long long*)(base + cap - (16u << 20)); }
+        int variant = -1;
+        if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {
+          ou_handle::ProfRec rec;
+          rec.flops = 0;
+          double wbytes = 0;
+          for (int s2 = 0; s2 < depth; s2++) {
+            rec.flops += 2.0 * Bk.C * (double)hu.T * Bk.C * ca.cv[s2].KW * B;
+            wbytes += 4.0 * Bk.C * Bk.C * ca.cv[s2].KW;
+          }
+          // activations: block input (also the residual) once, output once, the cond add when present
+          rec.bytes = 4.0 * B * (double)Bk.C * hu.T * (2 + (depth == 2 ? 1 : 0) + (ca.add ? 1 : 0)) + wbytes;
+          rec.cfg = -1;
+          ca.prof = h->prof_dev + 2 * h->prof_used;
+          h->prof.push_back(rec);
+          h->prof_used++;
+        }
+        chk(launch_chain(ca, h->num_cu, st, &variant), nm.c_str());
+        if (ca.prof) h->prof.back().cfg = variant;
+        if (h->trace)
+          std::fprintf(stderr, "OU_TRACE chain %-63s variant=%d depth=%d C=%d T=%d B=%d\n", nm.c_str(), variant, depth,
+                       Bk.C, hu.T, B);
+        h->n_conv++;
+      }
+    } else {
+      conv(Bk.c1, hu, nm + ".c1", e1, &c1);
+      conv(Bk.c2, c1, nm + ".c2", Epi(), &c2);
+      Epi e3;
+      e3.res = hu.p; e3.res_scale = kInvSqrt2;  // blocks.py:399
+      if (dry) e3.res = nullptr;
+      conv(Bk.c3, c2, nm + ".v", e3, &v);
+    }
     BlockOut o;
     o.v = v; o.c1 = c1; o.h_next = v;
     if (Bk.dir == 1) {  // blocks.py:401-410
@@ -374,7 +464,7 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
   // --- decoder  condition.py:264-270
   Tensor y = r.block(m.c_decin, lat, "cond.decin", nullptr, 0, nullptr, nullptr).v;
   for (int j = 0; j < m.n_blocks; j++) {
-    auto bo = r.block(m.c_dec[j], y, "cond.dec" + std::to_string(j), nullptr, 0, nullptr, nullptr);
+    auto bo = r.block(m.c_dec[j], y, "cond.dec" + std::to_string(j), nullptr, 0, nullptr, nullptr, true);
     y = bo.v;
     if (!r.dry && r.ok())
       r.chk(hipMemcpyAsync(P.cond[j].p, bo.c1.p, (size_t)r.B * bo.c1.C * bo.c1.T * 4, hipMemcpyDeviceToDevice, r.st), "cond copy");

@@ -94,6 +94,35 @@ hipError_t launch_sum(const float* a, const float* b, const float* c, const floa
 
 // Bidirectional GRU recurrence on a cluster of H/64 workgroups per (batch, direction).
 //   gx : (B, 6H, T) input projection incl. biases ; out: (B, 2H, T) ; out = res ? (h + res)*scale : h
+// Fused body of a ConvBlock (blocks.py:377-399) for the wide, shallow levels (C = 32 / 64): two or three stride-1
+// 'same' convs chained through LDS-resident activation tiles, see conv_chain_kernel.
+struct ChainConv {
+  const float* w = nullptr;     // packed generic-conv weights [C/CK][KW][CK][Mp]
+  const float* bias = nullptr;  // [C]
+  float alpha = 0.f;            // PReLU slope applied to this conv's INPUT
+  int KW = 3, CK = 32;
+};
+struct ChainArgs {
+  const float* x = nullptr;    // (B, C, T) input of the first fused conv
+  float* y = nullptr;          // (B, C, T) block output
+  const float* res = nullptr;  // residual added after the last conv: y = (conv + bias + res) * res_scale
+  float res_scale = 1.f;
+  const float* add = nullptr;  // depth 3 only: y1 = (conv1 + bias + add) * add_scale, then FiLM
+  float add_scale = 1.f;
+  const float* film = nullptr; // depth 3 only: [B][film_bstride] = gamma[C] | beta[C]
+  int film_bstride = 0;
+  float* c1_out = nullptr;     // depth 3 only: raw conv1 result, when a caller needs it
+  int B = 1, C = 32, T = 0, Mp = 64;
+  int depth = 3;               // number of fused convs: 3 = conv1..conv3, 2 = conv2, conv3
+  ChainConv cv[3];
+  int force_nc = 0;            // tuning: 128 / 256 columns per tile (0: chosen by the launcher)
+  unsigned long long* prof = nullptr;
+  long long* tstamps = nullptr;  // tuning: per-wave phase cycle counts
+};
+// Shape check + cost estimate (in cycles) of the best variant; <0 when the shape is not supported.
+double chain_cost(const ChainArgs& a, int num_cu, int* nc_out);
+hipError_t launch_chain(const ChainArgs& a, int num_cu, hipStream_t st, int* variant);
+
 struct GruArgs {
   const float* gx = nullptr;
   const float* whh = nullptr;  // canonical [dir][3H][H] row-major

@@ -24,18 +24,25 @@ def main(trace_csv, ou_trace_log=None):
     for n, (d, c) in sorted(tot.items(), key=lambda kv: -kv[1][0]):
         print(f"  {n:60s} {c:5d} calls {d/1e3:10.1f} us  {100*d/busy:5.1f}%  avg {d/c/1e3:8.1f} us")
     if ou_trace_log:
-        names = [l.split() for l in open(ou_trace_log) if l.startswith("OU_TRACE conv")]
+        names = [l.split() for l in open(ou_trace_log) if l.startswith("OU_TRACE conv") or l.startswith("OU_TRACE chain")]
         convs = [r for r in rows if "conv_mfma_kernel" in r["Kernel_Name"]]
         per = len(convs) // max(1, len(starts)) if starts else len(convs)
         # conv launches of the last enhance, in order, align with the last `per` trace lines
-        last = [r for r in seg if "conv_mfma_kernel" in r["Kernel_Name"]]
+        last = [r for r in seg if "conv_mfma_kernel" in r["Kernel_Name"] or "conv_chain_kernel" in r["Kernel_Name"]]
         lines = names[-len(last):]
         print(f"per-layer (last enhance, {len(last)} conv launches):")
         seen = set()
         for r, l in zip(last, lines):
             nm = l[2]
-            mflop = float(l[-1].split("=")[1])
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            if l[1] == "chain":
+                key = nm
+                if key in seen and not nm.startswith("cond."):
+                    continue
+                seen.add(key)
+                print(f"  {nm:28s} {' '.join(l[3:]):60s} {d:8.1f} us")
+                continue
+            mflop = float(l[-1].split("=")[1])
             key = nm
             if key in seen and not nm.startswith("cond."):
                 continue  # print the score layers once (first step)
