@@ -10,6 +10,27 @@ namespace ou {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+// global -> LDS copies (LDS-DMA): the destination is wave-uniform `lds` + lane * size.  Kept in non-template device
+// functions: the generic -> LDS address-space cast must not be instantiated on the host side of a kernel template.
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void dma_b32(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds, 4, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void dma_b128(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds, 16, voff, soff, 0, 0);
+}
+
 // =========================================================================================================
 // Generic Conv1d as an fp32-MFMA implicit GEMM
 //   GEMM view: rows m (output channel x phase), columns q (time), reduction (ci, tap).
@@ -82,13 +103,21 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
 
   const float* xb = p.x + (size_t)b * p.Cin * p.Tin;
   const bool act = p.act != 0;
-  const float alpha = p.alpha_val;
-
-  // stage-invariant gather offsets of this thread's X-tile elements (-1: zero padding); the loads of stage 0 are
-  // issued as soon as each offset is known, so their latency overlaps the rest of the index math
-  int goff[CONV_MAXX];
-  float xr[CONV_MAXX];
+  const float alpha = act ? p.alpha_val : 1.0f;  // applied to every B operand read (1: identity)
+  // input scale (mel front-end only): the conv is linear in its input and that layer has no PReLU prologue, so the
+  // scale is applied to the accumulators in the epilogue
   const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+
+  // Staging is direct global -> LDS (LDS-DMA buffer loads: no staging registers, no ds_write pass, the copy of stage
+  // c+1 runs under the MFMAs of stage c).  The LDS destination of such a load is wave-uniform base + lane * size, so
+  // the tile images are filled in thread order: element e = tid + i*NT of the X tile (one dword per lane) and float4
+  // f = tid + i*NT of the W tile; WHICH global word lands there is the per-lane byte offset computed once here --
+  // the per-stage part of the address is a scalar offset.  Zero padding: lanes whose sample lies outside the signal
+  // never load, their LDS words are zeroed once below (the positions are the same in every stage).  The PReLU
+  // prologue is applied where the B operand is read from LDS (a copy cannot transform).
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)p.Cin * (unsigned)p.Tin * 4u);
+  const __amdgpu_buffer_rsrc_t rwt = make_rsrc(p.w, (unsigned)p.Cin * (unsigned)KW * (unsigned)p.Mp * 4u);
+  int xvo[CONV_MAXX];  // byte offset inside a stage's SCK input rows, -1: zero padding / past the tile
 #pragma unroll
   for (int i = 0; i < CONV_MAXX; i++) {
     int e = tid + i * CONV_NT;
@@ -97,56 +126,33 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
       int l = (int)__umulhi((unsigned)e, p.magic_span[BN == 128 ? 0 : (BN == 64 ? 1 : 2)]);  // e / span
       int j = e - l * span;
       int t = n0 * stride - p.pad + j;
-      if (t >= 0 && t < p.Tin) g = l * p.Tin + t;
+      if (t >= 0 && t < p.Tin) g = (l * p.Tin + t) * 4;
+      else { Xs[e] = 0.f; Xs[xt_al + e] = 0.f; }
     }
-    goff[i] = g;
-    xr[i] = (g >= 0) ? xb[g] : 0.f;
+    xvo[i] = g;
   }
   // ... and of its W-tile float4s: LDS row (tap, cl) <- packed row (sub*KW + tap)*CK + l,  cl = sub*CK + l
-  int woff[CONV_MAXW];
-  f32x4 wr[CONV_MAXW];
+  int wvo[CONV_MAXW];
 #pragma unroll
   for (int i = 0; i < CONV_MAXW; i++) {
     int f = tid + i * CONV_NT;
     int row = f / (BM / 4), c4 = f % (BM / 4);
     int tap = row >> lsck, cl = row & (SCK - 1);
     int sub = cl >> lck, l = cl & (CK - 1);
-    woff[i] = ((sub * KW + tap) * CK + l) * p.Mp + c4 * 4;
-    if (f < wt4) wr[i] = *reinterpret_cast<const f32x4*>(p.w + m0 + woff[i]);
+    wvo[i] = f < wt4 ? (((sub * KW + tap) * CK + l) * p.Mp + c4 * 4 + m0) * 4 : -1;
   }
-
-  auto load_stage = [&](int c) {
-    const float* xc = xb + (size_t)c * SCK * p.Tin;
+  auto dma_stage = [&](int c, int buf) {
+    const int xso = c * SCK * p.Tin * 4, wso = c * KCs * p.Mp * 4;
+    float* xd = Xs + buf * xt_al + wave * 64;
+    float* wd = Ws + (size_t)buf * KCs * BM + wave * 256;
 #pragma unroll
-    for (int i = 0; i < CONV_MAXX; i++) {
-      int g = goff[i];
-      xr[i] = (g >= 0) ? xc[g] : 0.f;
-    }
-    const float* wc = p.w + ((size_t)c * KCs) * p.Mp + m0;
+    for (int i = 0; i < CONV_MAXX; i++)
+      if (xvo[i] >= 0) dma_b32(rx, xd + i * CONV_NT, xvo[i], xso);
 #pragma unroll
-    for (int i = 0; i < CONV_MAXW; i++) {
-      int f = tid + i * CONV_NT;
-      if (f < wt4) wr[i] = *reinterpret_cast<const f32x4*>(wc + woff[i]);
-    }
+    for (int i = 0; i < CONV_MAXW; i++)
+      if (wvo[i] >= 0) dma_b128(rwt, wd + i * CONV_NT * 4, wvo[i], wso);
   };
-  auto store_stage = [&](int buf) {
-    float* xd = Xs + buf * xt_al;
-#pragma unroll
-    for (int i = 0; i < CONV_MAXX; i++) {
-      int e = tid + i * CONV_NT;
-      if (e < xt) {
-        float v = xr[i] * insc;
-        if (act) v = v >= 0.f ? v : alpha * v;
-        xd[e] = v;
-      }
-    }
-    f32x4* wd = reinterpret_cast<f32x4*>(Ws + (size_t)buf * KCs * BM);
-#pragma unroll
-    for (int i = 0; i < CONV_MAXW; i++) {
-      int f = tid + i * CONV_NT;
-      if (f < wt4) wd[f] = wr[i];
-    }
-  };
+  if (!(p.dbg & 1)) dma_stage(0, 0);
 
   floatx16 acc[TM][TN];
 #pragma unroll
@@ -189,17 +195,22 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   };
   auto mma_group = [&](float (&av)[U][TM], float (&bv)[U][TN]) {
 #pragma unroll
-    for (int u = 0; u < U; u++)
+    for (int u = 0; u < U; u++) {
+      // PReLU prologue of the layer, applied to the B fragment at its point of use (the reads of this group were
+      // issued a whole group of MFMAs ago, so nothing waits on LDS here)
+      float bt[TN];
+#pragma unroll
+      for (int j = 0; j < TN; j++) bt[j] = bv[u][j] >= 0.f ? bv[u][j] : alpha * bv[u][j];
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bt[j], acc[i][j], 0, 0, 0);
+    }
   };
 
   if (ts_on) tsv[1] = __builtin_readcyclecounter();
-  store_stage(0);
-  __syncthreads();
+  __syncthreads();  // (waits for the stage-0 copies: an LDS-DMA in flight counts on vmcnt)
   if (ts_on) tsv[2] = __builtin_readcyclecounter();
   // Epilogue operands of the fast path (bias, FiLM, cond add, residual): fetched now, so that their latency hides
   // behind the whole main loop (kept in registers; only for tiles with <= 4 epilogue passes per thread)
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
     const int buf = c & 1;
     long long ta = 0;
     if (ts_on) ta = __builtin_readcyclecounter();
-    if (c + 1 < nstages && !(p.dbg & 1)) load_stage(c + 1);
+    if (c + 1 < nstages && !(p.dbg & 1)) dma_stage(c + 1, buf ^ 1);
     if (!(p.dbg & 2)) {
       const float* xsb = Xs + buf * xt_al + (2 * kw + lhalf) * span + b_col;
       const float* wsb = Ws + ((size_t)buf * KCs + 2 * kw + lhalf) * BM + a_col;
@@ -253,7 +264,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
     }
     long long tb = 0;
     if (ts_on) { tb = __builtin_readcyclecounter(); t_mma += tb - ta; }
-    if (c + 1 < nstages && !(p.dbg & 8)) store_stage(buf ^ 1);
     __syncthreads();
     if (ts_on) t_wait += __builtin_readcyclecounter() - tb;
   }
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
         f32x4 v = *reinterpret_cast<const f32x4*>(&Es[row * EP + q]);
 #pragma unroll
         for (int kk = 1; kk < WK; kk++) v += *reinterpret_cast<const f32x4*>(&Es[(kk * BM + row) * EP + q]);
+        if (p.in_scale) v *= insc;
         v += bi[k];
         if (p.add) v = (v + addv[k]) * p.add_scale;
         if (filmb) v = ga[k] * v + be[k];
@@ -315,6 +326,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
       float v = Es[(m - m0) * EP + q];
 #pragma unroll
       for (int k = 1; k < WK; k++) v += Es[(k * BM + (m - m0)) * EP + q];
+      if (p.in_scale) v *= insc;
       v += p.bias[co];
       const size_t idx = ybase + (size_t)co * Tout + t;
       if (p.add) v = (v + p.add[idx]) * p.add_scale;
@@ -448,17 +460,6 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
 //   * depth 2 (conv2, conv3 only; conv1 stays a generic launch) exists because of tile quantisation at B = 1:
 //     T = 32000 over 256 CUs is 125 samples per CU -- 126-sample tiles fit one round, 124-sample tiles do not.
 // =========================================================================================================
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
-}
-
 // Addressing: every global access is a buffer instruction -- the per-lane byte offset is computed once, the row
 // (channel) part of the address is a wave-uniform SGPR offset -- so the prologue / epilogues spend their VALU
 // cycles on the arithmetic only (they are a third of a block's time at C = 32).
