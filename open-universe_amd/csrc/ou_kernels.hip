@@ -31,6 +31,18 @@ __device__ __forceinline__ void dma_b128(__amdgpu_buffer_rsrc_t r, float* lds, i
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds, 16, voff, soff, 0, 0);
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): vmcnt = bits [3:0] | [15:14],
+// expcnt / lgkmcnt left at their maxima.
+#define OU_VMCNT_CASE(n) case n: __builtin_amdgcn_s_waitcnt(((n) & 0xF) | (((n) >> 4) << 14) | 0x0F70); break;
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+    OU_VMCNT_CASE(1) OU_VMCNT_CASE(2) OU_VMCNT_CASE(3) OU_VMCNT_CASE(4) OU_VMCNT_CASE(5) OU_VMCNT_CASE(6)
+    OU_VMCNT_CASE(7) OU_VMCNT_CASE(8) OU_VMCNT_CASE(9) OU_VMCNT_CASE(10) OU_VMCNT_CASE(11) OU_VMCNT_CASE(12)
+    OU_VMCNT_CASE(13) OU_VMCNT_CASE(14) OU_VMCNT_CASE(15) OU_VMCNT_CASE(16)
+    default: __builtin_amdgcn_s_waitcnt(0x0F70); break;  // 0, or out of table: wait for everything (always safe)
+  }
+}
+
 // =========================================================================================================
 // Generic Conv1d as an fp32-MFMA implicit GEMM
 //   GEMM view: rows m (output channel x phase), columns q (time), reduction (ci, tap).
@@ -94,6 +106,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   float* Zs = Ws + 2 * (size_t)KCs * BM;  // [2*BM] zeros: the A operand of k-steps past the end
   for (int i = tid; i < 2 * BM; i += CONV_NT) Zs[i] = 0.f;
   const int nstages = p.Cin / SCK;
+  const int nI_ = SCK >> 1;               // channel pairs per stage
 
   if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   long long tsv[8];
@@ -117,12 +130,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   // prologue is applied where the B operand is read from LDS (a copy cannot transform).
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)p.Cin * (unsigned)p.Tin * 4u);
   const __amdgpu_buffer_rsrc_t rwt = make_rsrc(p.w, (unsigned)p.Cin * (unsigned)KW * (unsigned)p.Mp * 4u);
+  constexpr bool PRIV_ = (WK == 8) && EXACT;  // wave-private pipeline (below): the block-wide images are not used
   int xvo[CONV_MAXX];  // byte offset inside a stage's SCK input rows, -1: zero padding / past the tile
 #pragma unroll
   for (int i = 0; i < CONV_MAXX; i++) {
     int e = tid + i * CONV_NT;
     int g = -1;
-    if (e < xt) {
+    if (!PRIV_ && e < xt) {
       int l = (int)__umulhi((unsigned)e, p.magic_span[BN == 128 ? 0 : (BN == 64 ? 1 : 2)]);  // e / span
       int j = e - l * span;
       int t = n0 * stride - p.pad + j;
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
     int row = f / (BM / 4), c4 = f % (BM / 4);
     int tap = row >> lsck, cl = row & (SCK - 1);
     int sub = cl >> lck, l = cl & (CK - 1);
-    wvo[i] = f < wt4 ? (((sub * KW + tap) * CK + l) * p.Mp + c4 * 4 + m0) * 4 : -1;
+    wvo[i] = (!PRIV_ && f < wt4) ? (((sub * KW + tap) * CK + l) * p.Mp + c4 * 4 + m0) * 4 : -1;
   }
   auto dma_stage = [&](int c, int buf) {
     const int xso = c * SCK * p.Tin * 4, wso = c * KCs * p.Mp * 4;
@@ -152,7 +166,67 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
     for (int i = 0; i < CONV_MAXW; i++)
       if (wvo[i] >= 0) dma_b128(rwt, wd + i * CONV_NT * 4, wvo[i], wso);
   };
-  if (!(p.dbg & 1)) dma_stage(0, 0);
+  // ---- split-K configs (exact variants): wave-PRIVATE stage pipeline -------------------------------------------
+  // Wave kw of a split-K block only ever reads the channel pairs I = kw, kw + WK, ... of a stage -- 1/WK of the X
+  // and W tiles.  So every wave copies exactly the rows it consumes into its own slice of LDS and runs its own
+  // double-buffered pipeline, ordered by its own vmcnt: no workgroup barrier in the main loop.  With a barrier per
+  // stage both waves of a SIMD stop together at every stage boundary (copy issue, first LDS round trip, barrier) and
+  // the MFMA pipe idles for about as long as a stage's 12-24 MFMAs keep it busy; unsynchronised, one wave's
+  // boundary hides under the other's MFMAs.
+  //   slice of wave kw, buffer b:  Xw[2*ppw][span] (rows: local pair i, half -> channel 2*(kw + WK*i) + half)
+  //                                Ww[KW][2*ppw][BM]
+  constexpr bool PRIV = (WK == 8) && EXACT;
+  constexpr int PMAXX = PRIV ? CONV_XCAP / WK / 64 : 1;
+  const int ppw = nI_ / WK;                       // channel pairs per wave and stage (power of two)
+  const int lp2 = 31 - __clz(2 * ppw);
+  const int xw = 2 * ppw * span, xw_al = (xw + 3) & ~3;
+  const int ww = KW * 2 * ppw * BM;
+  const int wsz = xw_al + ww;                     // floats per wave and buffer
+  float* const pbase = smem + (size_t)wave * 2 * wsz;
+  int pxvo[PMAXX], pwvo[PRIV ? CONV_MAXW : 1];
+  int Kw = 0;                                     // copies this wave issues per stage
+  if constexpr (PRIV) {
+#pragma unroll
+    for (int i = 0; i < PMAXX; i++) {
+      const int e = lane + 64 * i;
+      int g = -1;
+      if (e < xw) {
+        const int r = (int)__umulhi((unsigned)e, p.magic_span[BN == 128 ? 0 : (BN == 64 ? 1 : 2)]);  // e / span
+        const int jx = e - r * span;
+        const int cl = 2 * (kw + WK * (r >> 1)) + (r & 1);
+        const int t = n0 * stride - p.pad + jx;
+        g = (t >= 0 && t < p.Tin) ? (cl * p.Tin + t) * 4 : (int)0x80000000;  // past the buffer: reads as 0
+      }
+      pxvo[i] = g;
+      Kw += (64 * i < xw) ? 1 : 0;
+    }
+    const int wt4p = ww / 4;
+#pragma unroll
+    for (int i = 0; i < CONV_MAXW; i++) {
+      const int f = lane + 64 * i;
+      const int R = f / (BM / 4), c4 = f % (BM / 4);
+      const int tap = R >> lp2, r = R & (2 * ppw - 1);
+      const int cl = 2 * (kw + WK * (r >> 1)) + (r & 1);
+      const int sub = cl >> lck, l = cl & (CK - 1);
+      pwvo[i] = f < wt4p ? (((sub * KW + tap) * CK + l) * p.Mp + c4 * 4 + m0) * 4 : -1;
+      Kw += (64 * i < wt4p) ? 1 : 0;
+    }
+  }
+  auto dma_private = [&](int c, int buf) {
+    const int xso = c * SCK * p.Tin * 4, wso = c * KCs * p.Mp * 4;
+    float* xd = pbase + buf * wsz;
+    float* wd = xd + xw_al;
+#pragma unroll
+    for (int i = 0; i < PMAXX; i++)
+      if (pxvo[i] != -1) dma_b32(rx, xd + 64 * i, pxvo[i], xso);
+#pragma unroll
+    for (int i = 0; i < (PRIV ? CONV_MAXW : 1); i++)
+      if (pwvo[i] != -1) dma_b128(rwt, wd + 256 * i, pwvo[i], wso);
+  };
+  if (!(p.dbg & 1)) {
+    if constexpr (PRIV) dma_private(0, 0);
+    else dma_stage(0, 0);
+  }
 
   floatx16 acc[TM][TN];
 #pragma unroll
@@ -165,12 +239,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   const int lhalf = lane >> 5, l31 = lane & 31;
   const int a_col = wm * (32 * TM) + l31;
   const int b_col = (wn * (32 * TN) + l31) * stride;
-  const int nI = SCK >> 1;                             // channel pairs per stage
+  const int nI = nI_;
   const int my_steps = nI > kw ? (nI - kw + WK - 1) / WK : 0;  // pairs of this wave per tap
   const int gpt = (my_steps + U - 1) / U;              // fragment groups per tap
   const int ngroups = gpt * KW;
-  constexpr int a_step = 2 * WK * BM;  // operand strides between consecutive channel pairs of a wave
-  const int b_step = 2 * WK * span;
+  // operand strides between consecutive channel pairs of a wave, and between taps
+  constexpr int a_step = PRIV ? 2 * BM : 2 * WK * BM;
+  const int b_step = PRIV ? 2 * span : 2 * WK * span;
+  const int tap_step = PRIV ? 2 * ppw * BM : SCK * BM;
   const float* zrow = Zs + lhalf * BM + a_col;
 
   // group cursor (tap, jg) advanced by every load_group call, in program order
@@ -178,7 +254,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   // EXACT: every wave has a whole number of groups per tap (the launcher guarantees it) -> no guards, the A reads
   // are immediate offsets from one base register
   auto load_group = [&](const float* wsb, const float* xsb, float (&av)[U][TM], float (&bv)[U][TN]) {
-    const float* wt = wsb + cur_tap * (SCK * BM) + cur_jg * (U * a_step);
+    const float* wt = wsb + cur_tap * tap_step + cur_jg * (U * a_step);
     const float* xq = xsb + cur_tap + cur_jg * (U * b_step);
     const int j0 = cur_jg * U;
 #pragma unroll
@@ -210,7 +286,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   };
 
   if (ts_on) tsv[1] = __builtin_readcyclecounter();
-  __syncthreads();  // (waits for the stage-0 copies: an LDS-DMA in flight counts on vmcnt)
+  if constexpr (!PRIV) __syncthreads();  // (waits for the stage-0 copies: an LDS-DMA in flight counts on vmcnt)
   if (ts_on) tsv[2] = __builtin_readcyclecounter();
   // Epilogue operands of the fast path (bias, FiLM, cond add, residual): fetched now, so that their latency hides
   // behind the whole main loop (kept in registers; only for tiles with <= 4 epilogue passes per thread)
@@ -240,32 +316,51 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
     }
   };
   if (EARLY && fast_epi) fetch_epi();
-  for (int c = 0; c < nstages; c++) {
-    const int buf = c & 1;
-    long long ta = 0;
-    if (ts_on) ta = __builtin_readcyclecounter();
-    if (c + 1 < nstages && !(p.dbg & 1)) dma_stage(c + 1, buf ^ 1);
-    if (!(p.dbg & 2)) {
-      const float* xsb = Xs + buf * xt_al + (2 * kw + lhalf) * span + b_col;
-      const float* wsb = Ws + ((size_t)buf * KCs + 2 * kw + lhalf) * BM + a_col;
-      cur_tap = 0;
-      cur_jg = 0;
-      // software-pipelined: the LDS reads of group g+1 are issued before the MFMAs of group g
-      float a0[U][TM], b0[U][TN], a1[U][TM], b1[U][TN];
-      if (ngroups > 0) load_group(wsb, xsb, a0, b0);
-      for (int g = 0; g < ngroups; g += 2) {
-        if (g + 1 < ngroups) load_group(wsb, xsb, a1, b1);
-        mma_group(a0, b0);
-        if (g + 1 < ngroups) {
-          if (g + 2 < ngroups) load_group(wsb, xsb, a0, b0);
-          mma_group(a1, b1);
-        }
+  auto compute_from = [&](const float* wsb, const float* xsb) {
+    cur_tap = 0;
+    cur_jg = 0;
+    // software-pipelined: the LDS reads of group g+1 are issued before the MFMAs of group g
+    float a0[U][TM], b0[U][TN], a1[U][TM], b1[U][TN];
+    if (ngroups > 0) load_group(wsb, xsb, a0, b0);
+    for (int g = 0; g < ngroups; g += 2) {
+      if (g + 1 < ngroups) load_group(wsb, xsb, a1, b1);
+      mma_group(a0, b0);
+      if (g + 1 < ngroups) {
+        if (g + 2 < ngroups) load_group(wsb, xsb, a0, b0);
+        mma_group(a1, b1);
       }
     }
-    long long tb = 0;
-    if (ts_on) { tb = __builtin_readcyclecounter(); t_mma += tb - ta; }
-    __syncthreads();
-    if (ts_on) t_wait += __builtin_readcyclecounter() - tb;
+  };
+  if constexpr (PRIV) {
+    for (int c = 0; c < nstages; c++) {
+      const int buf = c & 1;
+      long long ta = 0, tb = 0;
+      if (ts_on) ta = __builtin_readcyclecounter();
+      const bool more = c + 1 < nstages;
+      if (more && !(p.dbg & 1)) dma_private(c + 1, buf ^ 1);
+      wait_vmcnt(more ? Kw : 0);  // this wave's copies of stage c have landed; those of stage c+1 stay in flight
+      if (ts_on) { tb = __builtin_readcyclecounter(); t_wait += tb - ta; }
+      if (!(p.dbg & 2)) {
+        const float* xd = pbase + buf * wsz;
+        compute_from(xd + xw_al + lhalf * BM + a_col, xd + lhalf * span + b_col);
+      }
+      if (ts_on) t_mma += __builtin_readcyclecounter() - tb;
+    }
+    __syncthreads();  // the epilogue re-uses the stage buffers of all waves
+  } else {
+    for (int c = 0; c < nstages; c++) {
+      const int buf = c & 1;
+      long long ta = 0;
+      if (ts_on) ta = __builtin_readcyclecounter();
+      if (c + 1 < nstages && !(p.dbg & 1)) dma_stage(c + 1, buf ^ 1);
+      if (!(p.dbg & 2))
+        compute_from(Ws + ((size_t)buf * KCs + 2 * kw + lhalf) * BM + a_col,
+                     Xs + buf * xt_al + (2 * kw + lhalf) * span + b_col);
+      long long tb = 0;
+      if (ts_on) { tb = __builtin_readcyclecounter(); t_mma += tb - ta; }
+      __syncthreads();
+      if (ts_on) t_wait += __builtin_readcyclecounter() - tb;
+    }
   }
   if (ts_on) tsv[3] = __builtin_readcyclecounter();
   if (p.dbg & 4) { if (acc[0][0][0] == 12345.f) p.y[0] = 1.f; return; }
@@ -369,6 +464,7 @@ static size_t conv_smem_bytes(const ConvCfg& c, const ConvArgs& a) {
   int span = (c.BN - 1) * a.stride + a.KW;
   size_t xt_al = ((size_t)a.SC * a.CK * span + 3) & ~size_t(3);
   size_t stage = 2 * (xt_al + (size_t)a.SC * a.CK * a.KW * c.BM) + 2 * c.BM;
+  if (c.WK == 8) stage += 2 * 4 * c.WK;  // wave-private slices: per-wave 16-B alignment of the X image
   size_t epi = (size_t)c.WK * c.BM * (c.BN + 4);
   return 4 * (stage > epi ? stage : epi);
 }
