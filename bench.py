@@ -180,26 +180,52 @@ def main():
         torch.cuda.synchronize()
         recs = model.profile_read(max_records=16384)
         model.profile(False)
-        ms = sum(r[0] for r in recs)
-        fl = sum(r[1] for r in recs)
-        by = sum(r[2] for r in recs)
-        n = len(recs)
-        tflops = fl / (ms * 1e-3) / 1e12
-        gbs = by / (ms * 1e-3) / 1e9
+        # records: (ms, algorithmic flops, algorithmic bytes, variant); variant < 100: conv_mfma_kernel tile configs,
+        # >= 100: conv_chain_kernel (fused ConvBlock body).  The roofline entry is the generic kernel -- the largest
+        # share of the enhance among the MFMA kernels; the fused kernel is reported beside it.
+        def summarise(rr):
+            if not rr:
+                return None
+            ms_ = sum(r[0] for r in rr)
+            fl_ = sum(r[1] for r in rr)
+            by_ = sum(r[2] for r in rr)
+            return {"launches": len(rr) // max(1, args.profile_steps), "avg_launch_us": 1e3 * ms_ / len(rr),
+                    "ms_per_enhance": ms_ / max(1, args.profile_steps),
+                    "algorithmic_gflop_per_enhance": fl_ / max(1, args.profile_steps) / 1e9,
+                    "algorithmic_GB_per_enhance": by_ / max(1, args.profile_steps) / 1e9,
+                    "tflops": fl_ / (ms_ * 1e-3) / 1e12, "gbs": by_ / (ms_ * 1e-3) / 1e9,
+                    "algorithmic_bytes_per_launch": by_ / len(rr)}
+        gen = summarise([r for r in recs if r[3] < 100])
+        fused = summarise([r for r in recs if r[3] >= 100])
+        traffic, traffic_note = None, "not collected in this run (PMC passes are separate rocprofv3 runs)"
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath) and args.model == "PP16" and args.batch == 1:
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic = tj.get("conv_mfma_kernel_bytes_per_launch")
+            traffic_note = tj.get("note", "")
         roofline = {
             "kernel": "ou::conv_mfma_kernel (generic fp32-MFMA implicit-GEMM Conv1d, all tile configs)",
             "bound": "mfma",
-            "achieved": tflops,
+            "achieved": gen["tflops"],
             "peak": FP32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
-            "frac": tflops / FP32_MFMA_PEAK_TFLOPS,
-            "traffic": None,
-            "launches": n // max(1, args.profile_steps),
-            "avg_launch_us": 1e3 * ms / n,
-            "algorithmic_gflop_per_enhance": fl / max(1, args.profile_steps) / 1e9,
-            "conv_ms_per_enhance": ms / max(1, args.profile_steps),
-            "hbm_view": {"achieved_GBs": gbs, "peak_GBs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
-                         "algorithmic_GB_per_enhance": by / max(1, args.profile_steps) / 1e9},
+            "frac": gen["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+            "traffic": traffic,
+            "traffic_note": traffic_note,
+            "launches": gen["launches"],
+            "avg_launch_us": gen["avg_launch_us"],
+            "algorithmic_bytes_per_launch": gen["algorithmic_bytes_per_launch"],
+            "algorithmic_gflop_per_enhance": gen["algorithmic_gflop_per_enhance"],
+            "conv_ms_per_enhance": gen["ms_per_enhance"],
+            "hbm_view": {"achieved_GBs": gen["gbs"], "peak_GBs": HBM_PEAK_GBS, "frac": gen["gbs"] / HBM_PEAK_GBS,
+                         "algorithmic_GB_per_enhance": gen["algorithmic_GB_per_enhance"]},
+            "fused_block_kernel": None if fused is None else {
+                "kernel": "ou::conv_chain_kernel (fused ConvBlock body, C = 32 / 64 levels)",
+                "achieved": fused["tflops"], "frac": fused["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                "launches": fused["launches"], "avg_launch_us": fused["avg_launch_us"],
+                "ms_per_enhance": fused["ms_per_enhance"],
+                "algorithmic_gflop_per_enhance": fused["algorithmic_gflop_per_enhance"]},
             "method": f"device-side per-launch timing (first block start .. last block end on the 100 MHz s_memrealtime clock) of every conv launch, profiled pass of {args.profile_steps} "
                       "enhance calls right after the timed region; algorithmic FLOPs/bytes = reference (un-folded) "
                       "layer-granular accounting, SURVEY.md 8(d)",

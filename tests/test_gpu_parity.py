@@ -243,3 +243,28 @@ def test_variable_length_batch_is_padded_batch_semantics():
     for b in range(len(lens)):
         one = run_enhance(model, batch[b], [z[b:b + 1] for z in nz], n_steps=3)
         assert O.si_sdr(out[b], one) > 100
+
+
+@pytest.mark.parametrize("mode", [("3", ""), ("2", ""), ("3", "128"), ("2", "256"), ("-1", "")])
+def test_fused_convblock_matches_unfused(mode, monkeypatch):
+    """The fused ConvBlock body (conv_chain_kernel: depth 3 / depth 2, 128- / 256-column tiles) against the three
+    generic launches on the full-size model (C = 32 and C = 64 levels), a ragged length and B = 2: tile edges, halo
+    recompute, zero padding at both ends of the signal, FiLM / cond-add / residual epilogues, the c1 tap of the
+    conditioner.  Same summation order per output element, so the match is far tighter than the parity gate."""
+    model, spec, sd = get_model("PP16")
+    B, T = 2, 23517
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    noise = noise_list(11, 3, B, Tp)
+    monkeypatch.setenv("OU_FUSE", "0")
+    monkeypatch.delenv("OU_FUSE_NC", raising=False)
+    ref = run_enhance(model, mix, noise, n_steps=3)
+    ref_launches = model.launch_stats()
+    model._ws.zero_()
+    monkeypatch.setenv("OU_FUSE", mode[0])
+    if mode[1]:
+        monkeypatch.setenv("OU_FUSE_NC", mode[1])
+    out = run_enhance(model, mix, noise, n_steps=3)
+    assert model.launch_stats()[0] < ref_launches[0], "the fused path did not run"
+    for b in range(B):
+        assert O.si_sdr(ref[b], out[b]) > 100.0
