@@ -175,6 +175,7 @@ struct Runner {
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
     a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
     { const char* d = std::getenv("OU_DBG"); a.dbg = d ? std::atoi(d) : 0; }
+    { const char* d = std::getenv("OU_XCD_MAP"); a.force_xcd_map = d ? std::atoi(d) : -1; }
     a.tstamps = h->tstamps;
     int cfg = -1;
     if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {

@@ -30,7 +30,9 @@ struct ConvArgs {
   unsigned magic_up = 0;               // 2^32/up + 1 (0 when up == 1)
   int SC = 1;                          // filled by launch_conv: packed chunks per pipeline stage
   int grid_n = 1, grid_m = 1;          // filled by launch_conv: tile counts (1-D grid, XCD-aware mapping)
+  int xcd_map = 0;                     // filled by launch_conv: block -> tile mapping (see the kernel)
   int force_cfg = -1, force_sc = 0;    // tuning overrides (ou_bench_conv)
+  int force_xcd_map = -1;              // tuning: 0 / 1 / 2
   int dbg = 0;                         // phase ablation switches (tuning only)
   long long* tstamps = nullptr;        // per-wave phase cycle counts (tuning only)
   unsigned long long* prof = nullptr;  // measurement: {min block start, ~max block end} in s_memrealtime ticks (10 ns)

@@ -76,16 +76,24 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar step math
   const int kw = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
-  // XCD-aware tile mapping: block i runs on XCD i % 8 (observed; speed only).  When there are >= 8 weight slabs
-  // (m-tiles), all time tiles of slab m go to XCD m % 8, so each slab is fetched into ONE L2 instead of eight.
+  // XCD-aware tile mapping: block i runs on XCD i % 8 (observed; speed only) and every XCD has its own L2, so the
+  // operand shared by the blocks of different XCDs is fetched from memory once per XCD.  The launcher picks which
+  // operand is owned (p.xcd_map): 1 = weight slabs (all time tiles of slab m on XCD m % 8; deep levels, W >> X),
+  // 2 = time tiles (all slabs of time tile n on XCD n % 8; wide levels, X >> W), 0 = plain row-major.
   int tile_m, tile_n;
   {
     const int L = blockIdx.x, gx = p.grid_n, gy = p.grid_m;
-    if ((gy & 7) == 0) {
+    if (p.xcd_map == 1) {
       const int q = L >> 3;
       const int mg = q / gx;
       tile_n = q - mg * gx;
       tile_m = mg * 8 + (L & 7);
+    } else if (p.xcd_map == 2) {
+      const int q = L >> 3;
+      const int ng = q / gy;
+      tile_m = q - ng * gy;
+      tile_n = ng * 8 + (L & 7);
+      if (tile_n >= gx) return;  // grid padded to whole groups of 8 time tiles
     } else {
       tile_m = L / gx;
       tile_n = L - tile_m * gx;
@@ -528,7 +536,16 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   aa.magic_up = a.up == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.up) + 1u;
   aa.grid_n = (a.Nq + c.BN - 1) / c.BN;
   aa.grid_m = (a.M + c.BM - 1) / c.BM;
-  dim3 grid(aa.grid_n * aa.grid_m, 1, a.B);
+  {  // which operand an XCD's L2 owns: memory-side bytes ~ 8 X + W (slabs) vs X + 8 W (time tiles)
+    const double xb = (double)a.Cin * a.Nq * a.stride, wb = (double)a.M * a.Cin * a.KW;
+    aa.xcd_map = 0;
+    if (aa.grid_m % 8 == 0 && wb >= xb) aa.xcd_map = 1;
+    else if (aa.grid_n >= 8) aa.xcd_map = 2;
+    if (a.force_xcd_map >= 0) aa.xcd_map = a.force_xcd_map;
+    if (aa.xcd_map == 1 && aa.grid_m % 8) aa.xcd_map = 0;
+  }
+  const int gn_pad = aa.xcd_map == 2 ? (aa.grid_n + 7) / 8 * 8 : aa.grid_n;
+  dim3 grid(gn_pad * aa.grid_m, 1, a.B);
   size_t smem = conv_smem_bytes(c, aa);
   // channel pairs per wave and tap: exact groups of 4 or 2 when every wave gets the same whole number of them
   const int pairs = aa.SC * a.CK / 2;
