@@ -90,7 +90,7 @@ const char* ou_packer_last_error(const ou_packer* p);
 /* ---- weights: replaces model.load_state_dict + EMA copy + (never called) remove_weight_norm ------------
  * model_loader.py:117-132, universe.py:841-865, blocks.py:36-50.
  * The packer takes tensors under the reference's state-dict keys (host fp32), folds weight-norm
- * (w = g*v/||v||), folds the binomial anti-alias FIR into the rate-change convs (blocks.py:213-227), lays
+ * (w = g*v/||v||), keeps the binomial anti-alias FIR of the rate-change convs (blocks.py:213-227) as separate taps, lays
  * every matrix out for the gfx950 kernels and returns one contiguous fp32 blob whose layout depends on the
  * config only.  The blob is what gets broadcast over RCCL and handed to ou_create(). */
 int ou_packer_create(const ou_config* cfg, ou_packer** out);
@@ -158,11 +158,11 @@ int ou_tensor(const ou_handle* h, const char* name, size_t* byte_offset, int32_t
 int ou_launch_stats(const ou_handle* h, int32_t* n_launches, int32_t* n_conv_launches);
 /* Reserved (intermediates are never aliased in this version, so ou_tensor() can return any of them). */
 int ou_set_debug(ou_handle* h, int32_t keep_intermediates);
-/* Measurement: when enabled, every launch of the generic conv kernel in subsequent forward calls records its own
+/* Measurement: when enabled, every launch of the conv kernels (generic and fused) in subsequent forward calls records its own
  * duration on the device (first block start .. last block end, constant 100 MHz clock -- HIP events around single
  * launches also count the command-processor gaps and over-read by ~4 us).  ou_profile_read() synchronises the
  * device and returns, per launch, the ms, the layer's algorithmic FLOPs / bytes (reference, un-folded
- * accounting) and the tile config. */
+ * accounting) and the tile config (>= 100: fused ConvBlock variants). */
 int ou_profile_enable(ou_handle* h, int32_t on);
 /* Tuning aid: time ONE packed conv layer (by its reference state-dict prefix) on synthetic data, optionally forcing
  * the tile configuration / chunks-per-stage; ms per launch from HIP events. */
