@@ -268,3 +268,37 @@ def test_fused_convblock_matches_unfused(mode, monkeypatch):
     assert model.launch_stats()[0] < ref_launches[0], "the fused path did not run"
     for b in range(B):
         assert O.si_sdr(ref[b], out[b]) > 100.0
+
+
+@pytest.mark.parametrize("T", [1, 37, 160, 161, 319, 2049])
+def test_edge_lengths_vs_oracle(T):
+    """Shortest inputs the reference accepts (universe.py:219-223 always pads by 1..tot_ds samples): a single sample,
+    less than one hop, exactly one hop (pads a whole extra hop), one over; the deepest level then has 1-3 frames, every
+    conv tile and the GRU cluster run with mostly-padding tiles.  B = 3 (odd batch)."""
+    model, spec, sd = get_model("PP16m")
+    B = 3
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(23, 3, B, Tp)
+    ref = O.enhance(sd, spec.to_dict(), mix, n_steps=3, noise=nz)
+    out = run_enhance(model, mix, nz, n_steps=3)
+    assert out.shape == ref.shape == (B, T)
+    assert torch.isfinite(out).all()
+    if T > 1:
+        assert O.si_sdr(ref, out) >= GATE_DB, O.si_sdr(ref, out)
+    else:
+        assert torch.allclose(ref, out, rtol=1e-3, atol=1e-6)
+
+
+def test_full_model_odd_batch_equals_single_utterances():
+    """Full-size UNIVERSE++ at B = 5 (GRU clusters for 10 (utterance, direction) pairs in one launch, fused ConvBlock
+    tiles across batch elements): every utterance equals the same utterance enhanced alone."""
+    model, spec, sd = get_model("PP16")
+    B, T = 5, 9000
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(31, 2, B, Tp)
+    full = run_enhance(model, mix, nz, n_steps=2)
+    for b in (0, 2, 4):
+        one = run_enhance(model, mix[b], [z[b:b + 1] for z in nz], n_steps=2)
+        assert O.si_sdr(full[b], one) > 100
