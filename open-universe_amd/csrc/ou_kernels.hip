@@ -56,6 +56,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 //   Register-prefetched double-buffered LDS staging: one barrier per channel chunk.
 // =========================================================================================================
 constexpr int CONV_XCAP = 4096;  // X-tile floats per stage (SC*CK*span), spread over the block's threads
+constexpr int CONV_XCAP_BIG = 8192;  // ... for the 64x64 split-K config (2x2 accumulator tiles per wave)
 
 // Pipeline stage = SC consecutive packed chunks = SCK = SC*CK input channels.
 // LDS images of a stage:
@@ -68,7 +69,8 @@ constexpr int CONV_XCAP = 4096;  // X-tile floats per stage (SC*CK*span), spread
 template <int TM, int TN, int WM, int WN, int WK, int CONV_MAXW, int U, bool EXACT>
 __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p) {
   constexpr int CONV_NT = 64 * WM * WN * WK;      // 4 or 8 waves
-  constexpr int CONV_MAXX = CONV_XCAP / CONV_NT;  // X-tile floats per thread
+  constexpr int XCAP = (WK == 8 && TM * TN == 4) ? CONV_XCAP_BIG : CONV_XCAP;
+  constexpr int CONV_MAXX = XCAP / CONV_NT;  // X-tile floats per thread
   static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "4 or 8 waves per block");
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   //   slice of wave kw, buffer b:  Xw[2*ppw][span] (rows: local pair i, half -> channel 2*(kw + WK*i) + half)
   //                                Ww[KW][2*ppw][BM]
   constexpr bool PRIV = (WK == 8) && EXACT;
-  constexpr int PMAXX = PRIV ? CONV_XCAP / WK / 64 : 1;
+  constexpr int PMAXX = PRIV ? XCAP / WK / 64 + 1 : 1;
   const int ppw = nI_ / WK;                       // channel pairs per wave and stage (power of two)
   const int lp2 = 31 - __clz(2 * ppw);
   const int xw = 2 * ppw * span, xw_al = (xw + 3) & ~3;
@@ -447,13 +449,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
 }
 
 struct ConvCfg {
-  int BM, BN, WK, MAXW, NT;
+  int BM, BN, WK, MAXW, NT, XCAP;
   void (*kern4)(ConvArgs);  // fragment groups of 4 k-steps, exact
   void (*kern2)(ConvArgs);  // ... of 2, exact (few channel pairs per wave and tap)
   void (*kern_g)(ConvArgs); // groups of 2 with guards (odd pair counts: tiny test models only)
 };
 #define OU_CONV_CFG(BM, BN, WK, MAXW, NT, TM, TN, WM, WN)                                             \
-  {BM, BN, WK, MAXW, NT, conv_mfma_kernel<TM, TN, WM, WN, WK, MAXW, 4, true>,                          \
+  {BM, BN, WK, MAXW, NT, (WK == 8 && TM * TN == 4) ? CONV_XCAP_BIG : CONV_XCAP,                       \
+   conv_mfma_kernel<TM, TN, WM, WN, WK, MAXW, 4, true>,                          \
    conv_mfma_kernel<TM, TN, WM, WN, WK, MAXW, 2, true>, conv_mfma_kernel<TM, TN, WM, WN, WK, MAXW, 2, false>}
 static const ConvCfg kConvCfgs[] = {
     OU_CONV_CFG(64, 128, 1, 6, 256, 1, 2, 2, 2),
@@ -465,6 +468,8 @@ static const ConvCfg kConvCfgs[] = {
     // 8 waves (two per SIMD), reduction split 8 ways
     OU_CONV_CFG(32, 64, 8, 6, 512, 1, 2, 1, 1),
     OU_CONV_CFG(32, 32, 8, 6, 512, 1, 1, 1, 1),
+    // 64x64, reduction split 8 ways, 2x2 accumulator tiles per wave: one LDS read per MFMA
+    OU_CONV_CFG(64, 64, 8, 12, 512, 2, 2, 1, 1),
 };
 constexpr int kNumConvCfgs = sizeof(kConvCfgs) / sizeof(kConvCfgs[0]);
 
@@ -481,13 +486,13 @@ static hipError_t init_chain_kernels();
 hipError_t init_conv_kernels() {
   for (int i = 0; i < kNumConvCfgs; i++) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kConvCfgs[i].kern4),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kConvCfgs[i].kern2),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kConvCfgs[i].kern_g),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
   return init_chain_kernels();
@@ -501,9 +506,15 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
     if (a.force_cfg >= 0 && i != a.force_cfg) continue;
     if (c.BM == 64 && a.M <= 32) continue;
     int span = (c.BN - 1) * a.stride + a.KW;
-    if ((long)a.CK * span > CONV_XCAP) continue;
+    if ((long)a.CK * span > c.XCAP) continue;
     if ((long)a.CK * a.KW * c.BM > (long)c.MAXW * c.NT * 4) continue;
-    if (a.force_cfg < 0 && c.WK == 4) continue;  // superseded by the 8-wave split-K variants (tools/conv_sweep.py)
+    if (a.force_cfg < 0 && c.WK == 4) continue;
+    if (a.force_cfg < 0 && c.BM == 64 && c.WK == 8) continue;  // tuning only (ou_bench_conv): needs a cross-CU split-K
+    // strided convs stage `stride` input samples per output column: with fewer than two blocks per CU the 64-column
+    // tile loses to the 32-column one (enc2 rate-change conv: 22 -> 16 us)
+    if (a.force_cfg < 0 && c.WK == 8 && c.BN == 64 && a.stride >= 4 &&
+        (long)((a.M + c.BM - 1) / c.BM) * ((a.Nq + c.BN - 1) / c.BN) * a.B < 2L * num_cu)
+      continue;  // superseded by the 8-wave split-K variants (tools/conv_sweep.py)
     if (a.force_cfg < 0 && c.WK == 8 && c.BN == 64 && a.KW == 1 && a.Nq < 1024) continue;  // 1x1, tiny T: 32x32 wins
     pick = i;
     // measured on MI355X (tools/conv_sweep.py): the one-tile-per-wave configs want >= 1.5 blocks per CU before
@@ -523,8 +534,10 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
     for (int cand = 4; cand >= 2; cand >>= 1) {
       if (a.force_sc > 0 && cand > a.force_sc) continue;
       if (nch % cand) continue;
-      if ((long)cand * a.CK * span > CONV_XCAP) continue;
+      if ((long)cand * a.CK * span > c.XCAP) continue;
       if ((long)cand * a.CK * a.KW * c.BM > (long)c.MAXW * c.NT * 4) continue;
+      aa.SC = cand;
+      if (conv_smem_bytes(c, aa) > 160 * 1024) continue;
       sc = cand;
       break;
     }

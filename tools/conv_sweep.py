@@ -11,6 +11,7 @@ spec = get_spec(sys.argv[1] if len(sys.argv) > 1 else "PP16")
 model = Universe(spec, state_dict=S.synthetic_state_dict(spec, 0), device="cuda:0")
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 p = "_edm_model"
+only = sys.argv[3] if len(sys.argv) > 3 else ""
 layers = [  # (prefix, Tin, MFLOP per batch element (reference accounting))
     (p + ".encoder.ds_modules.0.conv1", 64160, 657), (p + ".encoder.ds_modules.0.conv2", 64160, 394),
     (p + ".encoder.ds_modules.0.rate_change_conv", 64160, 263),
@@ -23,8 +24,10 @@ layers = [  # (prefix, Tin, MFLOP per batch element (reference accounting))
     ("condition_model.encoder.st_convs.0", 401, 2102),
 ]
 for name, Tin, mflop in layers:
+    if only and only not in name:
+        continue
     res = []
-    for cfg in range(7):
+    for cfg in range(8):
         for sc in (1, 2, 4):
             try:
                 ms, used = model.bench_conv(name, B, Tin, cfg=cfg, sc=sc, with_res=True, iters=10)
