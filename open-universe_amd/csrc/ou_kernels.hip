@@ -510,6 +510,9 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
     if ((long)a.CK * a.KW * c.BM > (long)c.MAXW * c.NT * 4) continue;
     if (a.force_cfg < 0 && c.WK == 4) continue;
     if (a.force_cfg < 0 && c.BM == 64 && c.WK == 8) continue;  // tuning only (ou_bench_conv): needs a cross-CU split-K
+    // latent-level k3 / k5 layers (a few hundred frames, K in the thousands): the barrier-free split-K pipelines
+    // beat the one-tile-per-wave configs even when the batch supplies enough blocks (B = 8: 134 -> 114 us)
+    if (a.force_cfg < 0 && c.WK == 1 && a.KW > 1 && a.Nq < 1024 && a.Cin * a.KW >= 1024) continue;
     // strided convs stage `stride` input samples per output column: with fewer than two blocks per CU the 64-column
     // tile loses to the 32-column one (enc2 rate-change conv: 22 -> 16 us)
     if (a.force_cfg < 0 && c.WK == 8 && c.BN == 64 && a.stride >= 4 &&
