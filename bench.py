@@ -4,12 +4,17 @@ bench.py -- headline benchmark of the `model.enhance` hot path on MI355X.
 
 Metric (BASELINE.json): real-time factor (+ utterances/s) of UNIVERSE++ 16 kHz, 8-step enhance.
   step      = one `enhance` call over one batch of synthetic 4 s utterances (default batch 1 per GPU = configs[1])
-  value     = whole-job audio seconds enhanced per wall second (inputs already resident in HBM)
+  value     = whole-job audio seconds enhanced per wall second (inputs already resident in HBM), measured in the
+              PRODUCT DEFAULT mode (`model.check_status = True`: the stream is synchronised and the device status word
+              read after every call); the free-running mode (no host sync inside the loop) is reported beside it
   roofline  = the generic conv kernel (conv_mfma_kernel, the dominant kernel): algorithmic FLOPs of its launches
-              / their HIP-event durations, against the fp32 MFMA peak (157.3 TFLOP/s) -- plus the HBM view
+              / their device-side durations, against the fp32 MFMA peak (157.3 TFLOP/s) -- plus the HBM view and the
+              whole-score-forward fractions (the unit of work is one score-network forward)
   cpu_baseline = the CPU oracle (plain-PyTorch restatement of the reference path) on this box's host cores
 
-Usage: python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+Usage: python bench.py --gpus N --steps K --warmup W
+  N > 1 without a launcher: the script re-executes itself under `torch.distributed.run` with N ranks (one per GPU);
+  under a launcher (RANK / WORLD_SIZE set) it asserts WORLD_SIZE == N.
 """
 import argparse
 import json
@@ -24,6 +29,11 @@ import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+
+# SURVEY.md 8(d) [probe]: algorithmic work of ONE score-network forward on a padded 4 s utterance, layer-granular
+# accounting (every dense op reads its input once and writes its output once, folded weights read once per forward):
+#   (GFLOP, activation MB per utterance, weight MB)
+SCORE_FORWARD_WORK = {"PP16": (30.82, 421.8 + 90.3, 51.6), "OR16": (30.65, 421.9, 52.3), "PP24": (106.9, 998.6 + 216.8, 117.5)}
 
 
 def synth_mix(fs, B, T, seed0):
@@ -41,7 +51,9 @@ def synth_mix(fs, B, T, seed0):
 
 
 def cpu_baseline_worker(model_name, n_steps, seconds, budget_s):
-    """Runs in a child process: the oracle timed on the host cores (torch's default intra-op thread count)."""
+    """Runs in a child process: the oracle timed on the host cores (torch's default intra-op thread count).
+    Bounded sample: one utterance; for more than 8 diffusion steps the cost is measured at 2 and at 8 steps and
+    extended linearly (one enhance = 1 conditioner pass + n score passes, all passes identical)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import restatement as O
     import open_universe_amd  # noqa: F401
@@ -55,25 +67,34 @@ def cpu_baseline_worker(model_name, n_steps, seconds, budget_s):
     mix = synth_mix(spec.fs, 1, T, 1000)
     sdict = spec.to_dict()
     g = torch.Generator().manual_seed(1028282)
-    t0 = time.time()
-    O.enhance(sd, sdict, mix, n_steps=n_steps, rng=g)  # warm-up
-    warm = time.time() - t0
+
+    def timed(n):
+        t0 = time.time()
+        O.enhance(sd, sdict, mix, n_steps=n, rng=g)
+        return time.time() - t0
+
+    n_meas = min(n_steps, 8)
+    warm = timed(n_meas)  # warm-up
     times = []
     while len(times) < 3 and (sum(times) + warm) < budget_s:
-        t0 = time.time()
-        O.enhance(sd, sdict, mix, n_steps=n_steps, rng=g)
-        times.append(time.time() - t0)
+        times.append(timed(n_meas))
     if not times:
         times = [warm]
     times.sort()
     med = times[len(times) // 2]
+    how = f"median of {len(times)} run(s) after 1 warm-up"
+    if n_meas != n_steps:
+        t2 = timed(2)
+        per_step = max(0.0, (med - t2) / (n_meas - 2))
+        med = t2 + per_step * (n_steps - 2)
+        how += f" at {n_meas} steps, extended linearly to {n_steps} steps with the 2-step run ({per_step:.2f} s per step)"
     print("CPU_BASELINE_JSON " + json.dumps({
         "value": seconds / med,
         "unit": "x_realtime",
         "utterances_per_s": 1.0 / med,
         "cores": cores,
         "kind": "port",
-        "sample": f"1 utterance of {seconds:.0f} s, {n_steps} steps, median of {len(times)} run(s) after 1 warm-up "
+        "sample": f"1 utterance of {seconds:.0f} s, {model_name}, {n_steps} steps, {how} "
                   f"({med:.2f} s per enhance, {cores} torch threads of {os.cpu_count()} logical CPUs); "
                   "oracle/restatement.py (validated against the imported reference)",
     }))
@@ -86,7 +107,7 @@ def cpu_baseline(model_name, n_steps, seconds, budget_s=25.0, hard_limit_s=150.0
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--model", model_name,
            "--n_steps", str(n_steps), "--seconds", str(seconds), "--cpu-budget", str(budget_s)]
     env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS"):
         env.pop(k, None)
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_limit_s, env=env)
@@ -100,7 +121,7 @@ def cpu_baseline(model_name, n_steps, seconds, budget_s=25.0, hard_limit_s=150.0
                 "sample": f"cpu baseline did not finish within {hard_limit_s:.0f} s (skipped)"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -109,11 +130,43 @@ def main():
     ap.add_argument("--model", default="PP16", choices=["PP16", "OR16", "PP24"])
     ap.add_argument("--n_steps", type=int, default=8, help="diffusion steps")
     ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--varlen", action="store_true",
+                    help="variable-length batch (configs[4]): lengths seconds*U(0.25,2) s, right-zero-padded to the batch "
+                         "maximum like the reference's max_collator (datasets/datamodule.py:24-42)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--share-devices", action="store_true",
+                    help="allow more ranks than visible GPUs (ranks wrap around the devices, gloo rendezvous): "
+                         "exercises the N > 1 path on a 1-GPU box; not a scaling measurement")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=25.0, help=argparse.SUPPRESS)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def timed_loop(step, steps, world, device):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, out
+
+
+def main():
+    args = parse_args()
     if args.cpu_baseline_only:
         cpu_baseline_worker(args.model, args.n_steps, args.seconds, args.cpu_budget)
         return
@@ -124,25 +177,45 @@ def main():
     from open_universe_amd import distributed as D
     from open_universe_amd import state_dict as S
 
-    rank, local_rank, world = D.init()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        args.gpus = world
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU)
+        raise SystemExit(D.respawn_under_launcher(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.gpus > ndev and not args.share_devices:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} HIP device(s) visible "
+                         "(--share-devices runs the ranks on shared GPUs for a functional check)")
+    rank, local_rank, world = D.init()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU")
+    device = D.local_device(local_rank)
     torch.cuda.set_device(device)
+    if world > 1:
+        assert torch.distributed.get_world_size() == args.gpus
+        devs = [None] * world
+        torch.distributed.all_gather_object(devs, f"rank{rank}:cuda:{device.index}")
+    else:
+        devs = [f"rank0:cuda:{device.index}"]
 
     spec = C.spec_from_config(C.builtin_config(args.model))
     sd = S.synthetic_state_dict(spec, seed=0) if rank == 0 else None
-    blob = D.broadcast_packed_weights(spec, sd, device)  # ONE RCCL broadcast; no collective in the loop
+    blob = D.broadcast_packed_weights(spec, sd, device)  # ONE broadcast (RCCL over xGMI); no collective in the loop
     cls = UniverseGAN if spec.kind == "universe_gan" else Universe
     model = cls(spec, packed_weights=blob, device=device)
-    model.check_status = False  # no host sync inside the timed region; status is checked afterwards
 
     T = int(args.seconds * spec.fs)
-    mix = synth_mix(spec.fs, args.batch, T, 1000 + rank * args.batch).to(device)
+    lens = [T] * args.batch
+    if args.varlen:
+        g = torch.Generator().manual_seed(5 + rank)
+        lens = sorted((int(T * (0.25 + 1.75 * float(u))) for u in torch.rand(args.batch, generator=g)), reverse=True)
+        T = lens[0]
+    mix = synth_mix(spec.fs, args.batch, T, 1000 + rank * args.batch)
+    for i, n in enumerate(lens):
+        mix[i, n:] = 0.0  # max_collator: right zero padding, no mask
+    mix = mix.to(device)
+    audio_s_per_step = sum(lens) / spec.fs
     rng = torch.Generator(device=device).manual_seed(1028282 + rank)
 
     def step():
@@ -150,27 +223,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    model.check_status = True   # product default: sync + device status word after every enhance
+    dt, out = timed_loop(step, args.steps, world, device)
+    model.check_status = False  # free-running: calls are only enqueued, status checked once afterwards
+    dt_async, out = timed_loop(step, args.steps, world, device)
     model.check_status = True
     model._status()
     assert torch.isfinite(out).all()
+    launches = model.launch_stats()
 
-    # ---- roofline of the dominant kernel: per-launch HIP events (separate profiled pass, same workload) ----
+    # ---- roofline of the dominant kernel: per-launch device-side timing (separate profiled pass, same workload) ----
     roofline = None
     if rank == 0:
         model.check_status = False
@@ -178,7 +240,7 @@ def main():
         for _ in range(max(1, args.profile_steps)):
             step()
         torch.cuda.synchronize()
-        recs = model.profile_read(max_records=16384)
+        recs = model.profile_read(max_records=32768)
         model.profile(False)
         # records: (ms, algorithmic flops, algorithmic bytes, variant); variant < 100: conv_mfma_kernel tile configs,
         # >= 100: conv_chain_kernel (fused ConvBlock body).  The roofline entry is the generic kernel -- the largest
@@ -197,13 +259,45 @@ def main():
                     "algorithmic_bytes_per_launch": by_ / len(rr)}
         gen = summarise([r for r in recs if r[3] < 100])
         fused = summarise([r for r in recs if r[3] >= 100])
-        traffic, traffic_note = None, "not collected in this run (PMC passes are separate rocprofv3 runs)"
+        traffic, traffic_note = None, "not collected (PMC passes are separate rocprofv3 runs)"
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.model == "PP16" and args.batch == 1:
+        if os.path.exists(tpath) and args.model == "PP16" and args.batch == 1 and args.n_steps == 8:
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = tj.get("conv_mfma_kernel_bytes_per_launch")
-            traffic_note = tj.get("note", "")
+            traffic_note = ("STATIC: copied from profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / "
+                            "WRITE_SIZE passes of this command on an earlier box), not measured in this run. "
+                            + tj.get("note", ""))
+
+        # whole score-network forward (the unit of work of SURVEY 8(d)): HIP events on the launch stream around
+        # K calls of the operator seam score_model(x, sigma | cond)
+        xin = torch.randn(args.batch, 1, T + (spec.tot_ds - T % spec.tot_ds), device=device)
+        model.condition_model(xin)
+        sig = torch.full((args.batch,), 0.5)
+        for _ in range(2):
+            model.score_model(xin, sig)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        K = 10
+        e0.record()
+        for _ in range(K):
+            model.score_model(xin, sig)
+        e1.record()
+        torch.cuda.synchronize()
+        fwd_ms = e0.elapsed_time(e1) / K
+        gf, act_mb, w_mb = SCORE_FORWARD_WORK[args.model]
+        scale = xin.shape[-1] / (4.0 * spec.fs + spec.tot_ds)
+        fwd_flop = gf * 1e9 * scale * args.batch
+        fwd_bytes = (act_mb * scale * args.batch + w_mb) * 1e6
+        score_forward = {
+            "ms": fwd_ms, "batch": args.batch,
+            "algorithmic_gflop": fwd_flop / 1e9, "algorithmic_MB": fwd_bytes / 1e6,
+            "compute_view": {"achieved_TFLOPs": fwd_flop / (fwd_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+                             "frac": fwd_flop / (fwd_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS},
+            "hbm_view": {"achieved_GBs": fwd_bytes / (fwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "frac": fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "method": f"HIP events on the launch stream around {K} score_model(x, sigma) calls (all launches of one "
+                      "forward incl. the GRU pass, sigma embedding and FiLM table)",
+        }
         roofline = {
             "kernel": "ou::conv_mfma_kernel (generic fp32-MFMA implicit-GEMM Conv1d, all tile configs)",
             "bound": "mfma",
@@ -221,20 +315,22 @@ def main():
             "hbm_view": {"achieved_GBs": gen["gbs"], "peak_GBs": HBM_PEAK_GBS, "frac": gen["gbs"] / HBM_PEAK_GBS,
                          "algorithmic_GB_per_enhance": gen["algorithmic_GB_per_enhance"]},
             "fused_block_kernel": None if fused is None else {
-                "kernel": "ou::conv_chain_kernel (fused ConvBlock body, C = 32 / 64 levels)",
+                "kernel": "ou::conv_chain_kernel (fused ConvBlock body)",
                 "achieved": fused["tflops"], "frac": fused["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                 "launches": fused["launches"], "avg_launch_us": fused["avg_launch_us"],
                 "ms_per_enhance": fused["ms_per_enhance"],
                 "algorithmic_gflop_per_enhance": fused["algorithmic_gflop_per_enhance"]},
+            "score_forward": score_forward,
             "method": f"device-side per-launch timing (first block start .. last block end on the 100 MHz s_memrealtime clock) of every conv launch, profiled pass of {args.profile_steps} "
                       "enhance calls right after the timed region; algorithmic FLOPs/bytes = reference (un-folded) "
                       "layer-granular accounting, SURVEY.md 8(d)",
         }
 
     if rank == 0:
-        audio_s = args.steps * args.batch * args.seconds * world
+        audio_s = args.steps * audio_s_per_step * world
+        what = {"PP16": "UNIVERSE++ 16 kHz", "OR16": "UNIVERSE (original) 16 kHz", "PP24": "UNIVERSE++ 24 kHz"}[args.model]
         res = {
-            "metric": "real_time_factor (audio s / wall s), UNIVERSE++ 16 kHz 8-step enhance",
+            "metric": f"real_time_factor (audio s / wall s), {what} {args.n_steps}-step enhance",
             "value": audio_s / dt,
             "unit": "x_realtime",
             "utterances_per_s": args.steps * args.batch * world / dt,
@@ -248,21 +344,27 @@ def main():
             "dtype": "f32",
             "data": "synthetic (seeded AM-sine + noise waveforms; seeded random weights with the reference key schema)",
             "config": {
-                "workload": f"UNIVERSE++ 16 kHz, {args.n_steps} diffusion steps, batch={args.batch} utterance(s) of "
-                            f"{args.seconds:.0f} s per GPU per step" if args.model == "PP16" else
-                            f"{args.model}, {args.n_steps} steps, batch={args.batch}, {args.seconds:.0f} s",
+                "workload": f"{what}, {args.n_steps} diffusion steps, batch={args.batch} utterance(s) of "
+                            + (f"{min(lens)/spec.fs:.1f}-{max(lens)/spec.fs:.1f} s (variable length, right-zero-padded)"
+                               if args.varlen else f"{args.seconds:.0f} s") + " per GPU per step",
                 "model": args.model,
                 "n_diffusion_steps": args.n_steps,
                 "batch_per_gpu": args.batch,
                 "samples_per_utterance": T,
                 "parallelism": "utterances sharded across GPUs; packed weights broadcast once over RCCL; "
                                "no collective in the sampling loop",
+                "devices": devs,
+                "backend": torch.distributed.get_backend() if world > 1 else None,
+                "launches_per_enhance": launches[0],
             },
+            "status_mode": "value / ms_per_step: product default (stream sync + device status read after every enhance)",
+            "free_running": {"value": audio_s / dt_async, "ms_per_step": 1e3 * dt_async / args.steps,
+                             "note": "model.check_status = False: no host sync inside the timed loop, status checked after it"},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.model, args.n_steps, args.seconds)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

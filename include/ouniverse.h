@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OU_ABI_VERSION 1
+#define OU_ABI_VERSION 2
 
 enum {
   OU_OK = 0,
@@ -76,6 +76,8 @@ typedef struct ou_config {
   int32_t signal_decoupling_act; /* OU_ACT_* */
   ou_net_config score;
   ou_net_config cond;
+  int32_t has_edm_data_level; /* edm.data_level_db given (universe.py:176-178); 0: sigma_data follows level_db */
+  float edm_data_level_db;
 } ou_config;
 
 typedef struct ou_packer ou_packer;
@@ -106,6 +108,10 @@ void ou_destroy(ou_handle* h);
 
 /* Workspace needed for a batch of B signals of padded length T (T % prod(rate_factors) == 0). */
 int ou_workspace_bytes(const ou_handle* h, int32_t B, int32_t T, size_t* nbytes);
+/* Once per workspace buffer, before its first use (and after every change of (B, T)): clears the header -- the sticky
+ * device status word and the GRU exchange granules (whose tags continue from launch to launch, so the forward calls
+ * themselves enqueue no memset).  Enqueued on `stream`. */
+int ou_workspace_init(ou_handle* h, int32_t B, int32_t T, void* ws, size_t ws_bytes, ou_stream_t stream);
 
 /* Sampler constants, universe.py:301-311: sigma[n] (fp32, n = 0..n_steps-1), eta, beta. */
 int ou_schedule(const ou_config* cfg, int32_t n_steps, double epsilon, float* sigma_out, double* eta, double* beta);
@@ -144,7 +150,15 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
                int32_t n_steps, double epsilon, const float* sigma_host, int32_t warm_start, uint32_t flags,
                void* ws, size_t ws_bytes, ou_stream_t stream);
 
-/* After the stream has been synchronised: OU_OK, or OU_ESYNC if a device-side timeout flag was raised. */
+/* One sampler update on caller-owned buffers, for bindings that keep the reference's Python loop
+ * (universe.py:339 `x = x + s_now^2 * eta * score + beta * z`, :343 `x = x + s_last^2 * score`):
+ *   x[i] += c1 * score[i] + c2 * z[i]     over n = B*T elements; z may be NULL (last step).
+ * Inside ou_enhance the same update is fused into the output conv of the score network. */
+int ou_sampler_step(ou_handle* h, float* x, const float* score, const float* z, float c1, float c2, size_t n,
+                    ou_stream_t stream);
+
+/* After the stream has been synchronised: OU_OK, or OU_ESYNC if a device-side timeout flag was raised.  The status
+ * word (first 4 bytes of the workspace) is sticky: it stays raised until ou_workspace_init() / this call clears it. */
 int ou_check_device_status(ou_handle* h, void* ws);
 
 /* ---- introspection (tests, profiling) ------------------------------------------------------------------- */
@@ -156,20 +170,7 @@ const char* ou_packer_plan_json(const ou_packer* p);
 int ou_tensor(const ou_handle* h, const char* name, size_t* byte_offset, int32_t* C, int32_t* T);
 /* Number of kernels the last forward enqueued, and the generic-conv launch count among them. */
 int ou_launch_stats(const ou_handle* h, int32_t* n_launches, int32_t* n_conv_launches);
-/* Reserved (intermediates are never aliased in this version, so ou_tensor() can return any of them). */
-int ou_set_debug(ou_handle* h, int32_t keep_intermediates);
-/* Measurement: when enabled, every launch of the conv kernels (generic and fused) in subsequent forward calls records its own
- * duration on the device (first block start .. last block end, constant 100 MHz clock -- HIP events around single
- * launches also count the command-processor gaps and over-read by ~4 us).  ou_profile_read() synchronises the
- * device and returns, per launch, the ms, the layer's algorithmic FLOPs / bytes (reference, un-folded
- * accounting) and the tile config (>= 100: fused ConvBlock variants). */
-int ou_profile_enable(ou_handle* h, int32_t on);
-/* Tuning aid: time ONE packed conv layer (by its reference state-dict prefix) on synthetic data, optionally forcing
- * the tile configuration / chunks-per-stage; ms per launch from HIP events. */
-int ou_bench_conv(ou_handle* h, const char* layer, int32_t B, int32_t Tin, int32_t cfg, int32_t sc, int32_t with_res,
-                  int32_t iters, void* ws, size_t ws_bytes, ou_stream_t stream, float* ms_per_iter, int32_t* cfg_used);
-int ou_profile_read(ou_handle* h, int32_t max_records, float* ms, double* flops, double* bytes, int32_t* cfg,
-                    int32_t* n_records);
+/* Measurement / tuning entry points (ou_profile_*, ou_bench_conv) are declared in ouniverse_tuning.h. */
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 OU_MAX_RATES = 8
-OU_ABI_VERSION = 1
+OU_ABI_VERSION = 2
 OU_OK, OU_EINVAL, OU_ENOTIMPL, OU_EMISSING, OU_ESHAPE, OU_EHIP, OU_ENOMEM, OU_ESYNC = 0, -1, -2, -3, -4, -5, -6, -7
 OU_KIND_UNIVERSE, OU_KIND_UNIVERSE_GAN = 0, 1
 OU_ACT_NONE, OU_ACT_PRELU, OU_ACT_SNAKE = 0, 1, 2
@@ -48,6 +48,8 @@ class Config(Structure):
         ("signal_decoupling_act", c_int32),
         ("score", NetConfig),
         ("cond", NetConfig),
+        ("has_edm_data_level", c_int32),
+        ("edm_data_level_db", c_float),
     ]
 
 
@@ -97,7 +99,8 @@ def load():
         "ou_packer_plan_json": (c_char_p, [vp]),
         "ou_tensor": (i32, [vp, c_char_p, POINTER(sz), POINTER(i32), POINTER(i32)]),
         "ou_launch_stats": (i32, [vp, POINTER(i32), POINTER(i32)]),
-        "ou_set_debug": (i32, [vp, i32]),
+        "ou_workspace_init": (i32, [vp, i32, i32, vp, sz, vp]),
+        "ou_sampler_step": (i32, [vp, vp, vp, vp, c_float, c_float, sz, vp]),
         "ou_profile_enable": (i32, [vp, i32]),
         "ou_bench_conv": (i32, [vp, c_char_p, i32, i32, i32, i32, i32, i32, vp, sz, vp, POINTER(c_float), POINTER(i32)]),
         "ou_profile_read": (i32, [vp, i32, POINTER(c_float), POINTER(c_double), POINTER(c_double), POINTER(i32), POINTER(i32)]),
@@ -114,7 +117,9 @@ EXPORTED_SYMBOLS = [
     "ou_version", "ou_last_error", "ou_packer_last_error", "ou_packer_create", "ou_packer_set", "ou_packer_finish",
     "ou_packer_destroy", "ou_packed_bytes", "ou_create", "ou_destroy", "ou_workspace_bytes", "ou_schedule",
     "ou_condition", "ou_score", "ou_aux_to_wav", "ou_enhance", "ou_check_device_status", "ou_plan_json",
-    "ou_packer_plan_json", "ou_tensor", "ou_launch_stats", "ou_set_debug", "ou_profile_enable", "ou_profile_read", "ou_bench_conv",
+    "ou_packer_plan_json", "ou_tensor", "ou_launch_stats", "ou_workspace_init", "ou_sampler_step",
+]
+TUNING_SYMBOLS = ["ou_profile_enable", "ou_profile_read", "ou_bench_conv",
 ]
 
 _EXC = {OU_EINVAL: ValueError, OU_ENOTIMPL: NotImplementedError, OU_EMISSING: KeyError, OU_ESHAPE: ValueError,
@@ -167,6 +172,9 @@ def make_config(spec):
     cfg.signal_decoupling_act = {"snake": OU_ACT_SNAKE, "prelu": OU_ACT_PRELU}.get(spec.signal_decoupling_act, OU_ACT_NONE)
     cfg.score = net(spec.score)
     cfg.cond = net(spec.cond)
+    data_level = getattr(spec, "edm_data_level_db", None)
+    cfg.has_edm_data_level = int(data_level is not None)
+    cfg.edm_data_level_db = float(data_level) if data_level is not None else 0.0
     return cfg
 
 

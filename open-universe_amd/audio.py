@@ -24,6 +24,11 @@ def _torchaudio():
         return None
 
 
+def can_decode(path):
+    """True when `load` can read this file here: anything with torchaudio, .wav without."""
+    return _torchaudio() is not None or Path(path).suffix.lower() == ".wav"
+
+
 def load(path):
     """-> (float32 tensor (channels, T) in [-1, 1], sample rate): torchaudio.load semantics."""
     ta = _torchaudio()

@@ -22,7 +22,7 @@ from pathlib import Path
 import torch
 
 from .. import inference_utils
-from ..audio import AUDIO_SUFFIXES, load, resample, save
+from ..audio import AUDIO_SUFFIXES, can_decode, load, resample, save
 
 
 def handle_help(argv):
@@ -87,7 +87,8 @@ def main(argv=None, model=None):
     if model is None:
         device = args.device
         if world > 1:
-            device = f"cuda:{int(os.environ.get('LOCAL_RANK', rank))}"
+            # one GPU per rank; ranks wrap around the visible devices when there are fewer GPUs than ranks
+            device = f"cuda:{int(os.environ.get('LOCAL_RANK', rank)) % max(1, torch.cuda.device_count())}"
         if not device.startswith("cuda"):
             raise ValueError("Device name should be 'cuda:X' where X is an integer (this build has no CPU path). "
                              f"Provided {device}")
@@ -108,6 +109,12 @@ def main(argv=None, model=None):
     rng = torch.Generator(device=device)
     rng.manual_seed(args.seed)
 
+    undecodable = [str(p) for p in files if not can_decode(p)]
+    if undecodable:
+        # fail before the first file is enhanced, not in the middle of a directory (torchaudio is what the reference
+        # decodes .mp3 / .flac with, bin/enhance.py:183)
+        raise RuntimeError(f"{len(undecodable)} input file(s) need torchaudio to be decoded (only .wav is read natively): "
+                           + ", ".join(undecodable[:5]))
     todo = plan_files(files, world, rank)
 
     done = []

@@ -61,6 +61,8 @@ class ModelSpec:
     use_signal_decoupling: bool = False
     signal_decoupling_act: Optional[str] = None
     ema_decay: float = 0.0
+    norm_ref: str = "both"                       # normalization_kwargs.ref (only the `target` mode looks at it)
+    edm_data_level_db: Optional[float] = None    # edm.data_level_db (universe.py:176-178); None: level_db
 
     @property
     def tot_ds(self):
@@ -165,6 +167,9 @@ def spec_from_config(config):
         use_signal_decoupling=bool(kind == "universe_gan" and losses.get("use_signal_decoupling", False)),
         signal_decoupling_act=losses.get("signal_decoupling_act") if kind == "universe_gan" else None,
         ema_decay=float((m.get("training") or {}).get("ema_decay", 0.0) or 0.0),
+        norm_ref=str(nk.get("ref", "noisy")),  # utils/norm.py:47 default
+        edm_data_level_db=(float(edm["data_level_db"]) if edm is not None and edm.get("data_level_db") is not None
+                           else None),
     )
 
 

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/ouniverse.h"
+#include "../../include/ouniverse_tuning.h"
 #include "ou_kernels.h"
 #include "ou_model.h"
 
@@ -537,7 +538,8 @@ StepCoef make_coef(const ou_config& cfg, float s, bool last, double eta, double 
   StepCoef c;
   const float s2 = s * s;
   if (cfg.has_edm) {
-    const double sd = std::pow(10.0, (double)cfg.level_db / 20.0);
+    // universe.py:176-178: sigma_data from edm.data_level_db, else from normalization_kwargs.level_db
+    const double sd = std::pow(10.0, (double)(cfg.has_edm_data_level ? cfg.edm_data_level_db : cfg.level_db) / 20.0);
     const float sd2 = (float)(sd * sd);
     const float sn2 = s2 + sd2;
     const float sn = std::sqrt(sn2);
@@ -738,7 +740,6 @@ int ou_condition(ou_handle* h, const float* mix_norm, int32_t B, int32_t T, void
   Runner r(h, ws, ws_bytes, false, (hipStream_t)stream, B);
   Persist P = layout_persist(r, T);
   if (r.oom) return finish(h, r);
-  r.chk(hipMemsetAsync(P.status, 0, 256, r.st), "status");
   run_condition(r, P, mix_norm, T);
   h->cond_B = B;
   h->cond_T = T;
@@ -812,7 +813,6 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
   Runner r(h, ws, ws_bytes, false, st, B);
   Persist P = layout_persist(r, T);
   if (r.oom) return finish(h, r);
-  r.chk(hipMemsetAsync(P.status, 0, 256, st), "status");
 
   std::vector<float> sigma(n_steps);
   double eta, beta;
@@ -909,7 +909,32 @@ int ou_check_device_status(ou_handle* h, void* ws) {
   unsigned v = 0;
   hipError_t e = hipMemcpy(&v, ws, sizeof(v), hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(h, OU_EHIP, hipGetErrorString(e));
-  if (v) return fail(h, OU_ESYNC, "device-side timeout in the GRU cluster exchange (status word " + std::to_string(v) + ")");
+  if (v) {
+    (void)hipMemset(ws, 0, sizeof(v));  // sticky until read
+    return fail(h, OU_ESYNC, "device-side timeout in the GRU cluster exchange (status word " + std::to_string(v) + ")");
+  }
+  return OU_OK;
+}
+
+int ou_workspace_init(ou_handle* h, int32_t B, int32_t T, void* ws, size_t ws_bytes, ou_stream_t stream) {
+  if (!h || !ws || B < 1 || T < 1) return fail(h, OU_EINVAL, "bad argument");
+  if (T % h->m.tot_ds) return fail(h, OU_EINVAL, "T must be a multiple of the total down-sampling factor");
+  auto keep = h->tensors;
+  Runner r(h, ws, ws_bytes, false, (hipStream_t)stream, B);
+  Persist P = layout_persist(r, T);
+  h->tensors = keep;
+  if (r.oom) return finish(h, r);
+  // header: status word, coefficient rows, statistics, both GRU exchange areas (everything in front of mel_scale)
+  const size_t hdr = (size_t)((char*)P.mel_scale - (char*)ws);
+  r.chk(hipMemsetAsync(ws, 0, hdr, r.st), "workspace init");
+  return finish(h, r);
+}
+
+int ou_sampler_step(ou_handle* h, float* x, const float* score, const float* z, float c1, float c2, size_t n,
+                    ou_stream_t stream) {
+  if (!h || !x || !score) return fail(h, OU_EINVAL, "bad argument");
+  hipError_t e = launch_sampler_step(x, score, z, c1, c2, n, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(h, OU_EHIP, hipGetErrorString(e));
   return OU_OK;
 }
 
@@ -929,8 +954,6 @@ int ou_launch_stats(const ou_handle* h, int32_t* n_launches, int32_t* n_conv_lau
   if (n_conv_launches) *n_conv_launches = h->n_conv;
   return OU_OK;
 }
-
-int ou_set_debug(ou_handle* h, int32_t keep) { (void)keep; return h ? OU_OK : OU_EINVAL; }
 
 // Micro-benchmark of ONE packed conv layer (measurement / tuning only): runs it `iters` times on random-ish data in
 // the caller's workspace with HIP events around the batch; cfg/sc < 0: the launcher's own choice.

@@ -78,6 +78,11 @@ hipError_t launch_post(const float* x, const float* stats, float* out, int B, in
 // x0 = sigma0 * noise (universe.py:326) ; optionally x0 = base + sigma*noise (warm start :330)
 hipError_t launch_init_x(const float* noise, const float* base, float sigma, float* x, size_t n, hipStream_t st);
 
+// x += c1*score + c2*z  (universe.py:339,343; z may be null) -- the stand-alone form of the update that ou_enhance fuses
+// into the output conv
+hipError_t launch_sampler_step(float* x, const float* score, const float* z, float c1, float c2, size_t n,
+                               hipStream_t st);
+
 // mel front-end (condition.py:92-108): power STFT -> mel fb ; esum[b][frame] = sum_mel mel^2
 hipError_t launch_mel(const float* x, const float* win, const float* tw, const float* fb, float* mel, float* esum,
                       int B, int T, int n_fft, int hop, int pad_left, int n_freq, int n_mels, int L, hipStream_t st);

@@ -1246,6 +1246,21 @@ hipError_t launch_init_x(const float* noise, const float* base, float sigma, flo
   return hipGetLastError();
 }
 
+__global__ void sampler_step_kernel(float* __restrict__ x, const float* __restrict__ score, const float* z, float c1,
+                                    float c2, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float r = x[i] + c1 * score[i];  // universe.py:339 / :343, same association as the fused update in out_conv_kernel
+  if (z) r = r + c2 * z[i];
+  x[i] = r;
+}
+hipError_t launch_sampler_step(float* x, const float* score, const float* z, float c1, float c2, size_t n,
+                               hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, score, z, c1, c2, n);
+  return hipGetLastError();
+}
+
 // ---- mel front-end -------------------------------------------------------------------------------------------
 // One block per (frame, batch).  n_fft is 640 / 960 (not a power of two): direct DFT with an exact
 // (k*n mod N) twiddle table in LDS; 0.33 GFLOP per utterance, once per enhance call.

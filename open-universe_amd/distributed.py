@@ -5,8 +5,15 @@ weights distributed once by an RCCL broadcast over xGMI, NO collective inside th
 the ensemble reduce stays on one rank).
 
 The reference has no multi-GPU inference (bin/enhance.py:173-192 is a serial per-file loop on one device).
+
+Backends: `nccl` (= RCCL) when every rank owns its own GPU; `gloo` otherwise -- CPU-only hosts (tests) and the
+"several ranks share one GPU" arrangement used to exercise the N > 1 path on a 1-GPU box: RCCL refuses two ranks on one
+device, so the weight blob is then broadcast over gloo on the host and copied to the device by each rank.
 """
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
@@ -18,16 +25,50 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def pick_backend(world):
+    """nccl (RCCL) iff there is one visible GPU per local rank; gloo for CPU hosts and shared-device runs."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= world:
+        return "nccl"
+    return "gloo"
+
+
+def local_device(local_rank):
+    """The HIP device of this rank (ranks wrap around the visible devices when they share GPUs), or CPU."""
+    if not torch.cuda.is_available():
+        return torch.device("cpu")
+    return torch.device("cuda", local_rank % torch.cuda.device_count())
+
+
 def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (nccl == RCCL on ROCm; gloo on CPU)."""
+    """Initialise torch.distributed from the torchrun environment (nccl == RCCL on ROCm; gloo on CPU / shared GPU)."""
     rank, local_rank, world = env_rank()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            backend = pick_backend(world)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_device(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def respawn_under_launcher(script, argv, nproc, timeout=None):
+    """`python <script> --gpus N` started WITHOUT a launcher: re-execute the same command line under
+    `torch.distributed.run` with N local ranks (rendezvous on 127.0.0.1) and return its exit code.  stdout / stderr are
+    inherited, so the one JSON line rank 0 prints is the output of the outer process too."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    return subprocess.run(cmd, env=env, timeout=timeout).returncode
 
 
 def shard_utterances(lengths, world_size):
@@ -45,15 +86,19 @@ def broadcast_packed_weights(spec, state_dict, device, src=0):
     (PP16: 185 MB, one xGMI hop).  Returns the device tensor to hand to Universe(packed_weights=...)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
+    device = torch.device(device)
     nfloats = _lib.packed_bytes(spec) // 4
+    # the collective runs where the backend lives: on the GPUs for RCCL, on the host for gloo
+    on_host = world > 1 and dist.get_backend() == "gloo"
+    xdev = torch.device("cpu") if on_host else device
     if rank == src:
         blob, _ = _lib.pack_weights(spec, state_dict)
-        blob = blob.to(device)
+        blob = blob.to(xdev)
     else:
-        blob = torch.empty(nfloats, dtype=torch.float32, device=device)
+        blob = torch.empty(nfloats, dtype=torch.float32, device=xdev)
     if world > 1:
         dist.broadcast(blob, src=src)
-    return blob
+    return blob.to(device)
 
 
 def gather_outputs(local_outputs, local_indices, n_total, dst=0):
@@ -74,3 +119,31 @@ def gather_outputs(local_outputs, local_indices, n_total, dst=0):
         for i, o in part:
             out[i] = o
     return out
+
+
+def utterance_generator(device, seed, index):
+    """Per-utterance noise stream: generator of utterance k is seeded with seed + k, so that the enhanced signal of an
+    utterance does not depend on which rank -- or beside which other utterances -- it was processed."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed) + int(index))
+    return g
+
+
+def enhance_sharded(model, signals, seed=1028282, gather=True, **enhance_kwargs):
+    """Enhance a list of 1-D signals (any lengths) across the ranks of the current process group.
+
+    Rank r takes its LPT shard (`shard_utterances`), enhances each utterance with its own generator
+    (`utterance_generator`) -- one `enhance` call per utterance, so no cross-utterance padding enters the result and a
+    1-rank run and an N-rank run are bit-identical -- and the results are gathered on rank 0 in the original order
+    (None on the other ranks; with gather=False every rank returns {index: tensor} of its shard)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    lengths = [int(s.shape[-1]) for s in signals]
+    mine = shard_utterances(lengths, world)[rank]
+    outs = []
+    for i in mine:
+        x = signals[i].to(model.device)
+        outs.append(model.enhance(x, rng=utterance_generator(model.device, seed, i), **enhance_kwargs))
+    if not gather:
+        return dict(zip(mine, outs))
+    return gather_outputs(outs, mine, len(signals))

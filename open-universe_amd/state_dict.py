@@ -289,27 +289,75 @@ def checkpoint_from_state_dict(spec: ModelSpec, sd, with_ema=True, ema_jitter=0.
     return ckpt
 
 
-def inference_state_dict(spec: ModelSpec, ckpt) -> Dict[str, torch.Tensor]:
+def merge_lora(sd, lora_alpha=None):
+    """Fold LoRA adapters back into plain weights (open_universe/lora/lora.py: `_get_weights` of LoraConv1d :68-71,
+    LoraConvTranspose1d :144-147, LoraLinear :245-247) and strip the `model.` prefix a `UniverseLoRA` wrapper adds
+    (networks/universe/lora.py:66-80 keeps the base model as `self.model`).
+
+    `lora.remove()` (lora/utils.py:72-89) only un-wraps LoraConv1d / LoraLinear, so a "merged" checkpoint still carries
+    adapters on the ConvTranspose1d layers; both forms -- and fully un-merged ones -- come out of here as the plain
+    `<prefix>.weight` / `<prefix>.bias` tensors of the base model.  W = W0 + (alpha / rank) * (A @ B).view_as(W0);
+    alpha is not stored in the checkpoint (default: alpha = rank -> scale 1)."""
+    sd = dict(sd)
+    if sd and all(k.startswith("model.") for k in sd):
+        sd = {k[len("model."):]: v for k, v in sd.items()}
+    for kind, inner in (("lora_weight", "conv"), ("lora_linear", "linear")):
+        for ka in [k for k in sd if k.endswith("." + kind + "_a")]:
+            pfx = ka[: -len(kind) - 3]
+            a, b = sd.pop(ka), sd.pop(pfx + "." + kind + "_b")
+            w0 = sd.pop(pfx + "." + inner + ".weight")
+            rank = a.shape[1]
+            scale = 1.0 if lora_alpha is None else float(lora_alpha) / rank
+            sd[pfx + ".weight"] = w0 + scale * (a.double() @ b.double()).view(w0.shape).to(w0.dtype)
+            if pfx + "." + inner + ".bias" in sd:
+                sd[pfx + ".bias"] = sd.pop(pfx + "." + inner + ".bias")
+    return sd
+
+
+def inference_state_dict(spec: ModelSpec, ckpt, lora_alpha=None) -> Dict[str, torch.Tensor]:
     """Resolve the tensors inference runs on (model_loader.py:117-132 + universe.py:841-865):
-    state_dict (strict=False, loss/discriminator keys ignored), overwritten by the EMA shadow weights."""
-    sd_in = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+    state_dict (loss/discriminator keys ignored), overwritten by the EMA shadow weights.
+
+    Also accepts what fine-tuning leaves behind: LoRA adapters (merged here, see merge_lora) and
+    weight-norm already removed (`Universe.remove_weight_norm`, universe.py:135-136 / blocks.py:45-50, called by
+    UniverseLoRA._fix_model): a plain `<p>.weight` stands in for `<p>.weight_g` + `<p>.weight_v` -- the packer takes
+    either.  Missing inference tensors are always fatal (the reference's strict=False would silently keep random
+    initialisation there)."""
+    has_wrapper = isinstance(ckpt, dict) and "state_dict" in ckpt
+    sd_in = ckpt["state_dict"] if has_wrapper else ckpt
+    had_lora = any(".lora_weight_" in k or ".lora_linear_" in k for k in sd_in)
+    sd_in = merge_lora(sd_in, lora_alpha)
     schema = model_schema(spec)
     out: Dict[str, torch.Tensor] = {}
     missing = []
+    unnormed = False
     for key, shape, is_p in schema:
         if key in sd_in:
             t = sd_in[key]
             if tuple(t.shape) != tuple(shape):
                 raise ValueError(f"checkpoint tensor {key} has shape {tuple(t.shape)}, expected {shape}")
             out[key] = t
+        elif key.endswith(".weight_g") and key[:-2] in sd_in:
+            unnormed = True  # weight-norm removed: handled with the matching weight_v entry
+        elif key.endswith(".weight_v") and key[:-2] in sd_in:
+            t = sd_in[key[:-2]]
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"checkpoint tensor {key[:-2]} has shape {tuple(t.shape)}, expected {shape}")
+            out[key[:-2]] = t
+            unnormed = True
         elif not is_p:
             out[key] = buffer_value(key, shape)
         else:
             missing.append(key)
     if missing:
         raise KeyError(f"{len(missing)} tensors missing from checkpoint, e.g. {missing[:4]}")
-    ema = ckpt.get("ema") if isinstance(ckpt, dict) and "state_dict" in ckpt else None
+    ema = ckpt.get("ema") if has_wrapper else None
     if ema is not None and spec.ema_decay > 0.0:
+        if had_lora or unnormed:
+            # the shadow list of such a run follows UniverseLoRA.trainable_parameters (lora.py:135-138), not
+            # model_parameters(): it cannot be mapped onto the base model's tensors
+            raise NotImplementedError("EMA shadow weights of a LoRA / weight-norm-removed checkpoint are not supported; "
+                                      "save the merged model's state_dict without the `ema` entry")
         names = parameter_names(spec)
         shadow = ema["shadow_params"]
         if len(shadow) != len(names):

@@ -51,12 +51,17 @@ class Universe:
         self.fs = spec.fs
         self.diff_kwargs = spec.diff_kwargs
         self.normalization_norm = 2
-        self.normalization_kwargs = {"ref": "both", "level_db": spec.level_db}
+        self.normalization_kwargs = {"ref": spec.norm_ref, "level_db": spec.level_db}
         self.with_edm = spec.edm_noise is not None
         self.tot_ds = spec.tot_ds
         self.n_channels = spec.score.n_channels
         self.device = device
-        self.check_status = True  # synchronise + read the device status word after every call
+        # True: synchronise the stream and raise on a device-side timeout after every call (product default).
+        # False: free-running -- the status word is still copied to pinned host memory after every call (async,
+        # no host sync) and examined at the start of the next call, in synchronize() and in _status(force=True).
+        self.check_status = True
+        self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._status_event = None
         self.training = False
         self._cfg = _lib.make_config(spec)
         if packed_weights is None:
@@ -107,14 +112,47 @@ class Universe:
             _lib.check(self._L.ou_workspace_bytes(self._handle, B, T, byref(n)), self._handle)
             self._ws = None
             self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(self._L.ou_workspace_init(self._handle, B, T, c_void_p(self._ws.data_ptr()),
+                                                     c_size_t(n.value), self._stream()), self._handle)
             self._ws_key = key
             self._cond_key = None
         return self._ws
 
-    def _status(self):
-        if self.check_status:
-            torch.cuda.current_stream(self.device).synchronize()
-            _lib.check(self._L.ou_check_device_status(self._handle, c_void_p(self._ws.data_ptr())), self._handle)
+    def _raise_on_status(self):
+        self._status_event = None
+        v = int(self._status_host[0])
+        if v:
+            self._status_host.zero_()
+            self._ws[:4].zero_()  # the device word is sticky until cleared
+            raise RuntimeError(f"device-side timeout in the GRU cluster exchange (status word {v}); "
+                               "the output of that call is invalid")
+
+    def _poll_deferred_status(self):
+        """Free-running mode: look at the status copy of an EARLIER call once its event has completed."""
+        if self._status_event is not None and self._status_event.query():
+            self._raise_on_status()
+
+    def _status(self, force=False):
+        """Called after every forward: enqueue the (async) copy of the device status word; in the default mode -- or
+        with force=True -- wait for it and raise if a kernel flagged a timeout."""
+        if self._ws is None:
+            return
+        st = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(st):
+            self._status_host.copy_(self._ws[:4].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        self._status_event = ev
+        if self.check_status or force:
+            ev.synchronize()
+            self._raise_on_status()
+
+    def synchronize(self):
+        """Wait for everything enqueued by this model and raise if any call since the last check timed out."""
+        torch.cuda.current_stream(self.device).synchronize()
+        if self._status_event is not None:
+            self._raise_on_status()
 
     def tensor(self, name):
         """Debug: view of a named intermediate of the last call inside the workspace -> (B, C, T) tensor."""
@@ -249,6 +287,7 @@ class Universe:
     @torch.no_grad()
     def _enhance(self, mix, n_steps, epsilon, target, fake_score_snr, rng, use_aux_signal, keep_rms, ensemble,
                  ensemble_stat, warm_start, noise):
+        self._poll_deferred_status()
         if epsilon is None:
             epsilon = self.diff_kwargs.epsilon
         if n_steps is None:
@@ -337,13 +376,19 @@ class Universe:
         tot = self.tot_ds
         level = 10 ** (self.spec.level_db / 20.0)
 
-        def norm(t):
-            t = torch.nn.functional.pad(t, (pad // 2, pad - pad // 2))
-            t = t - t.mean(dim=(1, 2), keepdim=True)
-            return t * (level / t.std(dim=(1, 2), keepdim=True).clamp(min=1e-5))
+        def stats(t):
+            mean = t.mean(dim=(1, 2), keepdim=True)
+            return mean, level / (t - mean).std(dim=(1, 2), keepdim=True).clamp(min=1e-5)
 
-        mixp = norm(mix)
-        tgt = norm(self._prep(target))
+        def padded(t):
+            return torch.nn.functional.pad(t, (pad // 2, pad - pad // 2))
+
+        # utils/norm.py:47-87: ref == "both" normalises the target by its own statistics, "noisy" by the mixture's
+        mixp, tgt = padded(mix), padded(self._prep(target))
+        m_mean, m_gain = stats(mixp)
+        t_mean, t_gain = stats(tgt) if self.normalization_kwargs["ref"] == "both" else (m_mean, m_gain)
+        mixp = (mixp - m_mean) * m_gain
+        tgt = (tgt - t_mean) * t_gain
         score_snr = 5.0 if fake_score_snr is None else fake_score_snr
         delta_t = 1.0 / (n_steps - 1)
         gamma = (self.diff_kwargs.sigma_max / self.diff_kwargs.sigma_min) ** -delta_t
@@ -375,15 +420,24 @@ class UniverseGAN(Universe):
 
 
 def signal_median(signal):
-    """utils/stats.py:22-66: pick, per batch entry, the ensemble member that is the per-sample median most often."""
+    """utils/stats.py:22-66 semantics without the sort: for every (batch entry, sample) the reference looks up, in the
+    ascending order of the n ensemble members, the POSITION of the member whose index is nearest to n/2 (first hit in
+    rank order on a tie), histograms those positions per batch entry and returns member number argmax(histogram).
+    Here the position of member c is obtained by counting the members that precede it ("x_j < x_c", ties broken by
+    member index like a stable sort), and the histogram is one bincount over (batch entry, position) pairs."""
     shape = signal.shape
-    signal = signal.flatten(start_dim=2)
-    n = signal.shape[0]
-    _, sorted_indices = signal.sort(dim=0)
-    _, min_indices = abs(sorted_indices - n / 2).min(dim=0)
-    pad_bins = torch.broadcast_to(torch.arange(n, device=signal.device)[None, :], (min_indices.shape[0], n))
-    min_indices = torch.cat((min_indices, pad_bins), dim=1)
-    counts = torch.cat([(min_indices == i).sum(dim=1, keepdim=True) for i in range(n)], dim=1) - 1
-    select = counts.argmax(dim=1)
-    med = torch.stack([signal[select[i], i, :] for i in range(signal.shape[1])], dim=0)
-    return med.reshape(shape[1:])
+    x = signal.flatten(start_dim=2)  # (n, B, S)
+    n, B, S = x.shape
+    dist = (torch.arange(n, dtype=torch.float64) - n / 2).abs()
+    cands = [c for c in range(n) if float(dist[c]) == float(dist.min())]
+    pos = None
+    for c in cands:
+        before = (x < x[c]).sum(dim=0)
+        if c > 0:
+            before = before + (x[:c] == x[c]).sum(dim=0)
+        pos = before if pos is None else torch.minimum(pos, before)  # (B, S): rank position, smaller wins a tie
+    rows = torch.arange(B, device=x.device)[:, None] * n
+    hist = torch.bincount((rows + pos).flatten(), minlength=B * n).view(B, n)
+    pick = hist.argmax(dim=1)  # first maximum, like the reference's counts.argmax
+    out = x[pick, torch.arange(B, device=x.device)]
+    return out.reshape(shape[1:])

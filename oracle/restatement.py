@@ -375,8 +375,9 @@ def normalize(x, level_db, eps=1e-5):
 
 
 def edm_weights(spec, sigma):
-    """universe.py:175-189."""
-    sigma_data = 10.0 ** (spec["level_db"] / 20.0)
+    """universe.py:175-189 (sigma_data from edm.data_level_db when given, else normalization_kwargs.level_db)."""
+    level_db = spec.get("edm_data_level_db")
+    sigma_data = 10.0 ** ((spec["level_db"] if level_db is None else level_db) / 20.0)
     sigma_norm = (sigma ** 2 + sigma_data ** 2) ** 0.5
     return {
         "skip": sigma_data ** 2 / (sigma ** 2 + sigma_data ** 2),
@@ -456,9 +457,15 @@ def enhance(sd, spec, mix, n_steps=None, epsilon=None, target=None, fake_score_s
     mix_len = mix.shape[-1]
     pad = tot_ds - mix_len % tot_ds  # universe.py:219-223 (a full block when already a multiple)
     mix = F.pad(mix, (pad // 2, pad - pad // 2))
-    mix = normalize(mix, spec["level_db"])
     if target is not None:
-        target = normalize(F.pad(target, (pad // 2, pad - pad // 2)), spec["level_db"])
+        target = F.pad(target, (pad // 2, pad - pad // 2))
+        if spec.get("norm_ref", "both") == "both":  # utils/norm.py:77-82: the target by its own statistics
+            target = normalize(target, spec["level_db"])
+        else:  # utils/norm.py:83-84 ref == "noisy": (tgt - mean_mix) * gain_mix
+            mean = mix.mean(dim=(1, 2), keepdim=True)
+            gain = 10 ** (spec["level_db"] / 20.0) / (mix - mean).std(dim=(1, 2), keepdim=True).clamp(min=1e-5)
+            target = (target - mean) * gain
+    mix = normalize(mix, spec["level_db"])
     score_snr = 5.0 if fake_score_snr is None else fake_score_snr
     noise_iter = iter(noise) if noise is not None else None
 

@@ -9,7 +9,13 @@ Fixtures are DATA only: inputs are regenerated from seeds, outputs are stored as
     small_<cfg>.npz      reduced-width models: conditioner / score-net / enhance outputs (several option sets)
     full_PP16.npz        UNIVERSE++ 16 kHz full size, 4 s, 8 steps (the headline configuration)
     schedule.npz         sampler constants for N in {2, 8, 32, 64}
-Run:  python tests/golden/make_golden.py
+    stress_<cfg>.npz     second weight draw (seed 1) and the "stress" draw (seed 3, gain 1.3: activations and GRU
+                         pre-activations several times larger) of the reduced-width models
+    full_PP16_n64.npz    BASELINE configs[2] per-utterance shape: UNIVERSE++ 16 kHz, 4 s, 64 steps
+    full_OR16_n32.npz    BASELINE configs[3]: original UNIVERSE 16 kHz, 4 s, 32 steps, 2 utterances
+    full_PP24_varlen.npz BASELINE configs[4]: UNIVERSE++ 24 kHz, 8 steps, variable-length batch of 8 right-zero-padded
+                         to its longest member (datasets/datamodule.py:24-42); rows 0 / 7 (longest / shortest) stored
+Run:  python tests/golden/make_golden.py [base] [stress] [configs]      (default: base)
 """
 import json
 import os
@@ -30,7 +36,16 @@ from open_universe_amd import state_dict as S  # noqa: E402
 REF_CFG = {"PP16": "default", "OR16": "universe_original", "PP24": "universepp_24k"}
 
 
-def build(name):
+STRESS = {"s1g1": dict(seed=1, gain=1.0), "s3g13": dict(seed=3, gain=1.3)}
+
+
+def varlen_lengths(fs=24000, n=8, seed=5):
+    """L_i = fs * U(1, 8) s, manual_seed(5), sorted descending."""
+    u = torch.rand(n, generator=torch.Generator().manual_seed(seed))
+    return sorted((int(fs * (1.0 + 7.0 * float(v))) for v in u), reverse=True)
+
+
+def build(name, seed=0, gain=1.0):
     base, over = SMALL.get(name, (name, {}))
     ov = {}
     for k, v in over.items():
@@ -38,13 +53,69 @@ def build(name):
         ov[k.replace("score_model", "condition_model")] = v
     m, cfg = R.build_reference_model(REF_CFG[base], ov)
     spec = get_spec(name)
-    sd = S.synthetic_state_dict(spec, seed=0)
+    sd = S.synthetic_state_dict(spec, seed=seed, gain=gain)
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all(k.startswith("loss_") for k in missing)
     if m.ema is not None:
         m.ema.shadow_params = [p.clone().detach() for p in m.model_parameters()]
     m.eval()
     return m, spec, sd
+
+
+def normalized_input(spec, mix, Tp):
+    T = mix.shape[-1]
+    xin = torch.nn.functional.pad(mix[:, None, :], ((Tp - T) // 2, (Tp - T) - (Tp - T) // 2))
+    xin = (xin - xin.mean(dim=(1, 2), keepdim=True))
+    return xin * (10 ** (spec.level_db / 20) / xin.std(dim=(1, 2), keepdim=True).clamp(min=1e-5))
+
+
+def make_stress():
+    for name in ("PP16s", "PP16m", "OR16s", "PP24s"):
+        out = {}
+        for tag, kw in STRESS.items():
+            m, spec, sd = build(name, **kw)
+            B, T = 2, spec.tot_ds * 12 + 5
+            mix = synth_mix(spec, B, T)
+            Tp = T + (spec.tot_ds - T % spec.tot_ds)
+            with torch.no_grad():
+                xin = normalized_input(spec, mix, Tp)
+                cond, aux, lat = m.condition_model(xin, x_wav=xin, train=True)
+                sig = torch.tensor([0.3, 1.7])
+                xs = noise_list(11, 1, B, Tp)[0] * sig[:, None, None]
+                out[tag + "_score"] = m.score_model(xs, sig, cond).numpy()
+                out[tag + "_latent"] = lat.numpy()
+                out[tag + "_cond_last"] = cond[-1].numpy()
+            out[tag + "_enh"] = enhance_with_noise(m, mix, noise_list(7, 4, B, Tp), n_steps=4).numpy()
+            out["B"], out["T"] = B, T
+        np.savez_compressed(os.path.join(HERE, f"stress_{name}.npz"), **out)
+        print("stress", name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+def make_configs():
+    # C3 (per-utterance shape): UNIVERSE++ 16 kHz, 64 steps
+    m, spec, sd = build("PP16")
+    T = 64000
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    enh = enhance_with_noise(m, synth_mix(spec, 1, T), noise_list(303, 64, 1, Tp), n_steps=64)
+    np.savez_compressed(os.path.join(HERE, "full_PP16_n64.npz"), enh=enh.numpy().astype(np.float32), T=T)
+    print("C3", enh.shape, float(enh.std()))
+    # C4: original UNIVERSE, 32 steps
+    m, spec, sd = build("OR16")
+    enh = enhance_with_noise(m, synth_mix(spec, 2, T), noise_list(404, 32, 2, Tp), n_steps=32)
+    np.savez_compressed(os.path.join(HERE, "full_OR16_n32.npz"), enh=enh.numpy().astype(np.float32), T=T)
+    print("C4", enh.shape, float(enh.std()))
+    # C5: UNIVERSE++ 24 kHz, variable-length batch of 8 (right zero padding, no mask)
+    m, spec, sd = build("PP24")
+    lens = varlen_lengths(spec.fs)
+    Tm = lens[0]
+    batch = torch.stack([torch.nn.functional.pad(synth_mix(spec, 1, L, seed=1000 + i)[0], (0, Tm - L))
+                         for i, L in enumerate(lens)])
+    Tp = Tm + (spec.tot_ds - Tm % spec.tot_ds)
+    enh = enhance_with_noise(m, batch, noise_list(505, 8, len(lens), Tp), n_steps=8)
+    np.savez_compressed(os.path.join(HERE, "full_PP24_varlen.npz"), lens=np.array(lens),
+                        row0=enh[0, :lens[0]].numpy().astype(np.float32),
+                        row7=enh[7, :lens[7]].numpy().astype(np.float32))
+    print("C5", lens, enh.shape, float(enh.std()))
 
 
 def noise_list(seed, n, B, T):
@@ -74,6 +145,13 @@ def enhance_with_noise(m, mix, noise, **kw):
 
 def main():
     torch.set_num_threads(8)
+    what = set(sys.argv[1:]) or {"base"}
+    if "stress" in what:
+        make_stress()
+    if "configs" in what:
+        make_configs()
+    if "base" not in what:
+        return
     # ---- key schema
     for name, ref in REF_CFG.items():
         m, cfg = R.build_reference_model(ref)

@@ -36,6 +36,70 @@ def synth_mix(spec, B, T, seed=1000):
     return torch.stack(out)
 
 
+def varlen_lengths(fs=24000, n=8, seed=5):
+    """L_i = fs * U(1, 8) s, manual_seed(5), sorted descending (same recipe as make_golden.py)."""
+    u = torch.rand(n, generator=torch.Generator().manual_seed(seed))
+    return sorted((int(fs * (1.0 + 7.0 * float(v))) for v in u), reverse=True)
+
+
+def lora_style_state_dict(sd, rank=4, seed=8):
+    """What LoRA fine-tuning of a reference model leaves in a checkpoint (networks/universe/lora.py:96-120,
+    lora/utils.py:72-89): keys under `model.`, weight-norm removed (plain `.weight`), Conv1d / Linear adapters already
+    merged by `lora.remove()`, ConvTranspose1d adapters still attached (`<p>.conv.weight`, `<p>.lora_weight_a/_b`).
+    Returns (that state dict, the equivalent plain state dict with every adapter merged)."""
+    g = torch.Generator().manual_seed(seed)
+    plain = {}
+    for k, v in sd.items():
+        if k.endswith(".weight_g"):
+            continue
+        if k.endswith(".weight_v"):
+            plain[k[:-2]] = torch._weight_norm(v, sd[k[:-2] + "_g"], 0)  # blocks.py:36-42, as remove_weight_norm leaves it
+        else:
+            plain[k] = v
+    merged = dict(plain)
+    out = {"model." + k: v for k, v in plain.items()}
+    for k, w in plain.items():
+        if not (k.endswith("rate_change_conv.conv.weight") and ".decoder.up_modules." in k):
+            continue
+        if w.shape[0] < rank or w.shape[1] < rank:
+            continue
+        pfx = k[: -len(".weight")]
+        a = 0.05 * torch.randn(w.shape[0], rank, generator=g)
+        b = 0.05 * torch.randn(rank, w.shape[1] * w.shape[2], generator=g)
+        out["model." + pfx + ".conv.weight"] = out.pop("model." + k)
+        if pfx + ".bias" in plain:
+            out["model." + pfx + ".conv.bias"] = out.pop("model." + pfx + ".bias")
+        out["model." + pfx + ".lora_weight_a"] = a
+        out["model." + pfx + ".lora_weight_b"] = b
+        merged[k] = w + (a.double() @ b.double()).view(w.shape).float()
+    return out, merged
+
+
+_OBSERVED = {}
+
+
+def record(name, value):
+    """Log an observed parity figure (dB) of a GPU test to gpurun_out/parity_observed.json: the gates in the tests are
+    set 15 dB below what is observed here, so a regression of that size fails instead of hiding under the 60 dB bar."""
+    import os
+
+    _OBSERVED[name] = round(float(value), 2)
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "parity_observed.json")
+        old = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                old = json.load(f)
+        old.update(_OBSERVED)
+        with open(path, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    return value
+
+
 def unpack_conv(blob, L):
     """Recover the dense [M][Cin][KW] weight, bias and PReLU slope of a packed generic-conv layer."""
     Cin, KW, CK, Mp, M = L["Cin"], L["KW"], L["CK"], L["Mp"], L["M"]

@@ -53,9 +53,58 @@ def test_resample_kernel_matches_survey_probe_shapes():
     k21, w21 = A._sinc_kernel(2, 1, "cpu")
     assert tuple(k12.shape) == (2, 1, 15) and w12 == 7
     assert tuple(k21.shape) == (1, 1, 28) and w21 == 13
-    import restatement as O
-    if hasattr(O, "resample_kernel"):
-        assert torch.allclose(k12, O.resample_kernel(1, 2)[0], atol=1e-7)
+    # the checkpoint-buffer restatement (state_dict.sinc_resample_kernel) is a separately written function
+    from open_universe_amd import state_dict as S
+    assert torch.allclose(k12, S.sinc_resample_kernel(1, 2), atol=1e-7)
+    assert torch.allclose(k21, S.sinc_resample_kernel(2, 1), atol=1e-7)
+
+
+def test_torchaudio_restatements_pinned_by_definition():
+    """torchaudio is absent from the image, so its two pieces of arithmetic on the path (HTK mel filterbank, condition.py
+    :75-81; sinc_interp_hann resampling kernels, alias_free_act.py:21-22) are restated from its documentation.  Pinned
+    here against an independent float64 numpy evaluation of the published formulas and hand-computed values."""
+    import math
+
+    import numpy as np
+
+    from open_universe_amd import state_dict as S
+
+    # ---- HTK filterbank, melscale_fbanks(n_freqs, 0, sr/2, n_mels, sr, norm=None, mel_scale="htk")
+    for n_fft, n_mels in ((640, 80), (960, 128)):
+        n_freqs, sr = n_fft // 2 + 1, 24000
+        fb = S.mel_filterbank(n_freqs, n_mels, sr).double().numpy()
+        mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)
+        imel = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+        pts = imel(np.linspace(mel(0.0), mel(sr / 2), n_mels + 2))
+        freqs = np.linspace(0, sr // 2, n_freqs)
+        ref = np.zeros((n_freqs, n_mels))
+        for m in range(n_mels):
+            lo, ce, hi = pts[m], pts[m + 1], pts[m + 2]
+            up = (freqs - lo) / (ce - lo)
+            down = (hi - freqs) / (hi - ce)
+            ref[:, m] = np.maximum(0.0, np.minimum(up, down))
+        assert np.abs(fb - ref).max() < 2e-5
+        assert fb.shape == (n_freqs, n_mels) and fb.min() >= 0.0 and fb.max() <= 1.0
+        assert np.all(fb[0] == 0.0) and np.abs(fb[-1]).max() < 1e-5  # DC and Nyquist sit on the outer edges
+    # hand-computed: mel(12 kHz) = 2595 log10(1 + 12000/700) = 3266.34...; first centre of the 80-band bank
+    assert abs(2595.0 * math.log10(1.0 + 12000.0 / 700.0) - 3266.3412) < 1e-3
+    c1 = 700.0 * (10.0 ** ((3266.3412 / 81.0) / 2595.0) - 1.0)  # = 25.5 Hz < one 37.5 Hz bin: band 0 has <= 1 bin
+    assert 25.0 < c1 < 26.0 and (S.mel_filterbank(321, 80)[:, 0] > 0).sum() <= 2
+
+    # ---- sinc_interp_hann kernels (lowpass_filter_width 6, rolloff 0.99)
+    for orig, new, width in ((1, 2, 7), (2, 1, 13)):
+        k = S.sinc_resample_kernel(orig, new).double().numpy()
+        base = min(orig, new) * 0.99
+        idx = np.arange(-width, width + orig, dtype=np.float64) / orig
+        ref = []
+        for ph in range(new):
+            t = np.clip((-ph / new + idx) * base, -6.0, 6.0)
+            ref.append(np.sinc(t) * np.cos(t * np.pi / 12.0) ** 2 * base / orig)  # np.sinc(x) = sin(pi x) / (pi x)
+        assert np.abs(k[:, 0, :] - np.stack(ref)).max() < 1e-7
+    k12 = S.sinc_resample_kernel(1, 2)
+    assert abs(float(k12[0, 0, 7]) - 0.99) < 1e-6        # phase 0, t = 0: sinc(0) * hann(0) * base/orig
+    assert abs(float(S.sinc_resample_kernel(2, 1)[0, 0, 13]) - 0.495) < 1e-6
+    assert abs(float(k12[0].sum()) - 1.0) < 0.02 and abs(float(k12[1].sum()) - 1.0) < 0.02  # unit DC gain per phase
 
 
 class _FakeModel:

@@ -1,0 +1,121 @@
+"""GPU (-m gpu): the N > 1 path on ONE GPU.  Two ranks share cuda:0 (RCCL refuses two ranks on one device, so the
+rendezvous is gloo and the weight blob is broadcast on the host): every rank enhances its LPT shard with per-utterance
+generators, and the gathered result is bit-equal to the single-process run.  Same for the CLI under two ranks and for
+`bench.py --gpus 2` started WITHOUT a launcher (it must spawn its own ranks and report n_gpus = 2)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+import yaml
+
+from helpers import get_spec, synth_mix
+from open_universe_amd import state_dict as S
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LENGTHS = [4100, 2900, 3555, 1600, 5200]
+
+
+def _signals(spec):
+    return [synth_mix(spec, 1, L, seed=60 + i)[0] for i, L in enumerate(LENGTHS)]
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from open_universe_amd import UniverseGAN
+    from open_universe_amd import distributed as D
+
+    r, lr, w = D.init()
+    assert dist.get_world_size() == world and dist.get_backend() == "gloo"  # 1 GPU < 2 ranks
+    device = D.local_device(lr)
+    spec = get_spec("PP16m")
+    sd = S.synthetic_state_dict(spec, seed=0) if rank == 0 else None     # only rank 0 has the checkpoint
+    blob = D.broadcast_packed_weights(spec, sd, device)
+    model = UniverseGAN(spec, packed_weights=blob, device=device)
+    outs = D.enhance_sharded(model, _signals(spec), seed=77, n_steps=3)
+    if rank == 0:
+        q.put([o.numpy() for o in outs])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_single_process():
+    from open_universe_amd import UniverseGAN
+    from open_universe_amd import distributed as D
+
+    spec = get_spec("PP16m")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = D.free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model = UniverseGAN(spec, state_dict=S.synthetic_state_dict(spec, seed=0), device="cuda:0")
+    ref = D.enhance_sharded(model, _signals(spec), seed=77, n_steps=3)  # world size 1: every utterance here
+    assert len(got) == len(ref) == len(LENGTHS)
+    for a, b, L in zip(got, ref, LENGTHS):
+        assert a.shape == (L,) and torch.equal(torch.from_numpy(a), b)
+    shards = D.shard_utterances(LENGTHS, 2)
+    assert sorted(shards[0] + shards[1]) == list(range(len(LENGTHS))) and len(shards[0]) == 3  # LPT deal
+
+
+def _run(cmd, timeout=900):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+
+
+def test_cli_under_two_ranks_equals_one_rank(tmp_path):
+    """`bin/enhance.py` sharded over two processes (files dealt LPT, per-file seeds) writes the same files as one
+    process with --per-file-seed."""
+    from open_universe_amd import audio as A
+    from open_universe_amd import config as C
+    from open_universe_amd import distributed as D
+
+    spec = get_spec("PP16s")
+    mdl = tmp_path / "model"
+    mdl.mkdir()
+    with open(mdl / "config.yaml", "w") as f:
+        yaml.safe_dump(C.builtin_config("PP16", **{"score_model.n_channels": 8}), f)
+    torch.save(S.checkpoint_from_state_dict(spec, S.synthetic_state_dict(spec, seed=0), ema_jitter=0.01), mdl / "weights.ckpt")
+    src = tmp_path / "in"
+    (src / "sub").mkdir(parents=True)
+    for i, L in enumerate([3000, 4200, 2100]):
+        A.save(src / ("sub" if i == 1 else "") / f"f{i}.wav", synth_mix(spec, 1, L, seed=90 + i), 16000)
+    base = [sys.executable, "-m", "open_universe_amd.bin.enhance", str(src)]
+    tail = ["--model", str(mdl / "weights.ckpt"), "--n_steps", "3", "--seed", "5"]
+    r1 = _run(base + [str(tmp_path / "out1")] + tail + ["--per-file-seed"])
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", str(D.free_port()), "-m", "open_universe_amd.bin.enhance", str(src),
+               str(tmp_path / "out2")] + tail)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    for rel in ("f0.wav", "sub/f1.wav", "f2.wav"):
+        a, _ = A.load(tmp_path / "out1" / rel)
+        b, _ = A.load(tmp_path / "out2" / rel)
+        assert torch.equal(a, b), rel
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: two ranks, n_gpus = 2 in the JSON line, per-rank device ids."""
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--share-devices", "--steps", "2", "--warmup", "1",
+              "--no-cpu-baseline", "--profile-steps", "1"])
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["devices"] == ["rank0:cuda:0", "rank1:cuda:0"]
+    assert res["config"]["backend"] == "gloo" and res["value"] > 0

@@ -112,8 +112,6 @@ def test_enhance_vs_reference_goldens(name):
         opts["warm"] = dict(n_steps=5, warm_start=2)
         opts["aux"] = dict(n_steps=4, use_aux_signal=True)
     for tag, kw in opts.items():
-        if tag == "keep_rms" and False:
-            continue
         E = kw.get("ensemble") or 1
         nz = noise_list(7, kw["n_steps"], B * E, Tp)
         out = run_enhance(model, mix, nz, **kw)

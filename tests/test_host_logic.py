@@ -123,3 +123,55 @@ def test_shard_utterances_lpt():
     assert sh[0][0] == 5 and sh[1][0] == 0 and sh[2][0] == 2  # longest first, dealt round-robin
     loads = [sum(lengths[i] for i in s) for s in sh]
     assert max(loads) - min(loads) <= max(lengths)
+
+
+def test_lora_and_weight_norm_removed_checkpoints():
+    """state dicts left by LoRA fine-tuning resolve to the same packed blob as the plain merged
+    weights; un-mappable EMA lists are refused instead of silently ignored."""
+    from helpers import lora_style_state_dict
+    from open_universe_amd import _lib
+
+    for name in ("PP16s", "OR16s"):
+        spec = get_spec(name)
+        sd = S.synthetic_state_dict(spec, seed=2)
+        lora_sd, merged = lora_style_state_dict(sd)
+        assert any(k.endswith("lora_weight_b") for k in lora_sd) and all(k.startswith("model.") for k in lora_sd)
+        got = S.inference_state_dict(spec, {"state_dict": lora_sd})
+        assert not any("lora" in k for k in got)
+        blob, _ = _lib.pack_weights(spec, got)
+        ref_blob, _ = _lib.pack_weights(spec, merged)
+        assert torch.equal(blob, ref_blob)
+        if spec.score.use_weight_norm:
+            # weight-norm folded by the packer (in double) vs folded up front in fp32: same weights to fp32 rounding
+            wn_blob, _ = _lib.pack_weights(spec, sd)
+            _, plain = lora_style_state_dict(sd, rank=10 ** 6)  # no adapter fits: plain == folded sd
+            pb, _ = _lib.pack_weights(spec, S.inference_state_dict(spec, plain))
+            assert torch.allclose(pb, wn_blob, rtol=3e-7, atol=1e-9)
+        with pytest.raises(NotImplementedError):
+            S.inference_state_dict(spec, {"state_dict": lora_sd, "ema": {"shadow_params": []}})
+    # alpha != rank scales the adapter
+    a = S.merge_lora({"p.conv.weight": torch.zeros(4, 4, 1), "p.lora_weight_a": torch.ones(4, 2),
+                      "p.lora_weight_b": torch.ones(2, 4)}, lora_alpha=1.0)
+    assert torch.allclose(a["p.weight"], torch.full((4, 4, 1), 1.0))
+
+
+def test_checkpoint_reader_executes_nothing(tmp_path):
+    """`torch.load(weights_only=False)` on a downloaded file is arbitrary code execution.  The reader takes
+    tensors only: a pickle whose `hyper_parameters` would run a callable on load is read without running it."""
+    from open_universe_amd.inference_utils import model_loader as ML
+
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, (f"touch {marker}",))
+
+    spec = get_spec("PP16s")
+    sd = S.synthetic_state_dict(spec, seed=0)
+    torch.save({"state_dict": sd, "hyper_parameters": {"x": Evil()}}, tmp_path / "evil.ckpt")
+    data = ML.read_checkpoint(tmp_path / "evil.ckpt")
+    assert not marker.exists()
+    assert set(data["state_dict"]) == set(sd) and all(torch.equal(data["state_dict"][k], sd[k]) for k in sd)
+    torch.save({"state_dict": sd, "epoch": 3}, tmp_path / "plain.ckpt")
+    assert ML.read_checkpoint(tmp_path / "plain.ckpt")["epoch"] == 3

@@ -96,3 +96,37 @@ def test_enhance_shapes_and_errors():
     # T already a multiple of tot_ds still gets a FULL extra block of padding (universe.py:219-223)
     y = O.enhance(sd, sdict, synth_mix(spec, 1, 1600), n_steps=2, rng=torch.Generator().manual_seed(0))
     assert y.shape[-1] == 1600
+
+
+@pytest.mark.parametrize("name", ["PP16s", "PP16m", "OR16s", "PP24s"])
+def test_oracle_vs_reference_second_seed_and_stress_weights(name):
+    """A second weight draw and the "stress" draw (gain 1.3: larger activations, GRU gates closer to saturation)."""
+    gold = np.load(os.path.join(G, f"stress_{name}.npz"))
+    spec = get_spec(name)
+    sdict = spec.to_dict()
+    B, T = int(gold["B"]), int(gold["T"])
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    pad = Tp - T
+    xin = O.normalize(torch.nn.functional.pad(mix[:, None, :], (pad // 2, pad - pad // 2)), spec.level_db)
+    for tag, kw in (("s1g1", dict(seed=1)), ("s3g13", dict(seed=3, gain=1.3))):
+        sd = S.synthetic_state_dict(spec, **kw)
+        cond, aux, lat = O.conditioner_network(sd, "condition_model", sdict, xin)
+        assert O.si_sdr(torch.from_numpy(gold[tag + "_latent"]), lat) > 100
+        assert O.si_sdr(torch.from_numpy(gold[tag + "_cond_last"]), cond[-1]) > 100
+        sig = torch.tensor([0.3, 1.7])
+        xs = noise_list(11, 1, B, Tp)[0] * sig[:, None, None]
+        assert O.si_sdr(torch.from_numpy(gold[tag + "_score"]), O.score_model(sd, sdict, xs, sig, cond)) > 100
+        out = O.enhance(sd, sdict, mix, n_steps=4, noise=noise_list(7, 4, B, Tp))
+        assert O.si_sdr(torch.from_numpy(gold[tag + "_enh"]), out) > 95, tag
+
+
+def test_oracle_vs_reference_64_step_config():
+    """BASELINE configs[2] per-utterance shape (UNIVERSE++ 16 kHz, 64 steps) against the real reference's output."""
+    gold = np.load(os.path.join(G, "full_PP16_n64.npz"))
+    spec = get_spec("PP16")
+    sd = S.synthetic_state_dict(spec, seed=0)
+    T = int(gold["T"])
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    out = O.enhance(sd, spec.to_dict(), synth_mix(spec, 1, T), n_steps=64, noise=noise_list(303, 64, 1, Tp))
+    assert O.si_sdr(torch.from_numpy(gold["enh"]), out) > 90

@@ -50,3 +50,29 @@ def test_buffers_bit_exact_vs_reference():
     for k, shape, is_p in S.model_schema(spec):
         if not is_p:
             assert torch.equal(sd[k], S.buffer_value(k, shape)), k
+
+
+def test_edm_data_level_and_noisy_ref_match_live_reference():
+    """Config options no shipped yaml sets: `edm.data_level_db` (universe.py:176-178) and
+    `normalization_kwargs.ref = noisy` (utils/norm.py:83-84, only visible with `target`)."""
+    ov = {"score_model.n_channels": 8, "condition_model.n_channels": 8, "edm.data_level_db": -20.0,
+          "normalization_kwargs.ref": "noisy"}
+    m, cfg = R.build_reference_model("default", ov)
+    spec = C.spec_from_config({"model": cfg})
+    assert spec.edm_data_level_db == -20.0 and spec.norm_ref == "noisy"
+    sd = S.synthetic_state_dict(spec, seed=5)
+    m.load_state_dict(sd, strict=False)
+    if m.ema is not None:
+        m.ema.shadow_params = [p.clone().detach() for p in m.model_parameters()]
+    m.eval()
+    mix = synth_mix(spec, 2, spec.tot_ds * 6 + 5)
+    with torch.no_grad():
+        ref = m.enhance(mix, n_steps=3, rng=torch.Generator().manual_seed(3))
+    out = O.enhance(sd, spec.to_dict(), mix, n_steps=3, rng=torch.Generator().manual_seed(3))
+    assert O.si_sdr(ref, out) > 100
+    tgt = 0.5 * mix[:, None, :] + 0.01
+    with torch.no_grad():
+        ref = m.enhance(mix[:, None, :], n_steps=3, target=tgt, fake_score_snr=10.0, rng=torch.Generator().manual_seed(3))
+    out = O.enhance(sd, spec.to_dict(), mix[:, None, :], n_steps=3, target=tgt, fake_score_snr=10.0,
+                    rng=torch.Generator().manual_seed(3))
+    assert torch.equal(ref, out)

@@ -82,8 +82,10 @@ def test_pack_errors(built_lib):
 
 def test_library_exports_every_declared_symbol(built_lib):
     import re, os
-    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "ouniverse.h")).read()
-    declared = set(re.findall(r"\b(ou_[a-z_]+)\s*\(", hdr))
-    assert declared == set(_lib.EXPORTED_SYMBOLS)
-    for s in declared:
+    inc = os.path.join(os.path.dirname(__file__), "..", "include")
+    declared = set(re.findall(r"\b(ou_[a-z_]+)\s*\(", open(os.path.join(inc, "ouniverse.h")).read()))
+    assert declared == set(_lib.EXPORTED_SYMBOLS)  # the drop-in boundary
+    tuning = set(re.findall(r"\b(ou_[a-z_]+)\s*\(", open(os.path.join(inc, "ouniverse_tuning.h")).read()))
+    assert tuning == set(_lib.TUNING_SYMBOLS) and not (tuning & declared)  # measurement entry points kept apart
+    for s in declared | tuning:
         assert hasattr(built_lib, s), s
