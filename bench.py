@@ -7,8 +7,9 @@ Metric (BASELINE.json): real-time factor (+ utterances/s) of UNIVERSE++ 16 kHz, 
   value     = whole-job audio seconds enhanced per wall second (inputs already resident in HBM), measured in the
               PRODUCT DEFAULT mode (`model.check_status = True`: the stream is synchronised and the device status word
               read after every call); the free-running mode (no host sync inside the loop) is reported beside it
-  roofline  = the generic conv kernel (conv_mfma_kernel, the dominant kernel): algorithmic FLOPs of its launches
-              / their device-side durations, against the fp32 MFMA peak (157.3 TFLOP/s) -- plus the HBM view and the
+  roofline  = the dominant conv kernel (the one with the most device time per enhance among conv_direct_kernel,
+              conv_mfma_kernel and conv_chain_kernel): algorithmic FLOPs of its launches / their device-side durations,
+              against the fp32 MFMA peak (157.3 TFLOP/s) -- plus the HBM view, the other conv kernels and the
               whole-score-forward fractions (the unit of work is one score-network forward)
   cpu_baseline = the CPU oracle (plain-PyTorch restatement of the reference path) on this box's host cores
 
@@ -242,9 +243,8 @@ def main():
         torch.cuda.synchronize()
         recs = model.profile_read(max_records=32768)
         model.profile(False)
-        # records: (ms, algorithmic flops, algorithmic bytes, variant); variant < 100: conv_mfma_kernel tile configs,
-        # >= 100: conv_chain_kernel (fused ConvBlock body).  The roofline entry is the generic kernel -- the largest
-        # share of the enhance among the MFMA kernels; the fused kernel is reported beside it.
+        # records: (ms, algorithmic flops, algorithmic bytes, variant); variant < 50: conv_mfma_kernel tile configs,
+        # 50-99: conv_direct_kernel variants, >= 100: conv_chain_kernel (fused ConvBlock body).
         def summarise(rr):
             if not rr:
                 return None
@@ -257,14 +257,24 @@ def main():
                     "algorithmic_GB_per_enhance": by_ / max(1, args.profile_steps) / 1e9,
                     "tflops": fl_ / (ms_ * 1e-3) / 1e12, "gbs": by_ / (ms_ * 1e-3) / 1e9,
                     "algorithmic_bytes_per_launch": by_ / len(rr)}
-        gen = summarise([r for r in recs if r[3] < 100])
-        fused = summarise([r for r in recs if r[3] >= 100])
+        KERNELS = {
+            "direct": "ou::conv_direct_kernel (register-direct split-K fp32-MFMA Conv1d, deep levels)",
+            "lds": "ou::conv_mfma_kernel (LDS-tiled fp32-MFMA implicit-GEMM Conv1d, wide levels / strided convs)",
+            "chain": "ou::conv_chain_kernel (fused ConvBlock body, C = 32 / 64 levels)",
+        }
+        groups = {"direct": summarise([r for r in recs if 50 <= r[3] < 100]),
+                  "lds": summarise([r for r in recs if r[3] < 50]),
+                  "chain": summarise([r for r in recs if r[3] >= 100])}
+        groups = {k: v for k, v in groups.items() if v}
+        dom = max(groups, key=lambda k: groups[k]["ms_per_enhance"])  # the dominant kernel = most time per enhance
+        gen = groups[dom]
+        allconv = summarise(list(recs))
         traffic, traffic_note = None, "not collected (PMC passes are separate rocprofv3 runs)"
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and args.model == "PP16" and args.batch == 1 and args.n_steps == 8:
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic = tj.get("conv_mfma_kernel_bytes_per_launch")
+            traffic = tj.get(dom + "_bytes_per_launch")
             traffic_note = ("STATIC: copied from profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / "
                             "WRITE_SIZE passes of this command on an earlier box), not measured in this run. "
                             + tj.get("note", ""))
@@ -299,7 +309,7 @@ def main():
                       "forward incl. the GRU pass, sigma embedding and FiLM table)",
         }
         roofline = {
-            "kernel": "ou::conv_mfma_kernel (generic fp32-MFMA implicit-GEMM Conv1d, all tile configs)",
+            "kernel": KERNELS[dom],
             "bound": "mfma",
             "achieved": gen["tflops"],
             "peak": FP32_MFMA_PEAK_TFLOPS,
@@ -314,12 +324,13 @@ def main():
             "conv_ms_per_enhance": gen["ms_per_enhance"],
             "hbm_view": {"achieved_GBs": gen["gbs"], "peak_GBs": HBM_PEAK_GBS, "frac": gen["gbs"] / HBM_PEAK_GBS,
                          "algorithmic_GB_per_enhance": gen["algorithmic_GB_per_enhance"]},
-            "fused_block_kernel": None if fused is None else {
-                "kernel": "ou::conv_chain_kernel (fused ConvBlock body)",
-                "achieved": fused["tflops"], "frac": fused["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                "launches": fused["launches"], "avg_launch_us": fused["avg_launch_us"],
-                "ms_per_enhance": fused["ms_per_enhance"],
-                "algorithmic_gflop_per_enhance": fused["algorithmic_gflop_per_enhance"]},
+            "other_conv_kernels": {KERNELS[k]: {
+                "achieved": v["tflops"], "frac": v["tflops"] / FP32_MFMA_PEAK_TFLOPS, "launches": v["launches"],
+                "avg_launch_us": v["avg_launch_us"], "ms_per_enhance": v["ms_per_enhance"],
+                "algorithmic_gflop_per_enhance": v["algorithmic_gflop_per_enhance"]} for k, v in groups.items() if k != dom},
+            "all_conv_kernels": {"achieved": allconv["tflops"], "frac": allconv["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                                 "launches": allconv["launches"], "ms_per_enhance": allconv["ms_per_enhance"],
+                                 "algorithmic_gflop_per_enhance": allconv["algorithmic_gflop_per_enhance"]},
             "score_forward": score_forward,
             "method": f"device-side per-launch timing (first block start .. last block end on the 100 MHz s_memrealtime clock) of every conv launch, profiled pass of {args.profile_steps} "
                       "enhance calls right after the timed region; algorithmic FLOPs/bytes = reference (un-folded) "

@@ -157,6 +157,20 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
 int ou_sampler_step(ou_handle* h, float* x, const float* score, const float* z, float c1, float c2, size_t n,
                     ou_stream_t stream);
 
+/* ---- signal transform of the STFT-domain configurations: CompressedMagSTFT / CompressedMagSTFTPadded
+ * (layers/dyn_range_comp.py:51-225; `model.transform`, universe.py:112-115, 274, 346).  Stateless: no handle.
+ *   transform_type: 0 "none", 1 "exponent" ((1e-7 + |s|)^(e-1) s factor), 2 "log" (log(1 + |s|) sgn(s) factor)
+ *   forward : x (B, T) -> out (B, 2F, n_frames), real parts then imaginary parts as channels, F = n_fft/2 + 1,
+ *             STFT with center=True, zero padding, onesided, `window` (n_fft) on the device; n_frames = ou_transform_frames
+ *   inverse : spec (B, 2F, n_frames) -> y (B, length): expansion, iSTFT (overlap-add / window envelope, torch.istft
+ *             semantics, centre trimmed); scratch = B * n_frames * n_fft floats (device) */
+int ou_transform_frames(int32_t T, int32_t n_fft, int32_t hop);
+int ou_transform_forward(const float* x, int32_t B, int32_t T, const float* window, int32_t n_fft, int32_t hop,
+                         int32_t transform_type, float abs_exponent, float factor, float* out, ou_stream_t stream);
+int ou_transform_inverse(const float* spec, int32_t B, int32_t n_frames, const float* window, int32_t n_fft, int32_t hop,
+                         int32_t transform_type, float abs_exponent, float factor, int32_t length, float* y,
+                         float* scratch, ou_stream_t stream);
+
 /* After the stream has been synchronised: OU_OK, or OU_ESYNC if a device-side timeout flag was raised.  The status
  * word (first 4 bytes of the workspace) is sticky: it stays raised until ou_workspace_init() / this call clears it. */
 int ou_check_device_status(ou_handle* h, void* ws);

@@ -177,6 +177,7 @@ struct Runner {
     a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
     { const char* d = std::getenv("OU_DBG"); a.dbg = d ? std::atoi(d) : 0; }
     { const char* d = std::getenv("OU_XCD_MAP"); a.force_xcd_map = d ? std::atoi(d) : -1; }
+    { const char* d = std::getenv("OU_CONV_DIRECT"); a.direct = d ? std::atoi(d) : 1; }
     a.tstamps = h->tstamps;
     int cfg = -1;
     if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {
@@ -240,8 +241,11 @@ struct Runner {
     return best;
   }
 
+  // `c1_dst` / `v_dst`: caller-provided (persistent) tensors for the conv1 result / the block output, so that
+  // conditioner outputs are produced in place instead of being copied out of the scratch area afterwards
   BlockOut block(const BlockL& Bk, const Tensor& hin, const std::string& nm, const float* film, int film_bs,
-                 const float* input_cond, const float* res, bool need_c1 = false) {
+                 const float* input_cond, const float* res, bool need_c1 = false, const Tensor* c1_dst = nullptr,
+                 const Tensor* v_dst = nullptr) {
     Tensor hu = hin;
     if (Bk.dir == 2) {
       if (Bk.rc.fir_mode == 2) {
@@ -260,9 +264,9 @@ struct Runner {
     Epi e1;
     if (input_cond) { e1.add = input_cond; e1.add_scale = kInvSqrt2; }  // blocks.py:384-386
     e1.film = film; e1.film_bstride = film_bs;                           // blocks.py:393-394
-    Tensor c1 = alloc(nm + ".c1", Bk.c1.Cout, hu.T);
+    Tensor c1 = c1_dst ? *c1_dst : alloc(nm + ".c1", Bk.c1.Cout, hu.T);
     Tensor c2 = alloc(nm + ".c2", Bk.c2.Cout, hu.T);
-    Tensor v = alloc(nm + ".v", Bk.c3.Cout, hu.T);
+    Tensor v = v_dst ? *v_dst : alloc(nm + ".v", Bk.c3.Cout, hu.T);
     // wide, shallow levels: the body runs as one fused launch (conv_chain_kernel), or conv1 + a fused (conv2, conv3)
     const int depth = dry ? 0 : plan_chain(Bk, hu.T);
     auto chain_conv = [&](const ConvL& L) {
@@ -337,7 +341,7 @@ struct Runner {
 
   // one bidirectional GRU layer: projection GEMM + cluster recurrence
   Tensor gru(const GruL& G, const Tensor& in, const std::string& nm, unsigned long long* xchg, unsigned* errw,
-             const float* res, float res_scale) {
+             unsigned* epoch, const float* res, float res_scale) {
     Epi e;
     e.act = false;
     Tensor gx = conv(G.proj, in, nm + ".gx", e);
@@ -345,7 +349,11 @@ struct Runner {
     if (dry || !ok()) return out;
     GruArgs a;
     a.gx = gx.p; a.whh = W(G.whh_off); a.bhn = W(G.bhn_off); a.out = out.p; a.res = res; a.res_scale = res_scale;
-    a.xchg = xchg; a.err = errw; a.B = B; a.T = in.T; a.H = G.H;
+    a.xchg = xchg; a.err = errw; a.epoch = epoch; a.B = B; a.T = in.T; a.H = G.H;
+    // kernel generation: the ring kernel (every wave gathers h straight from L2) is the latency-optimal one but its poll
+    // traffic grows with the number of clusters; batches > 1 stay on the polling-wave kernel (see gru_ring_kernel)
+    { const char* f = std::getenv("OU_GRU_V"); a.version = f ? std::atoi(f) : (B == 1 ? 2 : 1); }
+    { const char* f = std::getenv("OU_GRU_BMAX"); a.force_bmax = f ? std::atoi(f) : 0; }
     if (std::getenv("OU_GRU_TS")) a.tstamps = (long long*)(base + cap - (1u << 20));
     { const char* f = std::getenv("OU_GRU_UPW"); a.force_upw = f ? std::atoi(f) : 0; }
     { const char* f = std::getenv("OU_GRU_BACKOFF"); a.poll_backoff = f ? std::atoi(f) : 0; }
@@ -378,8 +386,8 @@ Persist layout_persist(Runner& r, int T) {
   int ncoef = kMaxSteps > r.B ? kMaxSteps : r.B;
   P.coef = (StepCoef*)r.alloc_raw((size_t)ncoef * 8);
   P.stats = r.alloc_raw((size_t)r.B * 4);
-  P.xchg = (unsigned long long*)r.alloc_raw((size_t)r.B * 4 * (m.OC / 2) * 2);
-  P.xchg2 = (unsigned long long*)r.alloc_raw((size_t)r.B * 4 * (m.OC / 2) * 2);
+  P.xchg = (unsigned long long*)r.alloc_raw(gru_granules(r.B, m.OC / 2) * 2);
+  P.xchg2 = (unsigned long long*)r.alloc_raw(gru_granules(r.B, m.OC / 2) * 2);
   P.mel_scale = r.alloc_raw(r.B);
   P.g = r.alloc_raw((size_t)ncoef * m.film.D);
   P.film = r.alloc_raw((size_t)ncoef * m.film.rows);
@@ -457,19 +465,18 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
   }
   // --- conv_block1 -> 2-layer GRU (+residual) -> conv_block2   condition.py:208-216
   Tensor cb1 = r.block(m.c_cb1, sum, "cond.cb1", nullptr, 0, nullptr, nullptr).v;
-  Tensor g0 = r.gru(m.c_gru0, cb1, "cond.gru0", P.xchg, P.status, nullptr, 1.f);
+  // status block: [0] error word, [2..3] / [4..5] = {tag epoch, finished-block count} of the two GRU exchange areas
+  Tensor g0 = r.gru(m.c_gru0, cb1, "cond.gru0", P.xchg, P.status, P.status + 2, nullptr, 1.f);
   const bool gres = m.cfg.cond.encoder_gru_residual != 0;
-  Tensor g1 = r.gru(m.c_gru1, g0, "cond.gru", P.xchg, P.status, gres ? cb1.p : nullptr, kInvSqrt2);
-  Tensor lat = r.block(m.c_cb2, g1, "cond.cb2", nullptr, 0, nullptr, nullptr).v;
-  if (!r.dry && r.ok())
-    r.chk(hipMemcpyAsync(P.latent.p, lat.p, (size_t)r.B * m.OC * L * 4, hipMemcpyDeviceToDevice, r.st), "latent");
+  Tensor g1 = r.gru(m.c_gru1, g0, "cond.gru", P.xchg, P.status, P.status + 2, gres ? cb1.p : nullptr, kInvSqrt2);
+  Tensor lat = r.block(m.c_cb2, g1, "cond.cb2", nullptr, 0, nullptr, nullptr, false, nullptr, &P.latent).v;
   // --- decoder  condition.py:264-270
   Tensor y = r.block(m.c_decin, lat, "cond.decin", nullptr, 0, nullptr, nullptr).v;
   for (int j = 0; j < m.n_blocks; j++) {
-    auto bo = r.block(m.c_dec[j], y, "cond.dec" + std::to_string(j), nullptr, 0, nullptr, nullptr, true);
+    // condition j = conv1 output of decoder block j (condition.py:264-270); the last block's output is the aux signal
+    auto bo = r.block(m.c_dec[j], y, "cond.dec" + std::to_string(j), nullptr, 0, nullptr, nullptr, true, &P.cond[j],
+                      j == m.n_blocks - 1 ? &P.aux : nullptr);
     y = bo.v;
-    if (!r.dry && r.ok())
-      r.chk(hipMemcpyAsync(P.cond[j].p, bo.c1.p, (size_t)r.B * bo.c1.C * bo.c1.T * 4, hipMemcpyDeviceToDevice, r.st), "cond copy");
     // score.py:208  sc = signal_cond_proj_j(cond_j): independent of x and sigma -> computed once here
     {
       Runner::Epi es;
@@ -477,8 +484,6 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
       r.conv(m.s_sig[j], bo.c1, "cond.sc" + std::to_string(j), es, &P.sc[j]);
     }
   }
-  if (!r.dry && r.ok())
-    r.chk(hipMemcpyAsync(P.aux.p, y.p, (size_t)r.B * m.C0 * T * 4, hipMemcpyDeviceToDevice, r.st), "aux copy");
 }
 
 // ScoreNetwork.forward + EDM wrapper + sampler update for the coefficient rows at `coef`
@@ -508,7 +513,7 @@ ScoreEnc run_score_enc(Runner& r, Persist& P, const float* x, const StepCoef* co
   }
   // GRU bottleneck; when decoder block 0 has no rate change its residual add (blocks.py:374-376) is fused here
   E.fuse_res = m.s_dec[0].dir == 0;
-  E.hg = r.gru(m.s_gru, hcur, "score.gru", P.xchg2, P.status,
+  E.hg = r.gru(m.s_gru, hcur, "score.gru", P.xchg2, P.status, P.status + 4,
                E.fuse_res && !r.dry ? E.residuals[m.n_blocks - 1].p : nullptr, kInvSqrt2);
   return E;
 }
@@ -902,6 +907,31 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
   }
   if (r.ok()) r.chk(launch_post(P.x.p, P.stats, out, B, T_raw, T, pad_left, keep_rms, peak, st), "post");
   return finish(h, r);
+}
+
+int ou_transform_frames(int32_t T, int32_t n_fft, int32_t hop) {
+  if (T < 1 || n_fft < 2 || hop < 1) return OU_EINVAL;
+  return 1 + (T + 2 * (n_fft / 2) - n_fft) / hop;
+}
+
+int ou_transform_forward(const float* x, int32_t B, int32_t T, const float* window, int32_t n_fft, int32_t hop,
+                         int32_t transform_type, float abs_exponent, float factor, float* out, ou_stream_t stream) {
+  if (!x || !window || !out || B < 1) return fail(nullptr, OU_EINVAL, "bad argument");
+  if (transform_type < 0 || transform_type > 2) return fail(nullptr, OU_ENOTIMPL, "transform_type must be none | exponent | log");
+  hipError_t e = launch_stft_forward(x, window, out, B, T, n_fft, hop, transform_type, abs_exponent, factor, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? OU_EINVAL : OU_EHIP, hipGetErrorString(e));
+  return OU_OK;
+}
+
+int ou_transform_inverse(const float* spec, int32_t B, int32_t n_frames, const float* window, int32_t n_fft, int32_t hop,
+                         int32_t transform_type, float abs_exponent, float factor, int32_t length, float* y,
+                         float* scratch, ou_stream_t stream) {
+  if (!spec || !window || !y || !scratch || B < 1) return fail(nullptr, OU_EINVAL, "bad argument");
+  if (transform_type < 0 || transform_type > 2) return fail(nullptr, OU_ENOTIMPL, "transform_type must be none | exponent | log");
+  hipError_t e = launch_stft_inverse(spec, window, scratch, y, B, n_frames, n_fft, hop, transform_type, abs_exponent, factor,
+                                     length, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? OU_EINVAL : OU_EHIP, hipGetErrorString(e));
+  return OU_OK;
 }
 
 int ou_check_device_status(ou_handle* h, void* ws) {

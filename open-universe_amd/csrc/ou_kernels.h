@@ -33,6 +33,7 @@ struct ConvArgs {
   int xcd_map = 0;                     // filled by launch_conv: block -> tile mapping (see the kernel)
   int force_cfg = -1, force_sc = 0;    // tuning overrides (ou_bench_conv)
   int force_xcd_map = -1;              // tuning: 0 / 1 / 2
+  int direct = 1;                      // 0: never use the register-direct split-K kernel (OU_CONV_DIRECT=0)
   int dbg = 0;                         // phase ablation switches (tuning only)
   long long* tstamps = nullptr;        // per-wave phase cycle counts (tuning only)
   unsigned long long* prof = nullptr;  // measurement: {min block start, ~max block end} in s_memrealtime ticks (10 ns)
@@ -82,6 +83,14 @@ hipError_t launch_init_x(const float* noise, const float* base, float sigma, flo
 // into the output conv
 hipError_t launch_sampler_step(float* x, const float* score, const float* z, float c1, float c2, size_t n,
                                hipStream_t st);
+
+// CompressedMagSTFT forward / inverse (layers/dyn_range_comp.py:51-225).  type: 0 none, 1 exponent, 2 log.
+//   forward: x (B, T) -> out (B, 2F, n_frames), F = n_fft/2 + 1, n_frames = 1 + T/hop-ish (center=True)
+//   inverse: spec (B, 2F, n_frames) -> y (B, length); `frames` = scratch of B * n_frames * n_fft floats
+hipError_t launch_stft_forward(const float* x, const float* win, float* out, int B, int T, int n_fft, int hop,
+                               int type, float e, float factor, hipStream_t st);
+hipError_t launch_stft_inverse(const float* spec, const float* win, float* frames, float* y, int B, int n_frames,
+                               int n_fft, int hop, int type, float e, float factor, int length, hipStream_t st);
 
 // mel front-end (condition.py:92-108): power STFT -> mel fb ; esum[b][frame] = sum_mel mel^2
 hipError_t launch_mel(const float* x, const float* win, const float* tw, const float* fb, float* mel, float* esum,
@@ -137,15 +146,20 @@ struct GruArgs {
   float* out = nullptr;
   const float* res = nullptr;
   float res_scale = 1.f;
-  unsigned long long* xchg = nullptr;  // B*2*2*H granules, zeroed by the launcher
+  unsigned long long* xchg = nullptr;  // exchange area: 2B clusters x (2H + 64) granules (see gru_granules())
+  unsigned* epoch = nullptr;           // version 2: {tag epoch, finished-block count} of this exchange area (device)
+  int version = 2;                     // 1: polling-wave kernel (memset per launch), 2: ring kernel (epoch tags)
   unsigned* err = nullptr;             // device status word
   long long* tstamps = nullptr;        // per-wave cycle breakdown (tuning only)
   int B = 1, T = 0, H = 0;
   int poll_backoff = 0;  // tuning: 0/1/2 x ~512 cycles of sleep before the first poll
   int agent_stores = 0;  // 1: publish with agent-scope stores even when the cluster shares one XCD
+  int force_bmax = 0;  // testing: cap the utterances per launch (forces the chunked path at small batches)
   int force_upw = 0;  // tuning: 16 / 32 / 64 hidden units per workgroup (0: chosen from the batch size)
 };
 hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st);
+// 8-byte exchange granules needed for a batch of B sequences with hidden size H (both kernel generations)
+inline size_t gru_granules(int B, int H) { return (size_t)2 * B * (2 * H + 64); }
 
 // Alias-free Snake + Conv1d(C -> 1, k3)  (universe_gan.py:117-126,145-149)
 hipError_t launch_decoupling(const float* aux, const float* alpha_exp, const float* up_k, const float* down_k,

@@ -498,8 +498,19 @@ hipError_t init_conv_kernels() {
   return init_chain_kernels();
 }
 
+static hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out);
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
   if (a.Cin % a.CK || a.CK < 2 || (a.CK & (a.CK - 1)) || a.Mp % 64 || a.Nq <= 0) return hipErrorInvalidValue;
+  // Deep levels (what the 8-wave split-K configs below were built for): the register-direct kernel.  Wide levels
+  // (>= 2 blocks of 64 x 128 per CU without splitting K) stay on the LDS-tiled configs.
+  if (a.direct != 0 && (a.force_cfg < 0 || a.force_cfg >= 100)) {
+    const long wide = (long)((a.M + 63) / 64) * ((a.Nq + 127) / 128) * a.B;
+    const bool deep = (a.Nq <= 16384 && wide < 3L * num_cu) || a.force_cfg >= 100;
+    if (deep) {
+      hipError_t e = launch_conv_direct(a, num_cu, stream, cfg_out);
+      if (e != hipErrorInvalidConfiguration) return e;
+    }
+  }
   int pick = -1;
   for (int i = 0; i < kNumConvCfgs; i++) {
     const ConvCfg& c = kConvCfgs[i];
@@ -569,6 +580,288 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   const int per_wave = pairs / c.WK;
   auto kern = (even && per_wave % 4 == 0) ? c.kern4 : ((even && per_wave % 2 == 0) ? c.kern2 : c.kern_g);
   hipLaunchKernelGGL(kern, grid, dim3(c.NT), smem, stream, aa);
+  return hipGetLastError();
+}
+
+// =========================================================================================================
+// Split-K Conv1d with register-direct operands ("direct" kernel) -- the deep levels (T <= ~8000, K in the hundreds to
+// thousands), stride 1, any tap count, transposed convs as phase GEMMs.
+//   In the 8-wave split-K configurations of conv_mfma_kernel every wave consumes its own K slice of both operands:
+//   nothing staged in LDS is ever shared between waves, LDS is only an asynchronous landing buffer -- paid for with a
+//   DMA -> wait -> ds_read -> wait -> MFMA chain per pipeline stage, ~1.6 LDS reads and a dozen scalar instructions per
+//   MFMA, and a 3 k-cycle prologue of index arithmetic.  Here the MFMA operands are loaded from L2 / L1 straight into
+//   the registers the MFMA reads:
+//     A fragment (tap, channel pair I): lane (m, half) <- w[row(2I + half, tap)][m0 + m]      2 x 128 B, streamed once
+//     B fragment (tap, pair I, tile j): lane (n, half) <- x[2I + half][n0 + 32 j + n + tap - pad]
+//                                       2 x 128 B; the KW shifted reads of a row hit the same L1 lines
+//   as a 4-deep ring of register groups (one group = GP channel pairs x KW taps): the loads of group g + 4 are issued
+//   right after the MFMAs of group g, so ~40-60 loads are in flight per wave at any time; the compiler's own
+//   s_waitcnt placement (loads return in order) turns the ring into counted vmcnt waits with no hand-written
+//   bookkeeping.  Zero padding = per-lane offsets past the buffer bounds (computed once per block).  No LDS, no
+//   barrier and ~1 scalar instruction per load in the main loop; LDS only for the cross-wave reduction of the epilogue
+//   (shared with conv_mfma_kernel's fused epilogue: bias, cond add, FiLM, residual).
+//   Same K order per output element as conv_mfma_kernel's split-K configs (pairs kw, kw + 8, ... tap-inner vs tap-outer
+//   differs) -- results agree to fp32 rounding, not bit-wise.
+// =========================================================================================================
+// One ring slot of the direct kernel: GP channel pairs x KW taps.  Loads and waits are inline asm (see the kernel).
+template <int KW, int TN, int GP>
+__device__ __forceinline__ void direct_issue(float (&av)[GP * KW], float (&bv)[GP * KW * TN], int g, int kw, int Tin,
+                                             int Mp, int CK, int lck, int avo, const int (&bvo)[KW][TN], u32x4 rx,
+                                             u32x4 rw) {
+#pragma unroll
+  for (int q = 0; q < GP; q++) {
+    const int ci = 2 * (kw + 8 * (g * GP + q));                          // first channel of the pair
+    const int xso = ci * Tin * 4;
+    const int wrow = ((ci >> lck) * KW) * CK + (ci & (CK - 1));          // packed row of (ci, tap 0)
+#pragma unroll
+    for (int k = 0; k < KW; k++) {
+      asm volatile("buffer_load_dword %0, %1, %2, %3 offen"
+                   : "=v"(av[q * KW + k]) : "v"(avo), "s"(rw), "s"((wrow + k * CK) * Mp * 4));
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen"
+                     : "=v"(bv[(q * KW + k) * TN + j]) : "v"(bvo[k][j]), "s"(rx), "s"(xso));
+    }
+  }
+}
+// wait until at most OUT groups issued after this slot's are still in flight (loads return in order), then the MFMAs
+template <int NA, int NB, int TN, int OUT>
+__device__ __forceinline__ void direct_mma(float (&av)[NA], float (&bv)[NB], floatx16 (&acc)[TN], float alpha) {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OUT * (NA + NB)));
+#pragma unroll
+  for (int u = 0; u < NA; u++) asm volatile("" : "+v"(av[u]));  // the registers are valid only past the wait
+#pragma unroll
+  for (int u = 0; u < NB; u++) asm volatile("" : "+v"(bv[u]));
+#pragma unroll
+  for (int u = 0; u < NA; u++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const float x = bv[u * TN + j];
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], x >= 0.f ? x : alpha * x, acc[j], 0, 0, 0);
+    }
+}
+
+template <int KW, int TN, int GP>
+__global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
+  constexpr int WK = 8, NT = 512, D = 4, BM = 32, BN = 32 * TN;
+  constexpr int NA = GP * KW, NB = GP * KW * TN;  // A / B dwords per group
+  static_assert(D * (NA + NB) <= 60, "loads in flight must fit vmcnt");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile_m, tile_n;
+  {
+    const int L = blockIdx.x, gx = p.grid_n, gy = p.grid_m;
+    if (p.xcd_map == 1) {
+      const int q = L >> 3, mg = q / gx;
+      tile_n = q - mg * gx;
+      tile_m = mg * 8 + (L & 7);
+    } else if (p.xcd_map == 2) {
+      const int q = L >> 3, ng = q / gy;
+      tile_m = q - ng * gy;
+      tile_n = ng * 8 + (L & 7);
+      if (tile_n >= gx) return;
+    } else {
+      tile_m = L / gx;
+      tile_n = L - tile_m * gx;
+    }
+  }
+  const int n0 = tile_n * BN, m0 = tile_m * BM, b = blockIdx.z;
+  if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+
+  const int lhalf = lane >> 5, l31 = lane & 31;
+  const int CK = p.CK, lck = 31 - __clz(CK);
+  const int Tin = p.Tin, Mp = p.Mp;
+  const float alpha = p.act ? p.alpha_val : 1.0f;
+  // Buffer descriptors as plain SGPR quads (base, bounds, raw-dword format): the loads and their vmcnt waits are
+  // inline asm -- the compiler's own wait-count insertion resolves a register ring carried around a loop to vmcnt(0)
+  // at the loop header, which is exactly the serialisation this kernel exists to avoid.
+  auto desc = [](const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    u32x4 d;
+    d.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    d.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+    d.z = __builtin_amdgcn_readfirstlane(bytes);
+    d.w = 0x00020000u;
+    return d;
+  };
+  const u32x4 rx = desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  const u32x4 rw = desc(p.w, (unsigned)p.Cin * (unsigned)KW * (unsigned)Mp * 4u);
+  // per-lane byte offsets: A = (half row, m); B = (half row, t) per (tap, tile) with the zero padding folded in
+  const int avo = (lhalf * Mp + m0 + l31) * 4;
+  int bvo[KW][TN];
+#pragma unroll
+  for (int k = 0; k < KW; k++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int t = n0 + 32 * j + l31 + k - p.pad;
+      bvo[k][j] = (t >= 0 && t < Tin) ? (lhalf * Tin + t) * 4 : (int)0x80000000;  // past the buffer: reads as 0
+    }
+  const int NG = (p.Cin >> 4) / GP;  // groups per wave (launcher: a multiple of D)
+  float av[D][NA], bv[D][NB];
+  floatx16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+#define OU_ISSUE(g, d) direct_issue<KW, TN, GP>(av[d], bv[d], (g), kw, Tin, Mp, CK, lck, avo, bvo, rx, rw)
+#define OU_MMA(d, out) direct_mma<NA, NB, TN, out>(av[d], bv[d], acc, alpha)
+  OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
+
+  // ---- epilogue operands (bias, cond add, FiLM, residual) of this thread's four output samples (row er, columns
+  // eq .. eq + 3): fetched now, consumed after the main loop.  Rows of any length / alignment (the deep levels have
+  // T = 401, 2005): 16-byte accesses when the row length allows, scalar otherwise.
+  constexpr int EP = BN + 4;
+  constexpr int C4e = BN / 4;  // column quads per row; NT / C4e >= BM rows, so one pass per thread
+  const bool plain_epi = p.up == 1;
+  const bool vec4 = (p.Tout & 3) == 0;
+  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+  int m_hi = m0 + BM - 1;
+  if (m_hi > p.M - 1) m_hi = p.M - 1;
+  const size_t ybase = (size_t)b * p.Cout * p.Tout;
+  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+  const int eq = (tid % C4e) * 4, er = tid / C4e;
+  const bool e_on = plain_epi && er < BM && m0 + er <= m_hi && n0 + eq < p.Nq;
+  const size_t eidx = ybase + (size_t)(m0 + er) * p.Tout + n0 + eq;
+  int e_n = p.Nq - (n0 + eq);  // valid samples of the quad
+  if (e_n > 4) e_n = 4;
+  f32x4 e_ad = {0.f, 0.f, 0.f, 0.f}, e_rs = {0.f, 0.f, 0.f, 0.f};
+  float e_bi = 0.f, e_ga = 1.f, e_be = 0.f;
+  if (e_on) {
+    e_bi = p.bias[m0 + er];
+    if (filmb) { e_ga = filmb[m0 + er]; e_be = filmb[p.Cout + m0 + er]; }
+    if (vec4) {  // Nq is a multiple of 4 here, so the quad is complete
+      if (p.add) e_ad = *reinterpret_cast<const f32x4*>(p.add + eidx);
+      if (p.res) e_rs = *reinterpret_cast<const f32x4*>(p.res + eidx);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (j < e_n) {
+          if (p.add) e_ad[j] = p.add[eidx + j];
+          if (p.res) e_rs[j] = p.res[eidx + j];
+        }
+    }
+  }
+
+  // ---- main loop: rounds of D groups; the last round issues nothing
+  const int NR = NG / D;
+  for (int r = 0; r + 1 < NR; r++) {
+    const int g = r * D;
+    OU_MMA(0, 3); OU_ISSUE(g + 4, 0);
+    OU_MMA(1, 3); OU_ISSUE(g + 5, 1);
+    OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
+    OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
+  }
+  OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
+#undef OU_ISSUE
+#undef OU_MMA
+
+  // ---- accumulators -> LDS (one slab per wave), reduce over the 8 K slices on read, fused epilogue, coalesced store
+  float* Es = smem;  // [WK][BM][EP]
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+      Es[(kw * BM + row) * EP + 32 * j + l31] = acc[j][r];
+    }
+  __syncthreads();
+  const int up = p.up, Cout = p.Cout, Tout = p.Tout;
+  if (plain_epi) {
+    if (e_on) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(&Es[er * EP + eq]);
+#pragma unroll
+      for (int kk = 1; kk < WK; kk++) v += *reinterpret_cast<const f32x4*>(&Es[(kk * BM + er) * EP + eq]);
+      if (p.in_scale) v *= insc;
+      v += e_bi;
+      if (p.add) v = (v + e_ad) * p.add_scale;
+      if (filmb) v = e_ga * v + e_be;
+      if (p.res) v = (v + e_rs) * p.res_scale;
+      if (vec4) {
+        *reinterpret_cast<f32x4*>(p.y + eidx) = v;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (j < e_n) p.y[eidx + j] = v[j];
+      }
+    }
+  } else {
+    // transposed conv (phase GEMM): e -> (co, q, ph) with the output sample t = (n0 + q)*up + ph fastest across threads
+    constexpr int LBN = (BN == 64) ? 6 : 5;
+    const int co_first = up == 1 ? m0 : (int)__umulhi((unsigned)m0, p.magic_up);
+    const int nco = (up == 1 ? m_hi : (int)__umulhi((unsigned)m_hi, p.magic_up)) - co_first + 1;
+    const int total = nco * BN * up;
+    for (int e = tid; e < total; e += NT) {
+      const int rest = up == 1 ? e : (int)__umulhi((unsigned)e, p.magic_up);  // e / up
+      const int ph = e - rest * up;
+      const int q = rest & (BN - 1);
+      const int co = co_first + (rest >> LBN);
+      const int m = co * up + ph;
+      const int t = (n0 + q) * up + ph;
+      if (m < m0 || m > m_hi || (n0 + q) >= p.Nq || t >= Tout) continue;
+      float v = Es[(m - m0) * EP + q];
+#pragma unroll
+      for (int k = 1; k < WK; k++) v += Es[(k * BM + (m - m0)) * EP + q];
+      if (p.in_scale) v *= insc;
+      v += p.bias[co];
+      const size_t idx = ybase + (size_t)co * Tout + t;
+      if (p.add) v = (v + p.add[idx]) * p.add_scale;
+      if (filmb) v = filmb[co] * v + filmb[Cout + co];
+      if (p.res) v = (v + p.res[idx]) * p.res_scale;
+      p.y[idx] = v;
+    }
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+struct DirectCfg {
+  int KW, TN, GP;
+  void (*kern)(ConvArgs);
+};
+static const DirectCfg kDirectCfgs[] = {
+    {1, 1, 4, conv_direct_kernel<1, 1, 4>}, {1, 1, 2, conv_direct_kernel<1, 1, 2>},
+    {1, 2, 4, conv_direct_kernel<1, 2, 4>}, {1, 2, 2, conv_direct_kernel<1, 2, 2>},
+    {3, 1, 2, conv_direct_kernel<3, 1, 2>}, {3, 1, 1, conv_direct_kernel<3, 1, 1>},
+    {3, 2, 1, conv_direct_kernel<3, 2, 1>},
+    {5, 1, 1, conv_direct_kernel<5, 1, 1>}, {5, 2, 1, conv_direct_kernel<5, 2, 1>},
+};
+
+// Launches the direct kernel when the layer fits it; hipErrorInvalidConfiguration = "use conv_mfma_kernel".
+static hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
+  if (a.stride != 1 || a.Cin % 16 || (a.in_scale != nullptr && a.act)) return hipErrorInvalidConfiguration;
+  if (a.KW != 1 && a.KW != 3 && a.KW != 5) return hipErrorInvalidConfiguration;
+  if ((long)a.Cin * a.Tin * 4 >= (1L << 31) || (long)a.Cin * a.KW * a.Mp * 4 >= (1L << 31)) return hipErrorInvalidConfiguration;
+  const int npw = a.Cin / 16;  // channel pairs per wave
+  const long gm = (a.M + 31) / 32;
+  // 64-column tiles when they still give about one block per CU (fewer A loads per MFMA), else 32 columns
+  const long b64 = gm * ((a.Nq + 63) / 64) * a.B;
+  int tn = (a.force_cfg == 105 || (a.force_cfg < 0 && b64 >= (long)num_cu * 15 / 16)) ? 2 : 1;
+  if (a.force_cfg == 106) tn = 1;
+  const DirectCfg* pick = nullptr;
+  for (const DirectCfg& c : kDirectCfgs) {
+    if (c.KW != a.KW || c.TN != tn) continue;
+    if (npw % (c.GP * 4)) continue;
+    pick = &c;
+    break;
+  }
+  if (!pick) return hipErrorInvalidConfiguration;
+  ConvArgs aa = a;
+  const int BN = 32 * tn;
+  aa.magic_up = a.up == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.up) + 1u;
+  aa.grid_n = (a.Nq + BN - 1) / BN;
+  aa.grid_m = (int)gm;
+  {
+    const double xb = (double)a.Cin * a.Nq, wb = (double)a.M * a.Cin * a.KW;
+    aa.xcd_map = 0;
+    if (aa.grid_m % 8 == 0 && wb >= xb) aa.xcd_map = 1;
+    else if (aa.grid_n >= 8) aa.xcd_map = 2;
+    if (a.force_xcd_map >= 0) aa.xcd_map = a.force_xcd_map;
+    if (aa.xcd_map == 1 && aa.grid_m % 8) aa.xcd_map = 0;
+  }
+  const int gn_pad = aa.xcd_map == 2 ? (aa.grid_n + 7) / 8 * 8 : aa.grid_n;
+  const size_t smem = (size_t)8 * 32 * (BN + 4) * 4;
+  if (cfg_out) *cfg_out = 50 + 10 * tn + pick->GP;  // 5x / 6x: direct kernel variants (profile records)
+  hipLaunchKernelGGL(pick->kern, dim3(gn_pad * aa.grid_m, 1, a.B), dim3(512), smem, stream, aa);
   return hipGetLastError();
 }
 
@@ -1261,6 +1554,161 @@ hipError_t launch_sampler_step(float* x, const float* score, const float* z, flo
   return hipGetLastError();
 }
 
+// ---- CompressedMagSTFT (layers/dyn_range_comp.py:51-225) --------------------------------------------------------
+// Signal pre-conditioning transform of the non-shipped STFT-domain configs: STFT (center=True, zero padding,
+// onesided) -> magnitude compression -> (real | imag) stacked as channels; and its inverse (expansion -> iSTFT =
+// windowed overlap-add / window envelope, torch.istft semantics).  n_fft is arbitrary (510 in the reference's
+// experiments): direct DFT with an exact (k*n mod N) twiddle table in LDS, one block per (frame, batch).
+__device__ __forceinline__ void stft_twiddles(float* tc, float* ts, int n_fft) {
+  for (int n = threadIdx.x; n < n_fft; n += blockDim.x) {
+    float sn, cs;
+    sincospif(2.0f * (float)n / (float)n_fft, &sn, &cs);
+    tc[n] = cs;
+    ts[n] = sn;
+  }
+}
+// (re, im) -> compressed (re, im).  dyn_range_comp.py:117-131
+__device__ __forceinline__ void spec_compress(float& re, float& im, int type, float e, float factor) {
+  if (type == 1) {        // "exponent": (1e-7 + |s|)^(e - 1) * s * factor
+    if (e != 1.0f) {
+      const float g = powf(1e-7f + sqrtf(re * re + im * im), e - 1.0f);
+      re *= g; im *= g;
+    }
+    re *= factor; im *= factor;
+  } else if (type == 2) {  // "log": log(1 + |s|) * sgn(s) * factor
+    const float mag = sqrtf(re * re + im * im);
+    const float g = mag > 0.f ? log1pf(mag) / mag : 0.f;
+    re *= g * factor; im *= g * factor;
+  }
+}
+// dyn_range_comp.py:133-145
+__device__ __forceinline__ void spec_expand(float& re, float& im, int type, float e, float factor) {
+  if (type == 1) {
+    re /= factor; im /= factor;
+    if (e != 1.0f) {
+      const float g = powf(1e-7f + sqrtf(re * re + im * im), 1.0f / e - 1.0f);
+      re *= g; im *= g;
+    }
+  } else if (type == 2) {
+    re /= factor; im /= factor;
+    const float mag = sqrtf(re * re + im * im);
+    const float g = mag > 0.f ? expm1f(mag) / mag : 0.f;
+    re *= g; im *= g;
+  }
+}
+
+__global__ __launch_bounds__(256) void stft_forward_kernel(const float* __restrict__ x, const float* __restrict__ win,
+                                                           float* __restrict__ out, int T, int n_fft, int hop, int F,
+                                                           int n_frames, int type, float e, float factor) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sx = sm;            // [n_fft] windowed frame
+  float* tc = sx + n_fft;    // [n_fft]
+  float* ts = tc + n_fft;    // [n_fft]
+  const int f = blockIdx.x, b = blockIdx.y;
+  const int pad = n_fft / 2;  // center=True, pad_mode="constant"
+  for (int n = threadIdx.x; n < n_fft; n += blockDim.x) {
+    const int t = f * hop + n - pad;
+    sx[n] = ((t >= 0 && t < T) ? x[(size_t)b * T + t] : 0.f) * win[n];
+  }
+  stft_twiddles(tc, ts, n_fft);
+  __syncthreads();
+  for (int k = threadIdx.x; k < F; k += blockDim.x) {
+    float re = 0.f, im = 0.f;
+    int idx = 0;
+    for (int n = 0; n < n_fft; n++) {
+      const float v = sx[n];
+      re = fmaf(v, tc[idx], re);
+      im = fmaf(-v, ts[idx], im);
+      idx += k;
+      if (idx >= n_fft) idx -= n_fft;
+    }
+    spec_compress(re, im, type, e, factor);
+    out[((size_t)b * 2 * F + k) * n_frames + f] = re;        // (batch, real/imag, freq, frame), dyn_range_comp.py:91-95
+    out[((size_t)b * 2 * F + F + k) * n_frames + f] = im;
+  }
+}
+
+// expansion + inverse real DFT + synthesis window of one frame -> frames[b][f][n]
+__global__ __launch_bounds__(256) void stft_inverse_frames_kernel(const float* __restrict__ spec,
+                                                                  const float* __restrict__ win,
+                                                                  float* __restrict__ frames, int n_fft, int F,
+                                                                  int n_frames, int type, float e, float factor) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sr = sm;          // [F]
+  float* si = sr + F;      // [F]
+  float* tc = si + F;      // [n_fft]
+  float* ts = tc + n_fft;  // [n_fft]
+  const int f = blockIdx.x, b = blockIdx.y;
+  for (int k = threadIdx.x; k < F; k += blockDim.x) {
+    float re = spec[((size_t)b * 2 * F + k) * n_frames + f];
+    float im = spec[((size_t)b * 2 * F + F + k) * n_frames + f];
+    spec_expand(re, im, type, e, factor);
+    sr[k] = re;
+    si[k] = im;
+  }
+  stft_twiddles(tc, ts, n_fft);
+  __syncthreads();
+  const bool even = (n_fft & 1) == 0;
+  const int kmax = even ? F - 1 : F;  // bins 1 .. kmax-1 appear twice (conjugate symmetry)
+  const float inv_n = 1.0f / (float)n_fft;
+  for (int n = threadIdx.x; n < n_fft; n += blockDim.x) {
+    float acc = sr[0];  // the imaginary parts of the DC and Nyquist bins are ignored (c2r transform)
+    if (even) acc += (n & 1) ? -sr[F - 1] : sr[F - 1];
+    float s2 = 0.f;
+    int idx = n;  // (k * n) mod N for k = 1, 2, ...
+    for (int k = 1; k < kmax; k++) {
+      s2 = fmaf(sr[k], tc[idx], s2);
+      s2 = fmaf(-si[k], ts[idx], s2);
+      idx += n;
+      if (idx >= n_fft) idx -= n_fft;
+    }
+    frames[((size_t)b * n_frames + f) * n_fft + n] = (acc + 2.0f * s2) * inv_n * win[n];
+  }
+}
+// overlap-add / window envelope, trimmed like torch.istft(center=True, length=...)
+__global__ __launch_bounds__(256) void stft_overlap_add_kernel(const float* __restrict__ frames,
+                                                               const float* __restrict__ win, float* __restrict__ y,
+                                                               int n_fft, int hop, int n_frames, int length) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= length) return;
+  const int tp = t + n_fft / 2;  // position in the centred (padded) signal
+  int f_hi = tp / hop;
+  if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+  int f_lo = (tp - n_fft + hop) / hop;  // ceil((tp - n_fft + 1) / hop)
+  if (tp - n_fft + 1 <= 0) f_lo = 0;
+  float acc = 0.f, env = 0.f;
+  for (int f = f_lo; f <= f_hi; f++) {
+    const int n = tp - f * hop;
+    if (n < 0 || n >= n_fft) continue;
+    acc += frames[((size_t)b * n_frames + f) * n_fft + n];
+    const float w = win[n];
+    env = fmaf(w, w, env);
+  }
+  y[(size_t)b * length + t] = env > 1e-11f ? acc / env : 0.f;
+}
+
+hipError_t launch_stft_forward(const float* x, const float* win, float* out, int B, int T, int n_fft, int hop,
+                               int type, float e, float factor, hipStream_t st) {
+  if (n_fft < 2 || n_fft > 8192 || hop < 1 || T < 1) return hipErrorInvalidValue;
+  const int F = n_fft / 2 + 1, n_frames = 1 + (T + 2 * (n_fft / 2) - n_fft) / hop;
+  hipLaunchKernelGGL(stft_forward_kernel, dim3(n_frames, B), dim3(256), (size_t)3 * n_fft * 4, st, x, win, out, T, n_fft,
+                     hop, F, n_frames, type, e, factor);
+  return hipGetLastError();
+}
+hipError_t launch_stft_inverse(const float* spec, const float* win, float* frames, float* y, int B, int n_frames,
+                               int n_fft, int hop, int type, float e, float factor, int length, hipStream_t st) {
+  if (n_fft < 2 || n_fft > 8192 || hop < 1 || n_frames < 1 || length < 1) return hipErrorInvalidValue;
+  const int F = n_fft / 2 + 1;
+  hipLaunchKernelGGL(stft_inverse_frames_kernel, dim3(n_frames, B), dim3(256), (size_t)(2 * F + 2 * n_fft) * 4, st, spec,
+                     win, frames, n_fft, F, n_frames, type, e, factor);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(stft_overlap_add_kernel, dim3((length + 255) / 256, B), dim3(256), 0, st, frames, win, y, n_fft, hop,
+                     n_frames, length);
+  return hipGetLastError();
+}
+
 // ---- mel front-end -------------------------------------------------------------------------------------------
 // One block per (frame, batch).  n_fft is 640 / 960 (not a power of two): direct DFT with an exact
 // (k*n mod N) twiddle table in LDS; 0.33 GFLOP per utterance, once per enhance call.
@@ -1649,6 +2097,273 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// GRU recurrence, second generation ("ring"): same cluster decomposition, different exchange.
+//   * every WAVE gathers the h columns its lanes need straight from L2 into registers (volatile agent-scope 16-byte
+//     buffer loads = two {value, tag} granules each): no polling wave, no LDS hop, no workgroup barrier -- the four
+//     waves of a workgroup run unsynchronised, each ordered only by the tags it reads;
+//   * tags never repeat: tag(step s of this launch) = epoch + s with a device-side epoch that the last block of a
+//     launch advances by T + 1 (graph-replay safe, no per-launch memset).  Stale granules therefore always carry
+//     SMALLER tags, so "all tags arrived" is one v_min3 tree + one compare;
+//   * granule = {h, tag}: the matvec multiplies a (W_r, W_z) row pair by the granule's low half with one v_pk_fma_f32
+//     (op_sel_hi = 0 on the h operand) and W_n by a scalar FMA -- the loaded registers are the FMA operands, no
+//     repacking;
+//   * the one-time XCD rendezvous uses the cluster's own rendezvous granules with tag = epoch.
+// Double buffering by step parity is enough without barriers: h_{s+2} overwrites h_s only after its writer has read all of
+// h_{s+1}, and every wave publishes its part of h_{s+1} only after it has finished reading h_s.
+// ---------------------------------------------------------------------------------------------------------
+// s_waitcnt vmcnt(0) that the register allocator sees as the producer of the gathered registers (the loads themselves are
+// inline asm, invisible to the compiler's own wait-count insertion)
+template <int N>
+__device__ __forceinline__ void gather_wait(u32x4 (&hv)[N]) {
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]));
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]));
+  else if constexpr (N == 8)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]),
+                 "+v"(hv[6]), "+v"(hv[7]));
+  else if constexpr (N == 12)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]),
+                 "+v"(hv[6]), "+v"(hv[7]), "+v"(hv[8]), "+v"(hv[9]), "+v"(hv[10]), "+v"(hv[11]));
+  else if constexpr (N == 16)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]),
+                 "+v"(hv[6]), "+v"(hv[7]), "+v"(hv[8]), "+v"(hv[9]), "+v"(hv[10]), "+v"(hv[11]), "+v"(hv[12]),
+                 "+v"(hv[13]), "+v"(hv[14]), "+v"(hv[15]));
+  else static_assert(N == 2, "gather_wait: unsupported register count");
+}
+
+constexpr unsigned GRU_EPOCH_WRAP = 0x7F000000u;  // past this the last block of a launch clears the exchange area
+
+template <int HB, int UPW>
+__global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters) {
+  constexpr int H = 64 * HB, NT = 256, LPU = NT / UPW, NC = H / LPU, NI = NC / 4, NWG = H / UPW;
+  constexpr int CSTRIDE = 2 * H + 64;  // granules per cluster: two parity buffers + rendezvous slots
+  static_assert(LPU == 8 || LPU == 16, "8 or 16 lanes per hidden unit");
+  static_assert(NC % 4 == 0 && NWG > 1 && NWG <= 64, "column blocks / rendezvous slots");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int cluster = xcd + 8 * (slot / NWG);
+  const int g = slot % NWG;
+  // tags of this launch: epoch (rendezvous), epoch + s (h after s steps).  The stored counter starts at 0 in a freshly
+  // cleared workspace, whose granules carry tag 0 -> + 1
+  const unsigned epoch = __hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const int T = p.T;
+  const bool ts_on = p.tstamps != nullptr;
+  long long c_poll = 0, c_comp = 0;
+  if (cluster < nclusters) {
+    const int dir = cluster & 1, b = cluster >> 1;
+    const int ul = tid / LPU, cg = tid % LPU;
+    const int unit = g * UPW + ul;
+
+    // this lane's weights: (W_r, W_z) row pairs and W_n for columns 4cg + 4 LPU i + {0..3}
+    f32x2 wrz[NC];
+    float wn[NC];
+    {
+      const float* wd = p.whh + (size_t)dir * 3 * H * H + (size_t)unit * H + cg * 4;
+#pragma unroll
+      for (int i = 0; i < NI; i++) {
+        const float4 vr = *reinterpret_cast<const float4*>(wd + 4 * LPU * i);
+        const float4 vz = *reinterpret_cast<const float4*>(wd + (size_t)H * H + 4 * LPU * i);
+        const float4 vn = *reinterpret_cast<const float4*>(wd + (size_t)2 * H * H + 4 * LPU * i);
+        wrz[4 * i + 0] = f32x2{vr.x, vz.x}; wrz[4 * i + 1] = f32x2{vr.y, vz.y};
+        wrz[4 * i + 2] = f32x2{vr.z, vz.z}; wrz[4 * i + 3] = f32x2{vr.w, vz.w};
+        wn[4 * i + 0] = vn.x; wn[4 * i + 1] = vn.y; wn[4 * i + 2] = vn.z; wn[4 * i + 3] = vn.w;
+      }
+    }
+    const bool fin = cg == 0;
+    const float bhn = p.bhn[dir * H + unit];
+    const float* gxb = p.gx + ((size_t)b * 6 * H + (size_t)dir * 3 * H) * T;
+    const size_t orow = ((size_t)b * 2 * H + (size_t)dir * H + unit) * T;
+    unsigned long long* xq = p.xchg + (size_t)cluster * CSTRIDE;
+    const bool has_res = p.res != nullptr;
+
+    // one-time rendezvous (also proves that every member of the cluster is resident): member g posts {xcc, epoch}
+    bool plain = false;
+    unsigned xcc;
+    {
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      xcc &= 0xFu;
+      if (tid == 0)
+        __hip_atomic_store(xq + 2 * H + g, ((unsigned long long)epoch << 32) | xcc, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      bool same = true, fail = false;
+      if (lane < NWG) {
+        unsigned spins = 0;
+        unsigned long long v;
+        while (true) {
+          v = __hip_atomic_load(xq + 2 * H + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)(v >> 32) == epoch) break;
+          if (++spins > GRU_SPIN_LIMIT) { fail = true; break; }
+        }
+        same = !fail && (unsigned)v == xcc;
+      }
+      plain = __builtin_amdgcn_ballot_w64(!same) == 0ull && !p.agent_stores;
+      if (fail) { atomicOr(p.err, 2u); p.err[8] = (unsigned)cluster; p.err[9] = (unsigned)g; p.err[10] = epoch; }
+    }
+
+    // Input projections (gx rows r, z, n of this wave's units) and the residual row are staged through a wave-private
+    // LDS ring in chunks of CH time steps: the global loads of chunk c + 2 are issued at the start of chunk c (coalesced
+    // along time, a whole chunk of steps to land) and parked in registers, moved to LDS one chunk later and read from
+    // there by the gate lanes -- the per-step loop touches global memory only for the exchange and the output store.
+    constexpr int CH = 32, UW = UPW / 4;           // steps per chunk, units per wave
+    constexpr int ROWS = 4 * UW, PER = ROWS * CH / 64;  // staged rows per wave (unit x {r, z, n, res}), floats per lane
+    static_assert(ROWS * CH % 64 == 0 && 64 % ROWS == 0, "staging map");
+    constexpr int LPR = 64 / ROWS;                 // lanes per staged row
+    __shared__ float stage[4][2][ROWS][CH];
+    const int wv = tid >> 6;
+    const int srow = lane / LPR, sq = lane % LPR;  // this lane loads steps sq * PER .. + PER of staged row srow
+    const int s_unit = g * UPW + wv * UW + (srow >> 2), s_kind = srow & 3;
+    const float* s_src = s_kind == 3 ? (has_res ? p.res + ((size_t)b * 2 * H + (size_t)dir * H + s_unit) * T : nullptr)
+                                     : gxb + (size_t)(s_kind * H + s_unit) * T;
+    float park[PER];
+    auto fetch_chunk = [&](int c) {  // -> park[]: steps c*CH + sq*PER + j
+#pragma unroll
+      for (int j = 0; j < PER; j++) {
+        const int sidx = c * CH + sq * PER + j;
+        const int tt = dir ? T - 1 - sidx : sidx;
+        park[j] = (s_src && sidx < T) ? s_src[tt] : 0.f;
+      }
+    };
+    auto park_to_lds = [&](int c) {
+#pragma unroll
+      for (int j = 0; j < PER; j++) stage[wv][c & 1][srow][sq * PER + j] = park[j];
+    };
+    fetch_chunk(0);
+    park_to_lds(0);
+    fetch_chunk(1);
+    const int ulw = ul - wv * UW;                  // this lane's unit within its wave
+    float hprev = 0.f;
+    int t = dir ? T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // weights landed: no vmcnt(0) inside the loop on their account
+
+    for (int step = 0; step < T; step++, t += dt) {
+      long long q0 = 0, q1 = 0;
+      if (ts_on) q0 = __builtin_readcyclecounter();
+      const int cidx = step / CH, soff = step % CH;
+      if (soff == 0 && step > 0) {  // chunk boundary: park -> LDS (chunk cidx), start fetching chunk cidx + 1
+        park_to_lds(cidx);
+        fetch_chunk(cidx + 1);
+      }
+      float xr = 0.f, xz = 0.f, xn = 0.f, rs = 0.f;
+      if (fin) {
+        const float* sp = &stage[wv][cidx & 1][ulw * 4][soff];
+        xr = sp[0]; xz = sp[CH]; xn = sp[2 * CH]; rs = sp[3 * CH];
+      }
+      // ---- h_step: zero at step 0, else gathered from the parity buffer (all granules must carry tag epoch + step)
+      u32x4 hv[NC / 2];
+      if (step == 0) {
+#pragma unroll
+        for (int k = 0; k < NC / 2; k++) hv[k] = u32x4{0u, 0u, 0u, 0u};
+      } else {
+        const unsigned want = epoch + (unsigned)step;
+        const unsigned long long* src = xq + (size_t)(step & 1) * H + cg * 4;
+        unsigned spins = 0;
+        while (true) {
+#pragma unroll
+          for (int i = 0; i < NI; i++) {
+            // agent-scope (sc1) 16-byte loads = two granules each; asm: the compiler must neither cache nor widen the scope
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1"
+                         : "=v"(hv[2 * i]) : "v"(src), "n"(4 * LPU * i * 8) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1"
+                         : "=v"(hv[2 * i + 1]) : "v"(src), "n"(4 * LPU * i * 8 + 16) : "memory");
+          }
+          gather_wait(hv);
+          unsigned m = hv[0].y < hv[0].w ? hv[0].y : hv[0].w;
+#pragma unroll
+          for (int k = 1; k < NC / 2; k++) {
+            const unsigned a = hv[k].y < hv[k].w ? hv[k].y : hv[k].w;
+            m = a < m ? a : m;
+          }
+          if (m == want) break;
+          // every wave polls all H granules: 32 line requests per wave and round.  Fine for the few clusters of a batch-1
+          // call (~10-25 % of the L2 request rate); with dozens of clusters the polls alone saturate the L2 channels and
+          // progress collapses (measured: OR16, B = 16 -> multi-second stalls), which is why launch_gru() keeps larger
+          // batches on the polling-wave kernel.  Back off if a wait gets long anyway.
+          ++spins;
+          if ((__builtin_amdgcn_readfirstlane(spins) & 63u) == 0u) __builtin_amdgcn_s_sleep(4);  // scalar branch: s_sleep ignores EXEC
+          if (spins > GRU_SPIN_LIMIT) {
+            atomicOr(p.err, 4u);  // diagnostics: who waited for what
+            p.err[12] = (unsigned)cluster; p.err[13] = (unsigned)g; p.err[14] = (unsigned)step; p.err[15] = m; p.err[16] = want;
+            p.err[17] = xcc; p.err[18] = plain ? 1u : 0u; p.err[19] = (unsigned)bid;
+            step = T;
+            break;
+          }
+        }
+        if (step >= T) break;
+      }
+      if (ts_on) q1 = __builtin_readcyclecounter();
+      // ---- matvec: (r, z) as packed row pairs against the granule's value half, n as scalar FMAs
+      f32x2 arz0 = {0.f, 0.f}, arz1 = {0.f, 0.f};
+      float an0 = 0.f, an1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < NC / 2; k++) {
+        const float h0 = __uint_as_float(hv[k].x), h1 = __uint_as_float(hv[k].z);
+        arz0 = __builtin_elementwise_fma(wrz[2 * k], f32x2{h0, h0}, arz0);
+        arz1 = __builtin_elementwise_fma(wrz[2 * k + 1], f32x2{h1, h1}, arz1);
+        an0 = fmaf(wn[2 * k], h0, an0);
+        an1 = fmaf(wn[2 * k + 1], h1, an1);
+      }
+      float hs[3] = {arz0.x + arz1.x, arz0.y + arz1.y, an0 + an1};
+#pragma unroll
+      for (int gt = 0; gt < 3; gt++) hs[gt] = LPU == 8 ? row8_sum(hs[gt]) : row16_sum(hs[gt]);
+
+      if (fin) {
+        const float r = sigmoidf_(xr + hs[0]);
+        const float z = sigmoidf_(xz + hs[1]);
+        const float n = tanhf_(xn + r * (hs[2] + bhn));
+        const float hnew = (hprev - n) * z + n;
+        hprev = hnew;
+        {  // publish first: everybody is waiting on this
+          const unsigned long long gran =
+              ((unsigned long long)(epoch + (unsigned)step + 1u) << 32) | (unsigned)__float_as_int(hnew);
+          unsigned long long* dst = xq + (size_t)((step + 1) & 1) * H + unit;
+          if (plain) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
+          else __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        p.out[orow + t] = has_res ? (hnew + rs) * p.res_scale : hnew;
+      }
+      if (ts_on) { c_poll += q1 - q0; c_comp += __builtin_readcyclecounter() - q1; }
+    }
+    if (ts_on && lane == 0) {
+      long long* o = p.tstamps + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 8;
+      o[0] = c_comp; o[1] = c_poll; o[2] = 0; o[3] = T; o[4] = 0; o[5] = 0; o[6] = 0;
+    }
+  }
+  // ---- epoch hand-over: the last block to finish advances the epoch for the next launch on this exchange area
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    const unsigned done = atomicAdd(p.epoch + 1, 1u);
+    if (done == gridDim.x - 1) {
+      p.epoch[1] = 0u;
+      unsigned next = epoch + (unsigned)T;  // stored counter = last tag used
+      if (next >= GRU_EPOCH_WRAP) {  // tags must stay monotonic: clear the area and restart (every block is done)
+        const size_t n = (size_t)nclusters * CSTRIDE;
+        for (size_t i = 0; i < n; i++) p.xchg[i] = 0ull;
+        next = 0u;
+      }
+      __threadfence();
+      __hip_atomic_store(p.epoch, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int HB>
+static hipError_t launch_gru_ring(const GruArgs& c, int upw, int nclusters, hipStream_t st) {
+  constexpr int H = 64 * HB;
+  const int nwg = H / upw;
+  dim3 grid(8 * nwg * ((nclusters + 7) / 8));
+  if constexpr (HB <= 4) {
+    if (upw == 32) {
+      hipLaunchKernelGGL((gru_ring_kernel<HB, 32>), grid, dim3(256), 0, st, c, nclusters);
+      return hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((gru_ring_kernel<HB, 16>), grid, dim3(256), 0, st, c, nclusters);
+  return hipGetLastError();
+}
+
 template <int HB>
 static hipError_t launch_gru_variant(const GruArgs& c, int upw, int nclusters, hipStream_t st) {
   constexpr int H = 64 * HB;
@@ -1672,8 +2387,11 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
   if (a.force_upw) upw = a.force_upw;
   else if (a.H % 16 == 0 && batch_cap(16) >= a.B) upw = 16;
   else if (a.H % 32 == 0 && batch_cap(32) >= a.B) upw = 32;
+  // the ring kernel runs 256-thread workgroups of 16 units (32 on request, H <= 256)
+  if (a.version == 2) upw = (a.force_upw == 32 && a.H <= 256) ? 32 : 16;
   const int nwg = a.H / upw;
-  const int bmax = batch_cap(upw);
+  int bmax = batch_cap(upw);
+  if (a.force_bmax > 0 && a.force_bmax < bmax) bmax = a.force_bmax;
   if (bmax < 1) return hipErrorInvalidConfiguration;
   for (int b0 = 0; b0 < a.B; b0 += bmax) {
     GruArgs c = a;
@@ -1681,6 +2399,19 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
     c.gx = a.gx + (size_t)b0 * 6 * a.H * a.T;
     c.out = a.out + (size_t)b0 * 2 * a.H * a.T;
     if (a.res) c.res = a.res + (size_t)b0 * 2 * a.H * a.T;
+    if (a.version == 2) {
+      if (!a.epoch) return hipErrorInvalidValue;
+      hipError_t e;
+      switch (HB) {
+        case 1: e = launch_gru_ring<1>(c, upw, 2 * c.B, st); break;
+        case 2: e = launch_gru_ring<2>(c, upw, 2 * c.B, st); break;
+        case 4: e = launch_gru_ring<4>(c, upw, 2 * c.B, st); break;
+        case 6: e = launch_gru_ring<6>(c, upw, 2 * c.B, st); break;
+        default: return hipErrorInvalidConfiguration;
+      }
+      if (e != hipSuccess) return e;
+      continue;
+    }
     if (nwg > 1) {
       hipError_t e = hipMemsetAsync(c.xchg, 0, (size_t)c.B * 4 * a.H * sizeof(unsigned long long), st);
       if (e != hipSuccess) return e;

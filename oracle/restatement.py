@@ -526,6 +526,51 @@ def enhance(sd, spec, mix, n_steps=None, epsilon=None, target=None, fake_score_s
     return x
 
 
+# --------------------------------------------------------------------------------------------------
+# layers/dyn_range_comp.py (signal transforms; no shipped config uses them)
+# --------------------------------------------------------------------------------------------------
+def compressed_mag_stft(x, n_fft, hop_length, window, transform_type, abs_exponent, factor, inv=False, length=None,
+                        pad_block=None):
+    """dyn_range_comp.py:51-225 CompressedMagSTFT / CompressedMagSTFTPadded (pad_block is not None -> Padded, whose
+    `_stft` applies `_pad` twice, :199-201).  window: the n_fft-tap analysis / synthesis window."""
+    padded = pad_block is not None
+
+    def _pad(sig):  # :182-196
+        if pad_block:
+            r = sig.shape[-1] % pad_block
+            if r > 0:
+                sig = F.pad(sig, (0, pad_block - r))
+        return sig[..., :-hop_length]
+
+    if not inv:
+        sig = x.squeeze(1)
+        if padded:
+            sig = _pad(_pad(sig))
+        spec = torch.stft(sig, n_fft=n_fft, hop_length=hop_length, window=window, center=True, return_complex=True,
+                          pad_mode="constant")
+        if transform_type == "exponent":  # :117-124
+            if abs_exponent != 1:
+                spec = (1e-7 + spec.abs()) ** (abs_exponent - 1.0) * spec
+            spec = spec * factor
+        elif transform_type == "log":  # :125-127
+            spec = torch.log(1 + spec.abs()) * torch.sgn(spec) * factor
+        out = torch.view_as_real(spec).moveaxis(3, 1)  # (batch, real/imag, freq, time)  :91-95
+        return out.flatten(start_dim=1, end_dim=2)
+    n_freq = x.shape[1] // 2
+    spec = torch.view_as_complex(x.reshape(x.shape[0], 2, n_freq, x.shape[2]).moveaxis(1, 3).contiguous())  # :104-106
+    if transform_type == "exponent":  # :133-139
+        spec = spec / factor
+        if abs_exponent != 1:
+            spec = (1e-7 + spec.abs()) ** (1.0 / abs_exponent - 1.0) * spec
+    elif transform_type == "log":  # :140-142
+        spec = spec / factor
+        spec = (torch.exp(spec.abs()) - 1) * torch.sgn(spec)
+    if padded and length is None:
+        length = spec.shape[-1] * hop_length  # :215-216
+    y = torch.istft(spec, n_fft=n_fft, hop_length=hop_length, window=window, center=True, length=length)
+    return y.unsqueeze(1)
+
+
 def si_sdr(ref, est):
     """Scale-invariant SDR in dB of `est` against `ref` (the parity gate: >= 60 dB)."""
     ref = ref.reshape(-1).double()

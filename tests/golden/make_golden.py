@@ -15,7 +15,8 @@ Fixtures are DATA only: inputs are regenerated from seeds, outputs are stored as
     full_OR16_n32.npz    BASELINE configs[3]: original UNIVERSE 16 kHz, 4 s, 32 steps, 2 utterances
     full_PP24_varlen.npz BASELINE configs[4]: UNIVERSE++ 24 kHz, 8 steps, variable-length batch of 8 right-zero-padded
                          to its longest member (datasets/datamodule.py:24-42); rows 0 / 7 (longest / shortest) stored
-Run:  python tests/golden/make_golden.py [base] [stress] [configs]      (default: base)
+    transform.npz        CompressedMagSTFT(Padded) forward / inverse of the reference's own classes (4 parameter sets)
+Run:  python tests/golden/make_golden.py [base] [stress] [configs] [transform]      (default: base)
 """
 import json
 import os
@@ -143,9 +144,31 @@ def enhance_with_noise(m, mix, noise, **kw):
         torch.randn = real
 
 
+def make_transform():
+    """CompressedMagSTFT / CompressedMagSTFTPadded of the reference (layers/dyn_range_comp.py) on a seeded signal."""
+    import importlib
+
+    from helpers import TRANSFORM_CASES
+
+    R.install_stubs()
+    drc = importlib.import_module("open_universe.layers.dyn_range_comp")
+    x = synth_mix(get_spec("PP16"), 2, 4000)[:, None, :] * 5.0
+    out = {}
+    for tag, stft_kw, spec_kw, pad_block in TRANSFORM_CASES:
+        t = (drc.CompressedMagSTFT(dict(stft_kw), dict(spec_kw)) if pad_block is None
+             else drc.CompressedMagSTFTPadded(dict(stft_kw), dict(spec_kw), pad_block=pad_block))
+        y = t(x)
+        out[tag + "_fwd"] = y.numpy()
+        out[tag + "_inv"] = t.inv(y, length=None if pad_block else 4000).numpy()
+    np.savez_compressed(os.path.join(HERE, "transform.npz"), **out)
+    print("transform", {k: v.shape for k, v in out.items()})
+
+
 def main():
     torch.set_num_threads(8)
     what = set(sys.argv[1:]) or {"base"}
+    if "transform" in what:
+        make_transform()
     if "stress" in what:
         make_stress()
     if "configs" in what:

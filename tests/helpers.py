@@ -36,6 +36,19 @@ def synth_mix(spec, B, T, seed=1000):
     return torch.stack(out)
 
 
+# parameter sets of the signal-transform tests: (tag, stft_kwargs, spec_kwargs, pad_block | None)
+TRANSFORM_CASES = [
+    ("exp05", dict(n_fft=510, hop_length=128, window_name="hann"),
+     dict(transform_type="exponent", abs_exponent=0.5, factor=0.15), None),
+    ("log", dict(n_fft=256, hop_length=64, window_name="sqrthann"),
+     dict(transform_type="log", abs_exponent=1.0, factor=0.5), None),
+    ("none_odd", dict(n_fft=255, hop_length=85, window_name="hamming"),
+     dict(transform_type="none", abs_exponent=1.0, factor=1.0), None),
+    ("padded", dict(n_fft=510, hop_length=128, window_name="hann"),
+     dict(transform_type="exponent", abs_exponent=0.667, factor=0.3), 1024),
+]
+
+
 def varlen_lengths(fs=24000, n=8, seed=5):
     """L_i = fs * U(1, 8) s, manual_seed(5), sorted descending (same recipe as make_golden.py)."""
     u = torch.rand(n, generator=torch.Generator().manual_seed(seed))
@@ -76,14 +89,30 @@ def lora_style_state_dict(sd, rank=4, seed=8):
 
 
 _OBSERVED = {}
+_GATES = None
 
 
-def record(name, value):
-    """Log an observed parity figure (dB) of a GPU test to gpurun_out/parity_observed.json: the gates in the tests are
-    set 15 dB below what is observed here, so a regression of that size fails instead of hiding under the 60 dB bar."""
+def gate(name, floor=60.0):
+    """Pass mark (dB) of a recorded parity figure: tests/parity_gates.json (= what was observed on MI355X minus 15 dB,
+    written by tools/make_gates.py), never below `floor` (60 dB = BASELINE.json's tolerance)."""
+    global _GATES
+    import os
+
+    if _GATES is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "parity_gates.json")
+        _GATES = json.load(open(path)) if os.path.exists(path) else {}
+    return max(float(floor), float(_GATES.get(name, floor)))
+
+
+def record(name, value, floor=60.0):
+    """Log an observed parity figure (dB) of a GPU test to gpurun_out/parity_observed.json and hold it against its gate:
+    15 dB below what was observed when the gates were last regenerated, so a regression of that size fails instead of
+    hiding under the 60 dB bar."""
     import os
 
     _OBSERVED[name] = round(float(value), 2)
+    g = gate(name, floor)
+    assert value >= g, f"{name}: {value:.1f} dB < gate {g:.1f} dB"
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(d, exist_ok=True)

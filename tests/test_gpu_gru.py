@@ -1,0 +1,56 @@
+"""GPU (-m gpu): the two generations of the GRU cluster kernel (torch.nn.GRU semantics, score.py:83-89,116 /
+condition.py:173-179,212) against each other and the epoch-tag machinery of the ring kernel."""
+import pytest
+import torch
+
+import restatement as O
+from helpers import get_spec, record, synth_mix
+from test_gpu_parity import get_model, noise_list, run_enhance
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,B", [("PP16", 1), ("PP16", 2), ("PP24", 1), ("PP24s", 2), ("PP16m", 9)])
+def test_ring_kernel_matches_polling_wave_kernel(name, B, monkeypatch):
+    """OU_GRU_V=1: first-generation kernel (one polling wave, LDS hand-over, memset per launch); OU_GRU_V=2: ring kernel
+    (every wave gathers from L2, epoch tags; the default at batch 1).  Same recurrence, different summation order
+    inside a row.  B = 9 covers batches that are not a multiple of the 8 XCDs, PP24 the 24-workgroup clusters."""
+    model, spec, sd = get_model(name)
+    T = spec.tot_ds * 37 + 11
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(29, 3, B, Tp)
+    monkeypatch.setenv("OU_GRU_V", "1")
+    model._ws_key = None  # the two generations lay the exchange area out differently: fresh (cleared) workspace each
+    ref = run_enhance(model, mix, nz, n_steps=3)
+    monkeypatch.setenv("OU_GRU_V", "2")
+    model._ws_key = None
+    out = run_enhance(model, mix, nz, n_steps=3)
+    out2 = run_enhance(model, mix, nz, n_steps=3)
+    assert torch.equal(out, out2)  # consecutive launches (advancing epochs) are deterministic
+    record(f"gru.ring_vs_v1.{name}.b{B}", O.si_sdr(ref, out), 90)
+    model._ws_key = None
+
+
+def test_ring_kernel_epoch_wrap(monkeypatch):
+    """Tags are epoch + step with a device-side epoch that only grows; near 2^31 the last block of a launch clears the
+    exchange area and restarts.  Poke the stored epochs close to the limit and run across it."""
+    monkeypatch.setenv("OU_GRU_V", "2")
+    model, spec, sd = get_model("PP16m")
+    model._ws_key = None
+    B, T = 2, spec.tot_ds * 25
+    mix = synth_mix(spec, B, T - 3)
+    nz = noise_list(31, 3, B, T)
+    ref = run_enhance(model, mix, nz, n_steps=3)
+    hdr = model._ws[:64].view(torch.int32)
+    near = 0x7F000000 - 40
+    hdr[2] = near  # conditioner exchange area: {epoch, finished blocks}
+    hdr[4] = near  # score-net exchange area
+    torch.cuda.synchronize()
+    out = run_enhance(model, mix, nz, n_steps=3)
+    assert torch.equal(ref, out)
+    torch.cuda.synchronize()
+    assert 0 <= int(hdr[2]) < 10 ** 6 and 0 <= int(hdr[4]) < 10 ** 6  # wrapped and restarted
+    assert int(hdr[3]) == 0 and int(hdr[5]) == 0                      # block counters back at zero
+    assert torch.equal(ref, run_enhance(model, mix, nz, n_steps=3))
+    model._ws_key = None

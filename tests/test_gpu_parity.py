@@ -2,7 +2,8 @@
 against the committed golden vectors of the real reference, and through size-independent properties.
 
 Gate (BASELINE.json north_star): SI-SDR(new vs reference output) >= 60 dB.  All arithmetic is fp32; the observed
-agreement is 100-130 dB, so the tests assert >= 80 dB on intermediates and >= 60 dB on end-to-end outputs."""
+agreement is 100-130 dB.  Every figure goes through helpers.record(): logged to gpurun_out/parity_observed.json and held
+against tests/parity_gates.json (= 15 dB below the last committed observation, never below 60 dB)."""
 import os
 
 import numpy as np
@@ -10,7 +11,7 @@ import pytest
 import torch
 
 import restatement as O
-from helpers import get_spec, synth_mix
+from helpers import get_spec, record, synth_mix
 from open_universe_amd import state_dict as S
 
 pytestmark = pytest.mark.gpu
@@ -66,16 +67,18 @@ def test_networks_vs_oracle_intermediates(name):
     c_ref, y_ref, h_ref = O.conditioner_network(sd, "condition_model", sdict, xin, taps=taps)
     cond, aux, lat = model.condition_model(xin.cuda(), train=True)
     for b in range(B):  # the stored mel is un-normalised: per-utterance scale, so compare per batch element
-        assert O.si_sdr(taps["mel"][b], model.tensor("cond.mel")[b].cpu()) > 80
+        record(f"net.{name}.mel{b}", O.si_sdr(taps["mel"][b], model.tensor("cond.mel")[b].cpu()), 80)
     checks = [("x_mel", "cond.melblock.v"), ("enc_sum", "cond.enc_sum"), ("gru", "cond.gru")]
     checks += [(f"st{i}", f"cond.st{i}") for i in range(len(spec.score.rate_factors) - 1)]
     for tap, nm in checks:
-        assert O.si_sdr(taps[tap], model.tensor(nm).cpu()) > 80, nm
+        record(f"net.{name}.{nm}", O.si_sdr(taps[tap], model.tensor(nm).cpu()), 80)
     for j, (a, b) in enumerate(zip(c_ref, cond)):
-        assert a.shape == b.shape and O.si_sdr(a, b.cpu()) > 80, j
-    assert O.si_sdr(y_ref, aux.cpu()) > 80 and O.si_sdr(h_ref, lat.cpu()) > 80
+        assert a.shape == b.shape
+        record(f"net.{name}.cond{j}", O.si_sdr(a, b.cpu()), 80)
+    record(f"net.{name}.aux", O.si_sdr(y_ref, aux.cpu()), 80)
+    record(f"net.{name}.latent", O.si_sdr(h_ref, lat.cpu()), 80)
     if spec.use_signal_decoupling:
-        assert O.si_sdr(O.aux_to_wav(sd, sdict, y_ref), model.aux_to_wav().cpu()) > 80
+        record(f"net.{name}.aux_to_wav", O.si_sdr(O.aux_to_wav(sd, sdict, y_ref), model.aux_to_wav().cpu()), 80)
     # score network, per-batch sigma (the operator seam score_model(x, sigma, cond))
     g = torch.Generator().manual_seed(5)
     sig = torch.tensor([0.3, 1.7])
@@ -91,9 +94,9 @@ def test_networks_vs_oracle_intermediates(name):
     assert torch.equal(taps["input_conv"], model.tensor("score.in").cpu()) or \
         O.si_sdr(taps["input_conv"], model.tensor("score.in").cpu()) > 120
     for i in range(nb):
-        assert O.si_sdr(taps[f"enc{i}.v"], model.tensor(f"score.enc{i}.v").cpu()) > 80, i
-        assert O.si_sdr(taps[f"dec{i}.v"], model.tensor(f"score.dec{i}.v").cpu()) > 80, i
-    assert O.si_sdr(O.score_model(sd, sdict, xs, sig, c_ref), s_hip) > 80
+        record(f"net.{name}.score.enc{i}", O.si_sdr(taps[f"enc{i}.v"], model.tensor(f"score.enc{i}.v").cpu()), 80)
+        record(f"net.{name}.score.dec{i}", O.si_sdr(taps[f"dec{i}.v"], model.tensor(f"score.dec{i}.v").cpu()), 80)
+    record(f"net.{name}.score", O.si_sdr(O.score_model(sd, sdict, xs, sig, c_ref), s_hip), 80)
 
 
 @pytest.mark.parametrize("name", ["PP16s", "PP16m", "OR16s", "PP24s"])
@@ -117,7 +120,7 @@ def test_enhance_vs_reference_goldens(name):
         out = run_enhance(model, mix, nz, **kw)
         ref = torch.from_numpy(gold["enh_" + tag])
         assert out.shape == ref.shape
-        assert O.si_sdr(ref, out) >= GATE_DB, (tag, O.si_sdr(ref, out))
+        record(f"gold.{name}.{tag}", O.si_sdr(ref, out))
 
 
 def test_full_size_headline_config_vs_reference_golden():
@@ -128,8 +131,7 @@ def test_full_size_headline_config_vs_reference_golden():
     mix = synth_mix(spec, 1, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     out = run_enhance(model, mix, noise_list(1028282, 8, 1, Tp), n_steps=8)
-    snr = O.si_sdr(torch.from_numpy(gold["enh"]), out)
-    assert snr >= GATE_DB, snr
+    record("gold.full_PP16.n8", O.si_sdr(torch.from_numpy(gold["enh"]), out))
     # properties that do not depend on the oracle
     assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6  # peak guard, universe.py:356-357
     out2 = run_enhance(model, mix, noise_list(1028282, 8, 1, Tp), n_steps=8)
@@ -149,7 +151,7 @@ def test_batch_independence_and_rank_conventions():
     for b in range(B):
         one = run_enhance(model, mix[b], [z[b:b + 1] for z in nz], n_steps=3)
         assert one.shape == (T,)
-        assert O.si_sdr(full[b], one) > 100
+        record(f"batch_independence.PP16m.{b}", O.si_sdr(full[b], one), 100)
     assert run_enhance(model, mix[:, None, :], nz, n_steps=3).shape == (B, 1, T)
     with pytest.raises(ValueError):
         model.enhance(mix.cuda()[None, :, None, :])
@@ -221,7 +223,7 @@ def test_other_baseline_configs_full_width(name, T, n_steps):
     nz = noise_list(11, n_steps, 1, Tp)
     ref = O.enhance(sd, spec.to_dict(), mix, n_steps=n_steps, noise=nz)
     out = run_enhance(model, mix, nz, n_steps=n_steps)
-    assert O.si_sdr(ref, out) >= GATE_DB, O.si_sdr(ref, out)
+    record(f"oracle.full_width.{name}", O.si_sdr(ref, out))
 
 
 def test_variable_length_batch_is_padded_batch_semantics():
@@ -237,10 +239,10 @@ def test_variable_length_batch_is_padded_batch_semantics():
     nz = noise_list(5, 3, len(lens), Tp)
     ref = O.enhance(sd, spec.to_dict(), batch, n_steps=3, noise=nz)
     out = run_enhance(model, batch, nz, n_steps=3)
-    assert O.si_sdr(ref, out) >= GATE_DB
+    record("varlen.PP24s.vs_oracle", O.si_sdr(ref, out))
     for b in range(len(lens)):
         one = run_enhance(model, batch[b], [z[b:b + 1] for z in nz], n_steps=3)
-        assert O.si_sdr(out[b], one) > 100
+        record(f"varlen.PP24s.alone{b}", O.si_sdr(out[b], one), 100)
 
 
 @pytest.mark.parametrize("mode", [("3", ""), ("2", ""), ("3", "128"), ("2", "256"), ("-1", "")])
@@ -283,7 +285,7 @@ def test_edge_lengths_vs_oracle(T):
     assert out.shape == ref.shape == (B, T)
     assert torch.isfinite(out).all()
     if T > 1:
-        assert O.si_sdr(ref, out) >= GATE_DB, O.si_sdr(ref, out)
+        record(f"edge.T{T}", O.si_sdr(ref, out))
     else:
         assert torch.allclose(ref, out, rtol=1e-3, atol=1e-6)
 
@@ -299,7 +301,7 @@ def test_full_model_odd_batch_equals_single_utterances():
     full = run_enhance(model, mix, nz, n_steps=2)
     for b in (0, 2, 4):
         one = run_enhance(model, mix[b], [z[b:b + 1] for z in nz], n_steps=2)
-        assert O.si_sdr(full[b], one) > 100
+        record(f"batch_independence.PP16.b5.{b}", O.si_sdr(full[b], one), 100)
 
 
 def test_cli_end_to_end_matches_oracle_pipeline(tmp_path):
@@ -330,4 +332,4 @@ def test_cli_end_to_end_matches_oracle_pipeline(tmp_path):
         ref = A.resample(O.enhance(sd, spec.to_dict(), mix, n_steps=3, noise=nz), spec.fs, fs)
         out, fs_out = A.load(dst / rel)
         assert fs_out == fs and out.shape == ref.shape
-        assert O.si_sdr(ref, out) >= GATE_DB, (rel, O.si_sdr(ref, out))
+        record(f"cli.{rel}", O.si_sdr(ref, out))

@@ -130,3 +130,19 @@ def test_oracle_vs_reference_64_step_config():
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     out = O.enhance(sd, spec.to_dict(), synth_mix(spec, 1, T), n_steps=64, noise=noise_list(303, 64, 1, Tp))
     assert O.si_sdr(torch.from_numpy(gold["enh"]), out) > 90
+
+
+def test_oracle_transform_vs_reference_golden():
+    """CompressedMagSTFT(Padded) restatement against the fixture produced by the reference's own classes."""
+    from helpers import TRANSFORM_CASES
+    from open_universe_amd.layers.dyn_range_comp import get_window
+
+    gold = np.load(os.path.join(G, "transform.npz"))
+    x = synth_mix(get_spec("PP16"), 2, 4000)[:, None, :] * 5.0
+    for tag, stft_kw, spec_kw, pad_block in TRANSFORM_CASES:
+        kw = dict(n_fft=stft_kw["n_fft"], hop_length=stft_kw["hop_length"],
+                  window=get_window(stft_kw["window_name"], stft_kw["n_fft"]), pad_block=pad_block, **spec_kw)
+        y = O.compressed_mag_stft(x, **kw)
+        assert torch.equal(y, torch.from_numpy(gold[tag + "_fwd"])), tag
+        inv = O.compressed_mag_stft(y, inv=True, length=None if pad_block else 4000, **kw)
+        assert torch.equal(inv, torch.from_numpy(gold[tag + "_inv"])), tag

@@ -76,3 +76,28 @@ def test_edm_data_level_and_noisy_ref_match_live_reference():
     out = O.enhance(sd, spec.to_dict(), mix[:, None, :], n_steps=3, target=tgt, fake_score_snr=10.0,
                     rng=torch.Generator().manual_seed(3))
     assert torch.equal(ref, out)
+
+
+from helpers import TRANSFORM_CASES  # noqa: E402
+
+
+def test_transform_restatement_matches_live_reference():
+    """CompressedMagSTFT(Padded) of the oracle against the reference's classes
+    (layers/dyn_range_comp.py), forward and inverse, incl. the Padded variant's double `_pad`."""
+    import importlib
+
+    R.install_stubs()
+    drc = importlib.import_module("open_universe.layers.dyn_range_comp")
+    x = synth_mix(get_spec("PP16"), 2, 4000)[:, None, :] * 5.0
+    for tag, stft_kw, spec_kw, pad_block in TRANSFORM_CASES:
+        if pad_block is None:
+            ref = drc.CompressedMagSTFT(dict(stft_kw), dict(spec_kw))
+        else:
+            ref = drc.CompressedMagSTFTPadded(dict(stft_kw), dict(spec_kw), pad_block=pad_block)
+        kw = dict(n_fft=stft_kw["n_fft"], hop_length=stft_kw["hop_length"], window=ref.stft_window,
+                  pad_block=pad_block, **spec_kw)
+        y_ref = ref(x)
+        y = O.compressed_mag_stft(x, **kw)
+        assert y.shape == y_ref.shape and torch.equal(y, y_ref), tag
+        length = None if pad_block else 4000
+        assert torch.equal(O.compressed_mag_stft(y, inv=True, length=length, **kw), ref.inv(y_ref, length=length)), tag

@@ -14,6 +14,11 @@ for _ in range(2):
 torch.cuda.synchronize()
 ws = model._ws
 ts = ws[ws.numel() - (1 << 20):].view(torch.int64)[: 64 * 8 * 8].view(64, 8, 8).cpu().double()
+v = os.environ.get("OU_GRU_V", "2")
 for blk in (0, 1, 8, 9):
-    print("block", blk, "per-step cycles [compute, poll(wave0)/idle, barrier | matvec, reduce, gates+stores]:",
-          [[round(float(v) / 401) for v in ts[blk, w, [0, 1, 2, 4, 5, 6]]] for w in (0, 1, 7)])
+    if v == "1":
+        print("v1 block", blk, "per-step cycles [compute, poll(wave0)/idle, barrier | matvec, reduce, gates+stores]:",
+              [[round(float(x) / 401) for x in ts[blk, w, [0, 1, 2, 4, 5, 6]]] for w in (0, 1, 7)])
+    else:
+        print("v2 block", blk, "per-step cycles per wave [compute (matvec..publish), gather (poll until all tags)]:",
+              [[round(float(x) / 401) for x in ts[blk, w, [0, 1]]] for w in (0, 1, 2, 3)])

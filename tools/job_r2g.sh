@@ -1,0 +1,9 @@
+export TMPDIR=/tmp
+O=gpurun_out/r2g; mkdir -p $O
+rm -f gpurun_out/parity_observed.json
+timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 > $O/pytest_gpu.txt 2>&1
+tail -14 $O/pytest_gpu.txt
+OU_TRACE=1 OU_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr -o t -- python tools/gpu_debug.py timing PP16 iters=2 > $O/timing_trace.txt 2> $O/trace.log
+python tools/trace_summary.py $O/tr/t_kernel_trace.csv $O/trace.log > $O/layers.txt 2>&1
+head -24 $O/layers.txt
+timeout 300 python tools/gpu_debug.py timing PP16 B=1 n_steps=8 2>&1 | grep TIMING

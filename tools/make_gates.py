@@ -1,0 +1,15 @@
+"""tests/parity_gates.json <- gpurun_out/parity_observed.json: gate = floor(observed - 15 dB), at least 60 dB (the
+tolerance BASELINE.json states), at most 120 dB (figures above that are fp32 noise-floor lottery).  Re-run after a GPU
+test pass whenever kernels change the summation order; the gates only ever move with a committed observation."""
+import json, math, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+obs = json.load(open(os.path.join(ROOT, "gpurun_out", "parity_observed.json")))
+path = os.path.join(ROOT, "tests", "parity_gates.json")
+old = json.load(open(path)) if os.path.exists(path) else {}
+keep_min = "--min" in sys.argv  # only ever lower a gate to the new observation (several kernel variants share a name)
+gates = dict(old)
+for k, v in obs.items():
+    g = float(min(120, max(60, math.floor(v - 15))))
+    gates[k] = min(g, old[k]) if (keep_min and k in old) else g
+json.dump(gates, open(path, "w"), indent=1, sort_keys=True)
+print(f"{len(gates)} gates -> {path}")

@@ -25,10 +25,9 @@ def main(trace_csv, ou_trace_log=None):
         print(f"  {n:60s} {c:5d} calls {d/1e3:10.1f} us  {100*d/busy:5.1f}%  avg {d/c/1e3:8.1f} us")
     if ou_trace_log:
         names = [l.split() for l in open(ou_trace_log) if l.startswith("OU_TRACE conv") or l.startswith("OU_TRACE chain")]
-        convs = [r for r in rows if "conv_mfma_kernel" in r["Kernel_Name"]]
-        per = len(convs) // max(1, len(starts)) if starts else len(convs)
         # conv launches of the last enhance, in order, align with the last `per` trace lines
-        last = [r for r in seg if "conv_mfma_kernel" in r["Kernel_Name"] or "conv_chain_kernel" in r["Kernel_Name"]]
+        last = [r for r in seg if any(k in r["Kernel_Name"] for k in ("conv_mfma_kernel", "conv_chain_kernel",
+                                                                      "conv_direct_kernel"))]
         lines = names[-len(last):]
         print(f"per-layer (last enhance, {len(last)} conv launches):")
         seen = set()
@@ -47,7 +46,7 @@ def main(trace_csv, ou_trace_log=None):
             if key in seen and not nm.startswith("cond."):
                 continue  # print the score layers once (first step)
             seen.add(key)
-            print(f"  {nm:28s} {' '.join(l[3:9]):60s} {d:8.1f} us {mflop/d/1e6*1e3:7.1f} TF/s" if d > 0 else nm)
+            print(f"  {nm:28s} {' '.join(l[3:9]):60s} {d:8.1f} us {mflop/d/1e6:7.1f} TF/s" if d > 0 else nm)
 
 
 if __name__ == "__main__":
