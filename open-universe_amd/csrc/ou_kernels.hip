@@ -2137,7 +2137,7 @@ template <int HB, int UPW>
 __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters) {
   constexpr int H = 64 * HB, NT = 256, LPU = NT / UPW, NC = H / LPU, NI = NC / 4, NWG = H / UPW;
   constexpr int CSTRIDE = 2 * H + 64;  // granules per cluster: two parity buffers + rendezvous slots
-  static_assert(LPU == 8 || LPU == 16, "8 or 16 lanes per hidden unit");
+  static_assert(LPU == 8 || LPU == 16 || LPU == 32, "8, 16 or 32 lanes per hidden unit");
   static_assert(NC % 4 == 0 && NWG > 1 && NWG <= 64, "column blocks / rendezvous slots");
   const int tid = threadIdx.x, lane = tid & 63;
   const int bid = blockIdx.x;
@@ -2170,7 +2170,9 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
         wn[4 * i + 0] = vn.x; wn[4 * i + 1] = vn.y; wn[4 * i + 2] = vn.z; wn[4 * i + 3] = vn.w;
       }
     }
-    const bool fin = cg == 0;
+    // the lane that ends up with the unit's gate sums: any lane of a 8 / 16-lane group (all-reduce), the upper row of a
+    // 32-lane group (row_bcast:15 adds the lower row's total into the upper row only)
+    const bool fin = cg == (LPU == 32 ? 16 : 0);
     const float bhn = p.bhn[dir * H + unit];
     const float* gxb = p.gx + ((size_t)b * 6 * H + (size_t)dir * 3 * H) * T;
     const size_t orow = ((size_t)b * 2 * H + (size_t)dir * H + unit) * T;
@@ -2275,13 +2277,13 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
             const unsigned a = hv[k].y < hv[k].w ? hv[k].y : hv[k].w;
             m = a < m ? a : m;
           }
-          if (m == want) break;
+          if (__builtin_amdgcn_ballot_w64(m != want) == 0ull) break;  // wave-uniform: the wave needs all H values anyway
           // every wave polls all H granules: 32 line requests per wave and round.  Fine for the few clusters of a batch-1
           // call (~10-25 % of the L2 request rate); with dozens of clusters the polls alone saturate the L2 channels and
           // progress collapses (measured: OR16, B = 16 -> multi-second stalls), which is why launch_gru() keeps larger
           // batches on the polling-wave kernel.  Back off if a wait gets long anyway.
           ++spins;
-          if ((__builtin_amdgcn_readfirstlane(spins) & 63u) == 0u) __builtin_amdgcn_s_sleep(4);  // scalar branch: s_sleep ignores EXEC
+          if ((spins & 63u) == 0u) __builtin_amdgcn_s_sleep(4);
           if (spins > GRU_SPIN_LIMIT) {
             atomicOr(p.err, 4u);  // diagnostics: who waited for what
             p.err[12] = (unsigned)cluster; p.err[13] = (unsigned)g; p.err[14] = (unsigned)step; p.err[15] = m; p.err[16] = want;
@@ -2306,7 +2308,13 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
       }
       float hs[3] = {arz0.x + arz1.x, arz0.y + arz1.y, an0 + an1};
 #pragma unroll
-      for (int gt = 0; gt < 3; gt++) hs[gt] = LPU == 8 ? row8_sum(hs[gt]) : row16_sum(hs[gt]);
+      for (int gt = 0; gt < 3; gt++) {
+        hs[gt] = LPU == 8 ? row8_sum(hs[gt]) : row16_sum(hs[gt]);
+        if (LPU == 32) {  // rows 1 / 3 += total of rows 0 / 2
+          const int lo = __builtin_amdgcn_update_dpp(0, __float_as_int(hs[gt]), 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+          hs[gt] += __int_as_float(lo);
+        }
+      }
 
       if (fin) {
         const float r = sigmoidf_(xr + hs[0]);
@@ -2360,6 +2368,12 @@ static hipError_t launch_gru_ring(const GruArgs& c, int upw, int nclusters, hipS
       return hipGetLastError();
     }
   }
+  if constexpr (HB >= 2 && HB <= 4) {  // 8 units per workgroup: half the columns (and polls) per lane, twice the workgroups
+    if (upw == 8) {
+      hipLaunchKernelGGL((gru_ring_kernel<HB, 8>), grid, dim3(256), 0, st, c, nclusters);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((gru_ring_kernel<HB, 16>), grid, dim3(256), 0, st, c, nclusters);
   return hipGetLastError();
 }
@@ -2388,7 +2402,7 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
   else if (a.H % 16 == 0 && batch_cap(16) >= a.B) upw = 16;
   else if (a.H % 32 == 0 && batch_cap(32) >= a.B) upw = 32;
   // the ring kernel runs 256-thread workgroups of 16 units (32 on request, H <= 256)
-  if (a.version == 2) upw = (a.force_upw == 32 && a.H <= 256) ? 32 : 16;
+  if (a.version == 2) upw = (a.force_upw == 32 && a.H <= 256) ? 32 : ((a.force_upw == 8 && a.H >= 128 && a.H <= 256) ? 8 : 16);
   const int nwg = a.H / upw;
   int bmax = batch_cap(upw);
   if (a.force_bmax > 0 && a.force_bmax < bmax) bmax = a.force_bmax;

@@ -333,3 +333,33 @@ def test_cli_end_to_end_matches_oracle_pipeline(tmp_path):
         out, fs_out = A.load(dst / rel)
         assert fs_out == fs and out.shape == ref.shape
         record(f"cli.{rel}", O.si_sdr(ref, out))
+
+
+def test_oracle_score_mode_vs_oracle_with_shared_noise(monkeypatch):
+    """target=... (universe.py:278-298) against the oracle draw for draw: `torch.randn` is replaced on both sides by one
+    pre-drawn list (the reference's draw order: x0, then per step the fake-score noise and z), so the device RNG no
+    longer stands between the two.  Covers normalisation of the target (ref = both), keep_rms and the peak guard."""
+    model, spec, sd = get_model("OR16s")
+    B, T, N = 2, 1600, 6
+    mix = synth_mix(spec, B, T)[:, None, :]
+    tgt = synth_mix(spec, B, T, seed=77)[:, None, :]
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    pool = noise_list(41, 2 * N, B, Tp)
+    real_randn = torch.randn
+
+    def run(fn, device):
+        it = iter(pool)
+
+        def fake(*a, **k):
+            return next(it).clone().to(device)
+
+        monkeypatch.setattr(torch, "randn", fake)
+        try:
+            return fn()
+        finally:
+            monkeypatch.setattr(torch, "randn", real_randn)
+
+    ref = run(lambda: O.enhance(sd, spec.to_dict(), mix, n_steps=N, target=tgt, fake_score_snr=20.0, keep_rms=True), "cpu")
+    out = run(lambda: model.enhance(mix.cuda(), n_steps=N, target=tgt.cuda(), fake_score_snr=20.0, keep_rms=True), "cuda:0")
+    assert out.shape == ref.shape
+    record("target_mode.vs_oracle", O.si_sdr(ref, out.cpu()), 100)
