@@ -233,6 +233,41 @@ def main():
     assert torch.isfinite(out).all()
     launches = model.launch_stats()
 
+    # ---- host side: time to ENQUEUE one enhance (no sync), eager walk of the network vs one hipGraph replay ----
+    host_enqueue = None
+    if rank == 0 and not args.varlen:
+        model.check_status = False
+
+        def enqueue_ms(fn, reps=10):
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+            ts.sort()
+            return 1e3 * ts[len(ts) // 2]
+
+        host_enqueue = {"eager_ms": enqueue_ms(step)}
+        try:
+            run = model.graphed_enhance(args.batch, T, n_steps=args.n_steps)
+            run(mix, rng=rng)
+            host_enqueue["hipgraph_ms"] = enqueue_ms(lambda: run(mix, rng=rng))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run(mix, rng=rng)
+            torch.cuda.synchronize()
+            host_enqueue["hipgraph_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / args.steps
+            host_enqueue["note"] = ("median host time of one enhance call returning without a sync: eager = Python + C walk "
+                                    "of the network (~430 launches on 4 streams); hipgraph = noise draws + one replay of "
+                                    "the captured ou_enhance (model.graphed_enhance)")
+        except Exception as e:  # capture support is a convenience, never the measured path
+            host_enqueue["hipgraph_error"] = repr(e)[:300]
+        model.check_status = True
+        model._status(force=True)
+
     # ---- roofline of the dominant kernel: per-launch device-side timing (separate profiled pass, same workload) ----
     roofline = None
     if rank == 0:
@@ -371,6 +406,7 @@ def main():
             "status_mode": "value / ms_per_step: product default (stream sync + device status read after every enhance)",
             "free_running": {"value": audio_s / dt_async, "ms_per_step": 1e3 * dt_async / args.steps,
                              "note": "model.check_status = False: no host sync inside the timed loop, status checked after it"},
+            "host_enqueue": host_enqueue,
             "roofline": roofline,
         }
         if not args.no_cpu_baseline:

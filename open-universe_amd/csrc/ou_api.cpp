@@ -256,6 +256,7 @@ struct Runner {
           chk(launch_fir(u.p, W(Bk.rc.fir_off), Bk.rc.fir_len, 0.f, 0, W(Bk.rc.fbias_off), res, kInvSqrt2, hu.p, B, u.C,
                          u.T, st), "fir(up)");
       } else {
+        // (fir_mode 4: FIR folded into 3-tap phase GEMMs by the packer, its manual bias = the conv bias)
         Epi e;
         e.res = res; e.res_scale = kInvSqrt2;  // blocks.py:374-376 fused into the up-conv epilogue
         hu = conv(Bk.rc, hin, nm + ".up", e);
@@ -333,7 +334,7 @@ struct Runner {
         e.act = false;  // PReLU applied by the FIR pass
         o.h_next = conv(Bk.rc, xf, nm + ".h", e);
       } else {
-        o.h_next = conv(Bk.rc, v, nm + ".h", Epi());
+        o.h_next = conv(Bk.rc, v, nm + ".h", Epi());  // (fir_mode 3: FIR folded into the 3r-tap weights)
       }
     }
     return o;

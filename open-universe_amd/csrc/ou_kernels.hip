@@ -9,6 +9,7 @@ namespace ou {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
@@ -603,6 +604,134 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
 //   Same K order per output element as conv_mfma_kernel's split-K configs (pairs kw, kw + 8, ... tap-inner vs tap-outer
 //   differs) -- results agree to fp32 rounding, not bit-wise.
 // =========================================================================================================
+// Block -> output tile of the direct kernels (same XCD-aware mappings as conv_mfma_kernel).  false: padding block.
+__device__ __forceinline__ bool direct_tile(const ConvArgs& p, int& tile_m, int& tile_n) {
+  const int L = blockIdx.x, gx = p.grid_n, gy = p.grid_m;
+  if (p.xcd_map == 1) {
+    const int q = L >> 3, mg = q / gx;
+    tile_n = q - mg * gx;
+    tile_m = mg * 8 + (L & 7);
+  } else if (p.xcd_map == 2) {
+    const int q = L >> 3, ng = q / gy;
+    tile_m = q - ng * gy;
+    tile_n = ng * 8 + (L & 7);
+    if (tile_n >= gx) return false;
+  } else {
+    tile_m = L / gx;
+    tile_n = L - tile_m * gx;
+  }
+  return true;
+}
+__device__ __forceinline__ u32x4 direct_desc(const void* base, unsigned bytes) {
+  // buffer descriptor as a plain SGPR quad (base, bounds, raw-dword format) for the inline-asm loads
+  const unsigned long long a = (unsigned long long)base;
+  u32x4 d;
+  d.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  d.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+  d.z = __builtin_amdgcn_readfirstlane(bytes);
+  d.w = 0x00020000u;
+  return d;
+}
+
+// Fused epilogue of the direct kernels: accumulators of the 8 K-slice waves -> LDS -> reduced on read -> bias, cond
+// add, FiLM, residual -> store.
+//   up == 1: each thread owns four consecutive samples of one output row (16-byte accesses when rows are 16-byte
+//            multiples, scalar otherwise: the deep levels have T = 401, 2005);
+//   up  > 1: transposed conv as `up` phase GEMMs (row m = co*up + ph -> sample t = q*up + ph): element e of the tile's
+//            (co, t) range, consecutive threads = consecutive samples.
+template <int TN>
+struct DirectEpilogue {
+  static constexpr int WK = 8, NT = 512, BM = 32, BN = 32 * TN, EP = BN + 4, C4 = BN / 4;
+
+  // Everything -- index arithmetic and the loads of bias / cond / FiLM / residual -- happens AFTER the main loop.
+  // Prefetching these operands before the ring (tried: inline-asm loads issued first, consumed here) hides one memory
+  // latency per launch but keeps 11-36 more registers live across the main loop: the 64-column kernels went from
+  // 97-125 to 136-165 VGPRs, i.e. from two resident workgroups per CU to one, and the 504-block latent layers got 25-30 %
+  // slower.  Occupancy wins.
+  static __device__ __forceinline__ void run(const ConvArgs& p, const floatx16 (&acc)[TN], float* Es, int tid, int kw,
+                                             int b, int m0, int n0) {
+    const int lane = tid & 63, lhalf = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+        Es[(kw * BM + row) * EP + 32 * j + l31] = acc[j][r];
+      }
+    __syncthreads();
+    const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+    int m_hi = m0 + BM - 1;
+    if (m_hi > p.M - 1) m_hi = p.M - 1;
+    const size_t ybase = (size_t)b * p.Cout * p.Tout;
+    const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+    if (p.up == 1) {
+      const int eq = (tid % C4) * 4, er = tid / C4;
+      if (er >= BM || m0 + er > m_hi || n0 + eq >= p.Nq) return;
+      const int m = m0 + er;
+      const size_t eidx = ybase + (size_t)m * p.Tout + n0 + eq;
+      int e_n = p.Nq - (n0 + eq);
+      if (e_n > 4) e_n = 4;
+      const bool vec4 = (p.Tout & 3) == 0;  // (then Nq is a multiple of 4 too and the quad is complete)
+      f32x4 ad = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+      if (vec4) {
+        if (p.add) ad = *reinterpret_cast<const f32x4*>(p.add + eidx);
+        if (p.res) rs = *reinterpret_cast<const f32x4*>(p.res + eidx);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (p.add && j < e_n) ad[j] = p.add[eidx + j];
+          if (p.res && j < e_n) rs[j] = p.res[eidx + j];
+        }
+      }
+      const float bi = p.bias[m];
+      const float ga = filmb ? filmb[m] : 1.f, be = filmb ? filmb[p.Cout + m] : 0.f;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&Es[er * EP + eq]);
+#pragma unroll
+      for (int kk = 1; kk < WK; kk++) v += *reinterpret_cast<const f32x4*>(&Es[(kk * BM + er) * EP + eq]);
+      if (p.in_scale) v *= insc;
+      v += bi;
+      if (p.add) v = (v + ad) * p.add_scale;
+      if (filmb) v = ga * v + be;
+      if (p.res) v = (v + rs) * p.res_scale;
+      if (vec4) {
+        *reinterpret_cast<f32x4*>(p.y + eidx) = v;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (j < e_n) p.y[eidx + j] = v[j];
+      }
+      return;
+    }
+    // up > 1: transposed conv as `up` phase GEMMs (row m = co*up + ph -> sample t = q*up + ph): element e of the tile's
+    // (co, t) range, consecutive threads = consecutive samples
+    constexpr int LBN = (BN == 64) ? 6 : 5;
+    const int up = p.up;
+    const int co_first = (int)__umulhi((unsigned)m0, p.magic_up);
+    const int nco = (int)__umulhi((unsigned)m_hi, p.magic_up) - co_first + 1;
+    const int total = nco * BN * up;
+    for (int e = tid; e < total; e += NT) {
+      const int rest = (int)__umulhi((unsigned)e, p.magic_up);  // e / up
+      const int ph = e - rest * up;
+      const int q = rest & (BN - 1);
+      const int co = co_first + (rest >> LBN);
+      const int m = co * up + ph;
+      const int t = (n0 + q) * up + ph;
+      if (m < m0 || m > m_hi || (n0 + q) >= p.Nq || t >= p.Tout) continue;
+      const int lds = (m - m0) * EP + q;
+      const size_t idx = ybase + (size_t)co * p.Tout + t;
+      float v = Es[lds];
+#pragma unroll
+      for (int k = 1; k < WK; k++) v += Es[k * BM * EP + lds];
+      if (p.in_scale) v *= insc;
+      v += p.bias[co];
+      if (p.add) v = (v + p.add[idx]) * p.add_scale;
+      if (filmb) v = filmb[co] * v + filmb[p.Cout + co];
+      if (p.res) v = (v + p.res[idx]) * p.res_scale;
+      p.y[idx] = v;
+    }
+  }
+};
+
 // One ring slot of the direct kernel: GP channel pairs x KW taps.  Loads and waits are inline asm (see the kernel).
 template <int KW, int TN, int GP>
 __device__ __forceinline__ void direct_issue(float (&av)[GP * KW], float (&bv)[GP * KW * TN], int g, int kw, int Tin,
@@ -615,12 +744,15 @@ __device__ __forceinline__ void direct_issue(float (&av)[GP * KW], float (&bv)[G
     const int wrow = ((ci >> lck) * KW) * CK + (ci & (CK - 1));          // packed row of (ci, tap 0)
 #pragma unroll
     for (int k = 0; k < KW; k++) {
+      // "+v": the destination is the SAME register as the slot's previous value -- one live range around the loop, so
+      // the allocator has no phi to resolve with a copy (a copy of a register whose load is still in flight reads
+      // garbage; tools/check_isa.py verifies the generated code)
       asm volatile("buffer_load_dword %0, %1, %2, %3 offen"
-                   : "=v"(av[q * KW + k]) : "v"(avo), "s"(rw), "s"((wrow + k * CK) * Mp * 4));
+                   : "+v"(av[q * KW + k]) : "v"(avo), "s"(rw), "s"((wrow + k * CK) * Mp * 4));
 #pragma unroll
       for (int j = 0; j < TN; j++)
         asm volatile("buffer_load_dword %0, %1, %2, %3 offen"
-                     : "=v"(bv[(q * KW + k) * TN + j]) : "v"(bvo[k][j]), "s"(rx), "s"(xso));
+                     : "+v"(bv[(q * KW + k) * TN + j]) : "v"(bvo[k][j]), "s"(rx), "s"(xso));
     }
   }
 }
@@ -643,29 +775,14 @@ __device__ __forceinline__ void direct_mma(float (&av)[NA], float (&bv)[NB], flo
 
 template <int KW, int TN, int GP>
 __global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
-  constexpr int WK = 8, NT = 512, D = 4, BM = 32, BN = 32 * TN;
+  constexpr int D = 4, BM = 32, BN = 32 * TN;
   constexpr int NA = GP * KW, NB = GP * KW * TN;  // A / B dwords per group
   static_assert(D * (NA + NB) <= 60, "loads in flight must fit vmcnt");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int kw = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile_m, tile_n;
-  {
-    const int L = blockIdx.x, gx = p.grid_n, gy = p.grid_m;
-    if (p.xcd_map == 1) {
-      const int q = L >> 3, mg = q / gx;
-      tile_n = q - mg * gx;
-      tile_m = mg * 8 + (L & 7);
-    } else if (p.xcd_map == 2) {
-      const int q = L >> 3, ng = q / gy;
-      tile_m = q - ng * gy;
-      tile_n = ng * 8 + (L & 7);
-      if (tile_n >= gx) return;
-    } else {
-      tile_m = L / gx;
-      tile_n = L - tile_m * gx;
-    }
-  }
+  if (!direct_tile(p, tile_m, tile_n)) return;
   const int n0 = tile_n * BN, m0 = tile_m * BM, b = blockIdx.z;
   if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 
@@ -673,20 +790,10 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
   const int CK = p.CK, lck = 31 - __clz(CK);
   const int Tin = p.Tin, Mp = p.Mp;
   const float alpha = p.act ? p.alpha_val : 1.0f;
-  // Buffer descriptors as plain SGPR quads (base, bounds, raw-dword format): the loads and their vmcnt waits are
-  // inline asm -- the compiler's own wait-count insertion resolves a register ring carried around a loop to vmcnt(0)
-  // at the loop header, which is exactly the serialisation this kernel exists to avoid.
-  auto desc = [](const void* base, unsigned bytes) {
-    const unsigned long long a = (unsigned long long)base;
-    u32x4 d;
-    d.x = __builtin_amdgcn_readfirstlane((unsigned)a);
-    d.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
-    d.z = __builtin_amdgcn_readfirstlane(bytes);
-    d.w = 0x00020000u;
-    return d;
-  };
-  const u32x4 rx = desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
-  const u32x4 rw = desc(p.w, (unsigned)p.Cin * (unsigned)KW * (unsigned)Mp * 4u);
+  // The loads and their vmcnt waits are inline asm: the compiler's own wait-count insertion resolves a register ring
+  // carried around a loop to vmcnt(0) at the loop header, which is exactly the serialisation this kernel exists to avoid.
+  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  const u32x4 rw = direct_desc(p.w, (unsigned)p.Cin * (unsigned)KW * (unsigned)Mp * 4u);
   // per-lane byte offsets: A = (half row, m); B = (half row, t) per (tap, tile) with the zero padding folded in
   const int avo = (lhalf * Mp + m0 + l31) * 4;
   int bvo[KW][TN];
@@ -699,6 +806,13 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
     }
   const int NG = (p.Cin >> 4) / GP;  // groups per wave (launcher: a multiple of D)
   float av[D][NA], bv[D][NB];
+#pragma unroll
+  for (int d0 = 0; d0 < D; d0++) {
+#pragma unroll
+    for (int u = 0; u < NA; u++) av[d0][u] = 0.f;
+#pragma unroll
+    for (int u = 0; u < NB; u++) bv[d0][u] = 0.f;
+  }
   floatx16 acc[TN];
 #pragma unroll
   for (int j = 0; j < TN; j++)
@@ -707,41 +821,6 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
 #define OU_ISSUE(g, d) direct_issue<KW, TN, GP>(av[d], bv[d], (g), kw, Tin, Mp, CK, lck, avo, bvo, rx, rw)
 #define OU_MMA(d, out) direct_mma<NA, NB, TN, out>(av[d], bv[d], acc, alpha)
   OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
-
-  // ---- epilogue operands (bias, cond add, FiLM, residual) of this thread's four output samples (row er, columns
-  // eq .. eq + 3): fetched now, consumed after the main loop.  Rows of any length / alignment (the deep levels have
-  // T = 401, 2005): 16-byte accesses when the row length allows, scalar otherwise.
-  constexpr int EP = BN + 4;
-  constexpr int C4e = BN / 4;  // column quads per row; NT / C4e >= BM rows, so one pass per thread
-  const bool plain_epi = p.up == 1;
-  const bool vec4 = (p.Tout & 3) == 0;
-  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
-  int m_hi = m0 + BM - 1;
-  if (m_hi > p.M - 1) m_hi = p.M - 1;
-  const size_t ybase = (size_t)b * p.Cout * p.Tout;
-  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
-  const int eq = (tid % C4e) * 4, er = tid / C4e;
-  const bool e_on = plain_epi && er < BM && m0 + er <= m_hi && n0 + eq < p.Nq;
-  const size_t eidx = ybase + (size_t)(m0 + er) * p.Tout + n0 + eq;
-  int e_n = p.Nq - (n0 + eq);  // valid samples of the quad
-  if (e_n > 4) e_n = 4;
-  f32x4 e_ad = {0.f, 0.f, 0.f, 0.f}, e_rs = {0.f, 0.f, 0.f, 0.f};
-  float e_bi = 0.f, e_ga = 1.f, e_be = 0.f;
-  if (e_on) {
-    e_bi = p.bias[m0 + er];
-    if (filmb) { e_ga = filmb[m0 + er]; e_be = filmb[p.Cout + m0 + er]; }
-    if (vec4) {  // Nq is a multiple of 4 here, so the quad is complete
-      if (p.add) e_ad = *reinterpret_cast<const f32x4*>(p.add + eidx);
-      if (p.res) e_rs = *reinterpret_cast<const f32x4*>(p.res + eidx);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (j < e_n) {
-          if (p.add) e_ad[j] = p.add[eidx + j];
-          if (p.res) e_rs[j] = p.res[eidx + j];
-        }
-    }
-  }
 
   // ---- main loop: rounds of D groups; the last round issues nothing
   const int NR = NG / D;
@@ -756,61 +835,142 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
 #undef OU_ISSUE
 #undef OU_MMA
 
-  // ---- accumulators -> LDS (one slab per wave), reduce over the 8 K slices on read, fused epilogue, coalesced store
-  float* Es = smem;  // [WK][BM][EP]
+  DirectEpilogue<TN>::run(p, acc, smem, tid, kw, b, m0, n0);
+  if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Strided variant of the direct kernel: Conv1d with stride R and KW = G*R taps, pad = (G - 1)/2 * R -- the rate-change
+// (down) convs: k = s = r (G = 1), or 3r taps with the binomial anti-alias FIR folded into the weights (G = 3, see the
+// packer).  Output column q reads x[(q + g - pad/R) R + j], j < R, for its tap block g: R CONSECUTIVE samples, so a
+// lane fetches a whole tap block with one or two wide loads (dwordx2 / x4 [+ dword]) that are contiguous across the
+// lanes of a half wave -- a lane-strided dword per tap would cost R times the cache-line traffic.  One ring slot =
+// (channel pair, tap block): R A dwords + the wide B loads, R x TN MFMAs.
+// ---------------------------------------------------------------------------------------------------------
+template <int R>
+struct StridedRun {  // R consecutive floats as 16 / 8 / 4-byte pieces
+  static constexpr int N4 = R / 4, N2 = (R % 4) / 2, N1 = R % 2;
+  f32x4 q[N4 ? N4 : 1];
+  f32x2 d[N2 ? N2 : 1];
+  float s[N1 ? N1 : 1];
+  __device__ __forceinline__ void clear() {
+    for (int i = 0; i < (N4 ? N4 : 1); i++) q[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < (N2 ? N2 : 1); i++) d[i] = f32x2{0.f, 0.f};
+    s[0] = 0.f;
+  }
+  __device__ __forceinline__ float get(int k) const {
+    if (k < 4 * N4) return q[k / 4][k % 4];
+    if (k < 4 * N4 + 2 * N2) return d[(k - 4 * N4) / 2][(k - 4 * N4) % 2];
+    return s[0];
+  }
+};
+template <int R>
+__device__ __forceinline__ void strided_load(StridedRun<R>& v, int voff, u32x4 rsrc, int soff) {
+  constexpr int N4 = StridedRun<R>::N4, N2 = StridedRun<R>::N2, N1 = StridedRun<R>::N1;
+#pragma unroll
+  for (int i = 0; i < N4; i++)
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "+v"(v.q[i]) : "v"(voff), "s"(rsrc), "s"(soff), "n"(16 * i));
+#pragma unroll
+  for (int i = 0; i < N2; i++)
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4" : "+v"(v.d[i]) : "v"(voff), "s"(rsrc), "s"(soff), "n"(16 * N4 + 8 * i));
+  if constexpr (N1 == 1)
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "+v"(v.s[0]) : "v"(voff), "s"(rsrc), "s"(soff), "n"(16 * N4 + 8 * N2));
+}
+template <int R>
+__device__ __forceinline__ void strided_touch(StridedRun<R>& v) {  // "valid past this point" for the register allocator
+#pragma unroll
+  for (int i = 0; i < StridedRun<R>::N4; i++) asm volatile("" : "+v"(v.q[i]));
+#pragma unroll
+  for (int i = 0; i < StridedRun<R>::N2; i++) asm volatile("" : "+v"(v.d[i]));
+  if constexpr (StridedRun<R>::N1 == 1) asm volatile("" : "+v"(v.s[0]));
+}
+
+template <int R, int G, int TN>
+__global__ __launch_bounds__(512) void conv_direct_strided_kernel(ConvArgs p) {
+  constexpr int WK = 8, D = 4, BM = 32, BN = 32 * TN, KW = R * G;
+  constexpr int NLD = StridedRun<R>::N4 + StridedRun<R>::N2 + StridedRun<R>::N1;  // load instructions per run
+  constexpr int LPG = R + TN * NLD;                                               // ... per ring slot
+  static_assert(D * LPG <= 60, "loads in flight must fit vmcnt");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile_m, tile_n;
+  if (!direct_tile(p, tile_m, tile_n)) return;
+  const int n0 = tile_n * BN, m0 = tile_m * BM, b = blockIdx.z;
+  if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const int lhalf = lane >> 5, l31 = lane & 31;
+  const int CK = p.CK, lck = 31 - __clz(CK);
+  const int Tin = p.Tin, Mp = p.Mp;
+  const float alpha = p.act ? p.alpha_val : 1.0f;
+  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  const u32x4 rw = direct_desc(p.w, (unsigned)p.Cin * (unsigned)KW * (unsigned)Mp * 4u);
+  const int avo = (lhalf * Mp + m0 + l31) * 4;
+  // B offsets per (tap block, tile): frame (n0 + 32 j + n) + g - pad/R of R samples; whole frames are inside or outside
+  // the signal (the launcher checks Tin == Nq * R), outside -> past the buffer bounds -> zeros
+  int bvo[G][TN];
+#pragma unroll
+  for (int g = 0; g < G; g++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int fr = n0 + 32 * j + l31 + g - p.pad / R;
+      bvo[g][j] = (fr >= 0 && fr < p.Nq) ? (lhalf * Tin + fr * R) * 4 : (int)0x80000000;
+    }
+  const int NS = (p.Cin >> 4) * G;  // ring slots per wave: (pair, tap block), tap block fastest (launcher: multiple of D)
+  float av[D][R];
+  StridedRun<R> bv[D][TN];
+#pragma unroll
+  for (int d0 = 0; d0 < D; d0++) {
+#pragma unroll
+    for (int k = 0; k < R; k++) av[d0][k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; j++) bv[d0][j].clear();
+  }
+  floatx16 acc[TN];
 #pragma unroll
   for (int j = 0; j < TN; j++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-      Es[(kw * BM + row) * EP + 32 * j + l31] = acc[j][r];
-    }
-  __syncthreads();
-  const int up = p.up, Cout = p.Cout, Tout = p.Tout;
-  if (plain_epi) {
-    if (e_on) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(&Es[er * EP + eq]);
-#pragma unroll
-      for (int kk = 1; kk < WK; kk++) v += *reinterpret_cast<const f32x4*>(&Es[(kk * BM + er) * EP + eq]);
-      if (p.in_scale) v *= insc;
-      v += e_bi;
-      if (p.add) v = (v + e_ad) * p.add_scale;
-      if (filmb) v = e_ga * v + e_be;
-      if (p.res) v = (v + e_rs) * p.res_scale;
-      if (vec4) {
-        *reinterpret_cast<f32x4*>(p.y + eidx) = v;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (j < e_n) p.y[eidx + j] = v[j];
-      }
-    }
-  } else {
-    // transposed conv (phase GEMM): e -> (co, q, ph) with the output sample t = (n0 + q)*up + ph fastest across threads
-    constexpr int LBN = (BN == 64) ? 6 : 5;
-    const int co_first = up == 1 ? m0 : (int)__umulhi((unsigned)m0, p.magic_up);
-    const int nco = (up == 1 ? m_hi : (int)__umulhi((unsigned)m_hi, p.magic_up)) - co_first + 1;
-    const int total = nco * BN * up;
-    for (int e = tid; e < total; e += NT) {
-      const int rest = up == 1 ? e : (int)__umulhi((unsigned)e, p.magic_up);  // e / up
-      const int ph = e - rest * up;
-      const int q = rest & (BN - 1);
-      const int co = co_first + (rest >> LBN);
-      const int m = co * up + ph;
-      const int t = (n0 + q) * up + ph;
-      if (m < m0 || m > m_hi || (n0 + q) >= p.Nq || t >= Tout) continue;
-      float v = Es[(m - m0) * EP + q];
-#pragma unroll
-      for (int k = 1; k < WK; k++) v += Es[(k * BM + (m - m0)) * EP + q];
-      if (p.in_scale) v *= insc;
-      v += p.bias[co];
-      const size_t idx = ybase + (size_t)co * Tout + t;
-      if (p.add) v = (v + p.add[idx]) * p.add_scale;
-      if (filmb) v = filmb[co] * v + filmb[Cout + co];
-      if (p.res) v = (v + p.res[idx]) * p.res_scale;
-      p.y[idx] = v;
-    }
+    for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+  auto slot_pair = [&](int s) { return G == 1 ? s : s / G; };
+#define OU_ISSUE(s_, d)                                                                                     \
+  {                                                                                                         \
+    const int s = (s_);                                                                                     \
+    const int pr = slot_pair(s), g = s - pr * G;                                                            \
+    const int ci = 2 * (kw + WK * pr);                                                                      \
+    const int wrow = ((ci >> lck) * KW + g * R) * CK + (ci & (CK - 1));                                     \
+    _Pragma("unroll") for (int k = 0; k < R; k++)                                                           \
+      asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(av[d][k]) : "v"(avo), "s"(rw), "s"((wrow + k * CK) * Mp * 4)); \
+    int bsel[TN];                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < TN; j++) {                                                        \
+      bsel[j] = bvo[0][j];                                                                                  \
+      if (G > 1 && g == 1) bsel[j] = bvo[G > 1 ? 1 : 0][j];                                                 \
+      if (G > 2 && g == 2) bsel[j] = bvo[G > 2 ? 2 : 0][j];                                                 \
+      strided_load<R>(bv[d][j], bsel[j], rx, ci * Tin * 4);                                                 \
+    }                                                                                                       \
   }
+#define OU_MMA(d, out)                                                                                      \
+  {                                                                                                         \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPG));                                                 \
+    _Pragma("unroll") for (int k = 0; k < R; k++) asm volatile("" : "+v"(av[d][k]));                        \
+    _Pragma("unroll") for (int j = 0; j < TN; j++) strided_touch<R>(bv[d][j]);                              \
+    _Pragma("unroll") for (int k = 0; k < R; k++)                                                           \
+      _Pragma("unroll") for (int j = 0; j < TN; j++) {                                                      \
+        const float x = bv[d][j].get(k);                                                                    \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d][k], x >= 0.f ? x : alpha * x, acc[j], 0, 0, 0); \
+      }                                                                                                     \
+  }
+  OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
+  const int NR = NS / D;
+  for (int r = 0; r + 1 < NR; r++) {
+    const int s0 = r * D;
+    OU_MMA(0, 3); OU_ISSUE(s0 + 4, 0);
+    OU_MMA(1, 3); OU_ISSUE(s0 + 5, 1);
+    OU_MMA(2, 3); OU_ISSUE(s0 + 6, 2);
+    OU_MMA(3, 3); OU_ISSUE(s0 + 7, 3);
+  }
+  OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
+#undef OU_ISSUE
+#undef OU_MMA
+  DirectEpilogue<TN>::run(p, acc, smem, tid, kw, b, m0, n0);
   if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
@@ -826,10 +986,22 @@ static const DirectCfg kDirectCfgs[] = {
     {5, 1, 1, conv_direct_kernel<5, 1, 1>}, {5, 2, 1, conv_direct_kernel<5, 2, 1>},
 };
 
-// Launches the direct kernel when the layer fits it; hipErrorInvalidConfiguration = "use conv_mfma_kernel".
+struct StridedCfg {
+  int R, G, TN;
+  void (*kern)(ConvArgs);
+};
+// 64-column tiles only: with the same source, the 32-column instantiations come out of the register allocator with phi
+// copies of ring registers whose loads are still in flight (tools/check_isa.py) -- and a 32 x 64 tile per wave has the
+// same MFMA time per CU as two waves with 32 x 32 tiles, with half the A traffic.
+#define OU_STRIDED(R, G) {R, G, 2, conv_direct_strided_kernel<R, G, 2>}
+static const StridedCfg kStridedCfgs[] = {
+    OU_STRIDED(2, 1), OU_STRIDED(2, 3), OU_STRIDED(3, 1), OU_STRIDED(3, 3), OU_STRIDED(4, 1), OU_STRIDED(4, 3),
+    OU_STRIDED(5, 1), OU_STRIDED(5, 3), OU_STRIDED(8, 1),
+};
+
+// Launches a direct kernel when the layer fits one; hipErrorInvalidConfiguration = "use conv_mfma_kernel".
 static hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
-  if (a.stride != 1 || a.Cin % 16 || (a.in_scale != nullptr && a.act)) return hipErrorInvalidConfiguration;
-  if (a.KW != 1 && a.KW != 3 && a.KW != 5) return hipErrorInvalidConfiguration;
+  if (a.Cin % 16 || (a.in_scale != nullptr && a.act)) return hipErrorInvalidConfiguration;
   if ((long)a.Cin * a.Tin * 4 >= (1L << 31) || (long)a.Cin * a.KW * a.Mp * 4 >= (1L << 31)) return hipErrorInvalidConfiguration;
   const int npw = a.Cin / 16;  // channel pairs per wave
   const long gm = (a.M + 31) / 32;
@@ -837,21 +1009,38 @@ static hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t 
   const long b64 = gm * ((a.Nq + 63) / 64) * a.B;
   int tn = (a.force_cfg == 105 || (a.force_cfg < 0 && b64 >= (long)num_cu * 15 / 16)) ? 2 : 1;
   if (a.force_cfg == 106) tn = 1;
-  const DirectCfg* pick = nullptr;
-  for (const DirectCfg& c : kDirectCfgs) {
-    if (c.KW != a.KW || c.TN != tn) continue;
-    if (npw % (c.GP * 4)) continue;
-    pick = &c;
-    break;
+  void (*kern)(ConvArgs) = nullptr;
+  int variant = 0;
+  if (a.stride == 1) {
+    if (a.KW != 1 && a.KW != 3 && a.KW != 5) return hipErrorInvalidConfiguration;
+    for (const DirectCfg& c : kDirectCfgs) {
+      if (c.KW != a.KW || c.TN != tn || npw % (c.GP * 4)) continue;
+      kern = c.kern;
+      variant = 50 + 10 * tn + c.GP;  // 6x / 7x: stride-1 direct variants (profile records)
+      break;
+    }
+  } else {
+    // k = s = r, or 3r taps with the anti-alias FIR folded in; whole frames only
+    const int R = a.stride, G = a.KW / R;
+    if (a.up != 1 || a.KW != G * R || (G != 1 && G != 3) || a.pad != (G - 1) / 2 * R || a.Tin != a.Nq * R)
+      return hipErrorInvalidConfiguration;
+    if ((npw * G) % 4) return hipErrorInvalidConfiguration;
+    tn = 2;
+    for (const StridedCfg& c : kStridedCfgs) {
+      if (c.R != R || c.G != G || c.TN != tn) continue;
+      kern = c.kern;
+      variant = 80 + 10 * (tn - 1) + G;  // 8x / 9x: strided direct variants
+      break;
+    }
   }
-  if (!pick) return hipErrorInvalidConfiguration;
+  if (!kern) return hipErrorInvalidConfiguration;
   ConvArgs aa = a;
   const int BN = 32 * tn;
   aa.magic_up = a.up == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.up) + 1u;
   aa.grid_n = (a.Nq + BN - 1) / BN;
   aa.grid_m = (int)gm;
   {
-    const double xb = (double)a.Cin * a.Nq, wb = (double)a.M * a.Cin * a.KW;
+    const double xb = (double)a.Cin * a.Nq * a.stride, wb = (double)a.M * a.Cin * a.KW;
     aa.xcd_map = 0;
     if (aa.grid_m % 8 == 0 && wb >= xb) aa.xcd_map = 1;
     else if (aa.grid_n >= 8) aa.xcd_map = 2;
@@ -860,8 +1049,8 @@ static hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t 
   }
   const int gn_pad = aa.xcd_map == 2 ? (aa.grid_n + 7) / 8 * 8 : aa.grid_n;
   const size_t smem = (size_t)8 * 32 * (BN + 4) * 4;
-  if (cfg_out) *cfg_out = 50 + 10 * tn + pick->GP;  // 5x / 6x: direct kernel variants (profile records)
-  hipLaunchKernelGGL(pick->kern, dim3(gn_pad * aa.grid_m, 1, a.B), dim3(512), smem, stream, aa);
+  if (cfg_out) *cfg_out = variant;
+  hipLaunchKernelGGL(kern, dim3(gn_pad * aa.grid_m, 1, a.B), dim3(512), smem, stream, aa);
   return hipGetLastError();
 }
 
@@ -1208,10 +1397,13 @@ hipError_t launch_chain(const ChainArgs& a, int num_cu, hipStream_t st, int* var
 // =========================================================================================================
 __device__ __forceinline__ float prelu(float v, float a) { return v >= 0.f ? v : a * v; }
 
+// grid = (time tiles of 256, channel groups of IN_CONV_CG, batch): at batch 1 a (T/256)-block grid is one block per CU
+// with 32 dependent stores per thread; splitting the channels gives the dispatcher 4x the blocks for the same traffic
+constexpr int IN_CONV_CG = 8;
 __global__ __launch_bounds__(256) void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, const StepCoef* coef,
                                                       int coef_bstride, float* __restrict__ y, int C, int T, int KW) {
-  const int b = blockIdx.y;
+  const int b = blockIdx.z;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
   const float sc = coef ? coef[(size_t)b * coef_bstride].w_in : 1.f;  // universe.py:199,202
@@ -1222,7 +1414,8 @@ __global__ __launch_bounds__(256) void in_conv_kernel(const float* __restrict__ 
     int tt = t + k - pad;
     xv[k] = (k < KW && tt >= 0 && tt < T) ? x[(size_t)b * T + tt] * sc : 0.f;
   }
-  for (int c = 0; c < C; c++) {
+  const int c0 = blockIdx.y * IN_CONV_CG, c1 = min(C, c0 + IN_CONV_CG);
+  for (int c = c0; c < c1; c++) {
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 7; k++)
@@ -1234,8 +1427,8 @@ __global__ __launch_bounds__(256) void in_conv_kernel(const float* __restrict__ 
 hipError_t launch_in_conv(const float* x, const float* w, const float* bias, const StepCoef* coef, int coef_bstride,
                           float* y, int B, int C, int T, int KW, hipStream_t s) {
   if (KW > 7) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(in_conv_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, x, w, bias, coef, coef_bstride, y, C, T,
-                     KW);
+  hipLaunchKernelGGL(in_conv_kernel, dim3((T + 255) / 256, (C + IN_CONV_CG - 1) / IN_CONV_CG, B), dim3(256), 0, s, x, w,
+                     bias, coef, coef_bstride, y, C, T, KW);
   return hipGetLastError();
 }
 
@@ -1901,8 +2094,6 @@ __device__ __forceinline__ float tanhf_(float x) {
   // tanh(x) = 1 - 2/(1 + e^{2x});  e^{2x} -> inf gives 1, -> 0 gives -1
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
 }
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 constexpr unsigned GRU_SPIN_LIMIT = 4000000u;
 
 // Thread mapping: a direction's H hidden units are split over NWG = H/UPW workgroups of NT threads;
@@ -2262,13 +2453,25 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
         const unsigned long long* src = xq + (size_t)(step & 1) * H + cg * 4;
         unsigned spins = 0;
         while (true) {
+          // 16-byte loads = two granules each; asm: the compiler must neither cache the values nor pick the scope.
+          // sc1 = agent scope.  (sc0 -- workgroup scope -- polls were tried for clusters that share an XCD: they never
+          // observe the other CUs' publishes; kept behind OU_GRU_BACKOFF=3 for the record.)
+          if (plain && p.poll_backoff == 3) {
 #pragma unroll
-          for (int i = 0; i < NI; i++) {
-            // agent-scope (sc1) 16-byte loads = two granules each; asm: the compiler must neither cache nor widen the scope
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1"
-                         : "=v"(hv[2 * i]) : "v"(src), "n"(4 * LPU * i * 8) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1"
-                         : "=v"(hv[2 * i + 1]) : "v"(src), "n"(4 * LPU * i * 8 + 16) : "memory");
+            for (int i = 0; i < NI; i++) {
+              asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0"
+                           : "=v"(hv[2 * i]) : "v"(src), "n"(4 * LPU * i * 8) : "memory");
+              asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0"
+                           : "=v"(hv[2 * i + 1]) : "v"(src), "n"(4 * LPU * i * 8 + 16) : "memory");
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+              asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1"
+                           : "=v"(hv[2 * i]) : "v"(src), "n"(4 * LPU * i * 8) : "memory");
+              asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1"
+                           : "=v"(hv[2 * i + 1]) : "v"(src), "n"(4 * LPU * i * 8 + 16) : "memory");
+            }
           }
           gather_wait(hv);
           unsigned m = hv[0].y < hv[0].w ? hv[0].y : hv[0].w;

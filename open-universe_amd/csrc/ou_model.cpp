@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -37,8 +38,17 @@ std::string finish_conv(ConvL& L, Alloc& a) {
   L.w_off = a.take(L.w_floats());
   L.b_off = a.take(L.Cout);
   L.a_off = a.take(1);
-  if (L.fir_mode) { L.fir_off = a.take(L.fir_len); L.fbias_off = a.take(L.Cout); }
+  if (L.fir_mode == 1 || L.fir_mode == 2) { L.fir_off = a.take(L.fir_len); L.fbias_off = a.take(L.Cout); }
   return "";
+}
+
+// OU_FIR_FOLD (bit 0: down path, bit 1: up path): fold the anti-alias FIRs into the rate-change conv weights.  One
+// launch and one bandwidth pass less per rate change, for 3x that conv's FLOPs.  Measured on MI355X (PP16, B = 1) the
+// separate 6.5 us FIR pass is cheaper on every level (down: 17-24 vs 21-42 us, up: 17-22 vs 24-38 us), so the default
+// is 0; the plan and the packed blob depend on it, so it has to be the same when packing and when creating the model.
+static int fir_fold() {
+  static const int v = [] { const char* e = getenv("OU_FIR_FOLD"); return e ? atoi(e) : 0; }();
+  return v;
 }
 
 std::string make_conv(ConvL& L, Alloc& a, const std::string& name, int kind, int cin, int cout, int k, int rate,
@@ -55,11 +65,23 @@ std::string make_conv(ConvL& L, Alloc& a, const std::string& name, int kind, int
       break;
     case CK_DOWN:
       L.Cin = cin; L.Cout = cout; L.stride = rate; L.up = 1; L.KW = rate; L.pad = 0;
-      if (aa) { L.fir_mode = 1; L.fir_len = 2 * rate + 1; }
+      // anti-aliased (blocks.py:211-215): FIR_{2r+1} as its own bandwidth pass before the conv, or (fold) ONE strided
+      // conv with 3r taps and left pad r
+      if (aa) {
+        L.fir_len = 2 * rate + 1;
+        if (fir_fold() & 1) { L.fir_mode = 3; L.KW = 3 * rate; L.pad = rate; }
+        else L.fir_mode = 1;
+      }
       break;
     case CK_UP:
       L.Cin = cin; L.Cout = cout; L.stride = 1; L.up = rate; L.KW = 1; L.pad = 0;
-      if (aa) { L.fir_mode = 2; L.fir_len = 2 * rate + 1; }
+      // anti-aliased (blocks.py:217-221): FIR_{2r+1} as a bandwidth pass after the phase GEMMs, or (fold) r phase GEMMs
+      // with 3 taps each -- FIR(convT_{k=s=r}(.)) reaches one input frame to either side of an output frame
+      if (aa) {
+        L.fir_len = 2 * rate + 1;
+        if (fir_fold() & 2) { L.fir_mode = 4; L.KW = 3; L.pad = 1; }
+        else L.fir_mode = 2;
+      }
       break;
     case CK_ST:
       L.Cin = cin * rate; L.Cout = cout; L.KW = 1; L.stride = 1; L.pad = 0; L.up = 1;
@@ -373,40 +395,71 @@ struct Packer {
         break;
       }
       case CK_DOWN: {
-        // blocks.py:213-217: y = conv_{k=s=r}(FIR(prelu(x))) + bias.  The FIR (+PReLU) runs as its own
-        // bandwidth-bound pass (fir_mode 1); the conv keeps its native k = stride = r.
+        // blocks.py:213-217: y = conv_{k=s=r}(FIR(prelu(x))) + bias.  fir_mode 1: the FIR (+PReLU) runs as its own
+        // bandwidth-bound pass, the conv keeps its native k = stride = r.  fir_mode 3: the binomial FIR (2r + 1 taps,
+        // 'same' zero padding) is folded into the conv: W2[co][ci][m] = sum_{k + j = m} W[co][ci][k] f[j], m < 3r, the
+        // conv then reads x[q r + m - r] -- identical arithmetic up to the order of the fp32 sums.
         const int r = L.rate;
-        if (!eff_weight(p + ".conv", {L.Cout, L.Cin, r}, W)) return;
         bool aa = has(p + ".low_pass_filter.weights");
-        if ((L.fir_mode == 1) != aa) { if (err.empty()) { err = "anti-aliasing config/checkpoint mismatch at " + p; code = OU_ESHAPE; } return; }
+        if ((L.fir_mode == 1 || L.fir_mode == 3) != aa) { if (err.empty()) { err = "anti-aliasing config/checkpoint mismatch at " + p; code = OU_ESHAPE; } return; }
+        if (!eff_weight(p + ".conv", {L.Cout, L.Cin, r}, aa ? w : W)) return;
         const HostTensor* b = get(aa ? p + ".bias" : p + ".conv.bias", {L.Cout});
         if (!b) return;
         for (int i = 0; i < L.Cout; i++) bias[i] = b->data[i];
         if (aa) {
           const HostTensor* f = get(p + ".low_pass_filter.weights", {2 * r + 1});
           if (!f) return;
-          putf(L.fir_off, f->data.data(), 2 * r + 1);
+          if (L.fir_mode == 1) {
+            putf(L.fir_off, f->data.data(), 2 * r + 1);
+            W = w;
+          } else {
+            W.assign((size_t)L.Cout * L.Cin * 3 * r, 0.0);
+            for (size_t oc = 0; oc < (size_t)L.Cout * L.Cin; oc++)
+              for (int k = 0; k < r; k++)
+                for (int j = 0; j <= 2 * r; j++) W[oc * 3 * r + k + j] += w[oc * r + k] * (double)f->data[j];
+          }
         }
         break;
       }
       case CK_UP: {
         // blocks.py:217-225: y = FIR(convT_{k=s=r}(prelu(x))) + bias.  ConvTranspose1d weight is (in, out, k) with
         // weight-norm over dim 0 = in-channels; lowered to r phase-GEMMs: row m = co*r + ph, y[q*r + ph].
+        // fir_mode 2: FIR + manual bias as a pass after the conv.  fir_mode 4, FIR folded in: output sample q r + ph sees u[q r + ph + j - r], j <= 2r, i.e. input
+        // frames q - 1, q, q + 1:  W3[co r + ph][ci][dq + 1] = sum_{j : floor((ph + j - r) / r) = dq} f[j] W[ci][co][(ph + j - r) mod r]
         const int r = L.rate;
         if (!eff_weight(p + ".conv", {L.Cin, L.Cout, r}, w)) return;
         bool aa = has(p + ".low_pass_filter.weights");
-        if ((L.fir_mode == 2) != aa) { if (err.empty()) { err = "anti-aliasing config/checkpoint mismatch at " + p; code = OU_ESHAPE; } return; }
-        W.assign((size_t)L.M * L.Cin, 0.0);
-        for (int co = 0; co < L.Cout; co++)
-          for (int ph = 0; ph < r; ph++)
-            for (int ci = 0; ci < L.Cin; ci++) W[(size_t)(co * r + ph) * L.Cin + ci] = w[((size_t)ci * L.Cout + co) * r + ph];
-        if (aa) {
+        if ((L.fir_mode == 2 || L.fir_mode == 4) != aa) { if (err.empty()) { err = "anti-aliasing config/checkpoint mismatch at " + p; code = OU_ESHAPE; } return; }
+        if (aa && L.fir_mode == 2) {
           const HostTensor* f = get(p + ".low_pass_filter.weights", {2 * r + 1});
           const HostTensor* b = get(p + ".bias", {L.Cout});
           if (!f || !b) return;
+          W.assign((size_t)L.M * L.Cin, 0.0);
+          for (int co = 0; co < L.Cout; co++)
+            for (int ph = 0; ph < r; ph++)
+              for (int ci = 0; ci < L.Cin; ci++) W[(size_t)(co * r + ph) * L.Cin + ci] = w[((size_t)ci * L.Cout + co) * r + ph];
           putf(L.fir_off, f->data.data(), 2 * r + 1);
           putf(L.fbias_off, b->data.data(), L.Cout);  // added after the FIR; the conv's own bias stays 0
+        } else if (aa) {
+          const HostTensor* f = get(p + ".low_pass_filter.weights", {2 * r + 1});
+          const HostTensor* b = get(p + ".bias", {L.Cout});
+          if (!f || !b) return;
+          W.assign((size_t)L.M * L.Cin * 3, 0.0);
+          for (int co = 0; co < L.Cout; co++)
+            for (int ph = 0; ph < r; ph++)
+              for (int j = 0; j <= 2 * r; j++) {
+                const int sft = ph + j - r;                       // position relative to the start of frame q
+                const int dq = sft < 0 ? -1 : (sft >= r ? 1 : 0);
+                const int pp = sft - dq * r;
+                for (int ci = 0; ci < L.Cin; ci++)
+                  W[((size_t)(co * r + ph) * L.Cin + ci) * 3 + dq + 1] += (double)f->data[j] * w[((size_t)ci * L.Cout + co) * r + pp];
+              }
+          for (int i = 0; i < L.Cout; i++) bias[i] = b->data[i];  // the manual bias added after the FIR (the conv has none)
         } else {
+          W.assign((size_t)L.M * L.Cin, 0.0);
+          for (int co = 0; co < L.Cout; co++)
+            for (int ph = 0; ph < r; ph++)
+              for (int ci = 0; ci < L.Cin; ci++) W[(size_t)(co * r + ph) * L.Cin + ci] = w[((size_t)ci * L.Cout + co) * r + ph];
           const HostTensor* b = get(p + ".conv.bias", {L.Cout});
           if (!b) return;
           for (int i = 0; i < L.Cout; i++) bias[i] = b->data[i];

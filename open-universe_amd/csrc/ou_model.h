@@ -26,7 +26,9 @@ struct ConvL {
   size_t w_off = 0;       // float offsets into the blob
   size_t b_off = 0;       // bias[Cout]
   size_t a_off = 0;       // prelu slope (1 float) when act
-  int fir_mode = 0;       // anti-alias FIR (blocks.py:213-221): 0 none, 1 before the conv (down), 2 after it (up)
+  int fir_mode = 0;       // anti-alias FIR (blocks.py:213-221): 0 none; 1 / 2 = separate FIR pass before (down) / after
+                          // (up) the conv; folded into the conv weights by the packer (OU_FIR_FOLD, see make_conv):
+                          // 3 = down (KW = 3r, stride r, pad r), 4 = up (3-tap phase GEMMs)
   int fir_len = 0;        // 2*rate + 1 taps
   size_t fir_off = 0;     // taps
   size_t fbias_off = 0;   // fir_mode 2: the manual bias added after the FIR (the conv itself has none)

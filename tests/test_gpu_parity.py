@@ -363,3 +363,23 @@ def test_oracle_score_mode_vs_oracle_with_shared_noise(monkeypatch):
     out = run(lambda: model.enhance(mix.cuda(), n_steps=N, target=tgt.cuda(), fake_score_snr=20.0, keep_rms=True), "cuda:0")
     assert out.shape == ref.shape
     record("target_mode.vs_oracle", O.si_sdr(ref, out.cpu()), 100)
+
+
+@pytest.mark.parametrize("name,B,T", [("PP16", 2, 23517), ("PP24", 1, 30011), ("OR16", 3, 9000)])
+def test_direct_conv_kernels_match_lds_kernels(name, B, T, monkeypatch):
+    """The register-direct split-K kernels (stride 1: k1 / k3 / k5 and the 3-tap phase GEMMs of the FIR-folded up convs;
+    strided: k = s = r and the 3r-tap FIR-folded down convs) against the LDS-tiled kernel on the same packed weights
+    (OU_CONV_DIRECT=0): same K split over the 8 waves, different order inside a wave's slice -- fp32 rounding apart.
+    Ragged lengths put partial tiles and the zero-padded halo at both ends of every level."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(37, 3, B, Tp)
+    monkeypatch.setenv("OU_CONV_DIRECT", "0")
+    ref = run_enhance(model, mix, nz, n_steps=3)
+    n_ref = model.launch_stats()
+    monkeypatch.delenv("OU_CONV_DIRECT")
+    out = run_enhance(model, mix, nz, n_steps=3)
+    assert model.launch_stats() == n_ref
+    for b in range(B):
+        record(f"direct_vs_lds.{name}.{b}", O.si_sdr(ref[b], out[b]), 100)

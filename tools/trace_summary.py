@@ -27,7 +27,7 @@ def main(trace_csv, ou_trace_log=None):
         names = [l.split() for l in open(ou_trace_log) if l.startswith("OU_TRACE conv") or l.startswith("OU_TRACE chain")]
         # conv launches of the last enhance, in order, align with the last `per` trace lines
         last = [r for r in seg if any(k in r["Kernel_Name"] for k in ("conv_mfma_kernel", "conv_chain_kernel",
-                                                                      "conv_direct_kernel"))]
+                                                                      "conv_direct"))]
         lines = names[-len(last):]
         print(f"per-layer (last enhance, {len(last)} conv launches):")
         seen = set()
@@ -46,7 +46,7 @@ def main(trace_csv, ou_trace_log=None):
             if key in seen and not nm.startswith("cond."):
                 continue  # print the score layers once (first step)
             seen.add(key)
-            print(f"  {nm:28s} {' '.join(l[3:9]):60s} {d:8.1f} us {mflop/d/1e6:7.1f} TF/s" if d > 0 else nm)
+            print(f"  {nm:28s} {' '.join(l[3:9]):60s} {d:8.1f} us {mflop/d:7.1f} TF/s" if d > 0 else nm)
 
 
 if __name__ == "__main__":
