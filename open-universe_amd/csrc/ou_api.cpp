@@ -156,7 +156,13 @@ struct Runner {
     float res_scale = 1.f;
     const float* in_scale = nullptr;
     bool act = true;  // apply the layer's PReLU prologue (if it has one)
+    // up-path anti-alias FIR fused into the conv epilogue: taps, 2r + 1, the manual bias added after the FIR.  conv()
+    // sets `unsupported` instead of failing when no kernel with that epilogue fits the layer.
+    const float* fir = nullptr;
+    int fir_len = 0;
+    const float* fir_bias = nullptr;
   };
+  bool unsupported = false;
 
   Tensor conv(const ConvL& L, const Tensor& in, const std::string& name, const Epi& e, const Tensor* dst = nullptr) {
     int Nq, Tout;
@@ -172,6 +178,7 @@ struct Runner {
     a.add = e.add; a.add_scale = e.add_scale;
     a.film = e.film; a.film_bstride = e.film_bstride;
     a.res = e.res; a.res_scale = e.res_scale;
+    if (e.fir) { a.fir = e.fir; a.fir_len = e.fir_len; a.bias = e.fir_bias; }
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
     a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
@@ -191,7 +198,16 @@ struct Runner {
       h->prof.push_back(rec);
       h->prof_used++;
     }
-    chk(launch_conv(a, h->num_cu, st, &cfg), L.name.c_str());
+    unsupported = false;
+    {
+      const hipError_t le = launch_conv(a, h->num_cu, st, &cfg);
+      if (le == hipErrorNotSupported && e.fir) {  // the caller falls back to conv + launch_fir
+        if (a.prof) { h->prof.pop_back(); h->prof_used--; }
+        unsupported = true;
+        return out;
+      }
+      chk(le, L.name.c_str());
+    }
     if (a.prof) h->prof.back().cfg = cfg;
     h->last_cfg = cfg;
     if (h->trace)
@@ -249,12 +265,28 @@ struct Runner {
     Tensor hu = hin;
     if (Bk.dir == 2) {
       if (Bk.rc.fir_mode == 2) {
-        // PReLU -> transposed conv (r phase GEMMs) ; then FIR + bias + residual add as one bandwidth pass
-        Tensor u = conv(Bk.rc, hin, nm + ".upc", Epi());
+        // PReLU -> transposed conv (r phase GEMMs) -> FIR + bias + residual add: fused into the conv's epilogue where
+        // the direct kernel takes the layer, else as one bandwidth pass after it
+        Tensor u = alloc(nm + ".upc", Bk.rc.Cout, hin.T * Bk.rc.up);
         hu = alloc(nm + ".up", u.C, u.T);
-        if (!dry && ok())
-          chk(launch_fir(u.p, W(Bk.rc.fir_off), Bk.rc.fir_len, 0.f, 0, W(Bk.rc.fbias_off), res, kInvSqrt2, hu.p, B, u.C,
-                         u.T, st), "fir(up)");
+        if (!dry && ok()) {
+          const char* fenv = std::getenv("OU_FUSE_UPFIR");
+          const bool fuse = fenv ? std::atoi(fenv) != 0 : true;
+          bool done = false;
+          if (fuse) {
+            Epi e;
+            e.res = res; e.res_scale = kInvSqrt2;
+            e.fir = W(Bk.rc.fir_off); e.fir_len = Bk.rc.fir_len; e.fir_bias = W(Bk.rc.fbias_off);
+            conv(Bk.rc, hin, nm + ".up", e, &hu);
+            done = !unsupported;
+          }
+          if (!done) {
+            conv(Bk.rc, hin, nm + ".upc", Epi(), &u);
+            if (ok())
+              chk(launch_fir(u.p, W(Bk.rc.fir_off), Bk.rc.fir_len, 0.f, 0, W(Bk.rc.fbias_off), res, kInvSqrt2, hu.p, B,
+                             u.C, u.T, st), "fir(up)");
+          }
+        }
       } else {
         // (fir_mode 4: FIR folded into 3-tap phase GEMMs by the packer, its manual bias = the conv bias)
         Epi e;
@@ -351,9 +383,14 @@ struct Runner {
     GruArgs a;
     a.gx = gx.p; a.whh = W(G.whh_off); a.bhn = W(G.bhn_off); a.out = out.p; a.res = res; a.res_scale = res_scale;
     a.xchg = xchg; a.err = errw; a.epoch = epoch; a.B = B; a.T = in.T; a.H = G.H;
-    // kernel generation: the ring kernel (every wave gathers h straight from L2) is the latency-optimal one but its poll
-    // traffic grows with the number of clusters; batches > 1 stay on the polling-wave kernel (see gru_ring_kernel)
-    { const char* f = std::getenv("OU_GRU_V"); a.version = f ? std::atoi(f) : (B == 1 ? 2 : 1); }
+    // kernel generation: the ring kernel (every wave gathers h straight from L2) is the latency-optimal one; its poll
+    // traffic grows with the number of clusters, so it takes the launches of up to 256 workgroups (PP16: B <= 8) and the
+    // polling-wave kernel the rest (measured: 12.4 / 19.4 / 34.0 vs 13.2 / 20.2 / 34.6 ms per PP16 enhance at B = 2 / 4 /
+    // 8; OR16 B = 16 and PP24 B = 8: 65.1 / 112.7 vs 63.4 / 111.3 ms)
+    {
+      const char* f = std::getenv("OU_GRU_V");
+      a.version = f ? std::atoi(f) : (2 * B * (G.H / 16) <= 256 ? 2 : 1);
+    }
     { const char* f = std::getenv("OU_GRU_BMAX"); a.force_bmax = f ? std::atoi(f) : 0; }
     if (std::getenv("OU_GRU_TS")) a.tstamps = (long long*)(base + cap - (1u << 20));
     { const char* f = std::getenv("OU_GRU_UPW"); a.force_upw = f ? std::atoi(f) : 0; }

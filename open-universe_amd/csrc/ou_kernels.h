@@ -34,6 +34,12 @@ struct ConvArgs {
   int force_cfg = -1, force_sc = 0;    // tuning overrides (ou_bench_conv)
   int force_xcd_map = -1;              // tuning: 0 / 1 / 2
   int direct = 1;                      // 0: never use the register-direct split-K kernel (OU_CONV_DIRECT=0)
+  // Anti-alias FIR of the up path fused into the epilogue (direct kernel, up > 1, KW == 1 only; launch_conv returns
+  // hipErrorNotSupported otherwise and the caller runs launch_fir after a plain launch):
+  //   y = FIR_{2 up + 1}(u) + bias ; y = res ? (y + res) * res_scale : y,   u = the transposed conv's output WITHOUT bias
+  const float* fir = nullptr;
+  int fir_len = 0;
+  int tile_bm = 32, tile_bn = 0, tile_halo = 0;  // filled by launch_conv_direct: rows / columns a tile advances by, left halo
   int dbg = 0;                         // phase ablation switches (tuning only)
   long long* tstamps = nullptr;        // per-wave phase cycle counts (tuning only)
   unsigned long long* prof = nullptr;  // measurement: {min block start, ~max block end} in s_memrealtime ticks (10 ns)

@@ -512,6 +512,7 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
       if (e != hipErrorInvalidConfiguration) return e;
     }
   }
+  if (a.fir) return hipErrorNotSupported;  // only the direct kernel has the fused FIR epilogue
   int pick = -1;
   for (int i = 0; i < kNumConvCfgs; i++) {
     const ConvCfg& c = kConvCfgs[i];
@@ -648,31 +649,85 @@ struct DirectEpilogue {
   // latency per launch but keeps 11-36 more registers live across the main loop: the 64-column kernels went from
   // 97-125 to 136-165 VGPRs, i.e. from two resident workgroups per CU to one, and the 504-block latent layers got 25-30 %
   // slower.  Occupancy wins.
+  // Up path with its anti-alias FIR (blocks.py:217-225): y = FIR_{2R+1}(u) + bias, R = up, u = convT output.  The tile
+  // holds MB = (32 / R) * R rows = whole output channels (all R phases) and BN frames of which the outer two are halo:
+  // an output sample needs u up to R samples = one frame to either side.  Same summation order as the separate
+  // launch_fir pass (8 K slices in order, taps in order), so results are bit-identical to it.
+  template <int R>
+  static __device__ __forceinline__ void fir_up(const ConvArgs& p, float* Es, int tid, int m0, int n0, size_t ybase,
+                                                float insc) {
+    constexpr int LBN = (BN == 64) ? 6 : 5, MB = (32 / R) * R, NTAP = 2 * R + 1;
+    constexpr int SPAN = (BN - 2) * R;             // output samples per channel of this tile
+    constexpr int TOTAL = (MB / R) * SPAN, EPT = (TOTAL + NT - 1) / NT;
+    float f[NTAP];
+#pragma unroll
+    for (int j = 0; j < NTAP; j++) f[j] = p.fir[j];
+    // the residual / bias operands of this thread's outputs first: their latency overlaps the reduction below
+    float rs[EPT], bi[EPT];
+    size_t idx[EPT];
+    int tl_[EPT], cl_[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+      const int e = tid + k * NT;
+      const int cl = e / SPAN, tl = e - cl * SPAN + R;  // local channel, local sample (frames 1 .. BN - 2)
+      const int co = m0 / R + cl;
+      const long t = (long)n0 * R + tl;
+      const bool on = e < TOTAL && co < p.Cout && t >= 0 && t < p.Tout;
+      cl_[k] = on ? cl : -1; tl_[k] = tl;
+      idx[k] = on ? ybase + (size_t)co * p.Tout + (size_t)t : 0;
+      bi[k] = on ? p.bias[co] : 0.f;
+      rs[k] = (on && p.res) ? p.res[idx[k]] : 0.f;
+    }
+    for (int e = tid; e < BM * BN; e += NT) {  // reduce the K slices in place; zero outside the signal ('same' padding)
+      const int row = e >> LBN, q = e & (BN - 1);
+      float v = Es[row * EP + q];
+#pragma unroll
+      for (int k = 1; k < WK; k++) v += Es[(k * BM + row) * EP + q];
+      if (p.in_scale) v *= insc;
+      const int fr = n0 + q;
+      if (row >= MB || m0 + row >= p.M || fr < 0 || fr >= p.Nq) v = 0.f;
+      Es[row * EP + q] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+      if (cl_[k] < 0) continue;
+      const int tau = tl_[k] - R;  // >= 0
+      int fq = tau / R, ph = tau - fq * R;
+      const float* zrow = Es + (cl_[k] * R) * EP;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < NTAP; j++) {
+        acc = fmaf(f[j], zrow[ph * EP + fq], acc);
+        if (++ph == R) { ph = 0; fq++; }
+      }
+      acc += bi[k];
+      if (p.res) acc = (acc + rs[k]) * p.res_scale;
+      p.y[idx[k]] = acc;
+    }
+  }
+
   static __device__ __forceinline__ void run(const ConvArgs& p, const floatx16 (&acc)[TN], float* Es, int tid, int kw,
                                              int b, int m0, int n0) {
     const int lane = tid & 63, lhalf = lane >> 5, l31 = lane & 31;
-#pragma unroll
-    for (int j = 0; j < TN; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-        Es[(kw * BM + row) * EP + 32 * j + l31] = acc[j][r];
-      }
-    __syncthreads();
     const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
     int m_hi = m0 + BM - 1;
     if (m_hi > p.M - 1) m_hi = p.M - 1;
     const size_t ybase = (size_t)b * p.Cout * p.Tout;
     const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
-    if (p.up == 1) {
-      const int eq = (tid % C4) * 4, er = tid / C4;
-      if (er >= BM || m0 + er > m_hi || n0 + eq >= p.Nq) return;
-      const int m = m0 + er;
-      const size_t eidx = ybase + (size_t)m * p.Tout + n0 + eq;
-      int e_n = p.Nq - (n0 + eq);
-      if (e_n > 4) e_n = 4;
-      const bool vec4 = (p.Tout & 3) == 0;  // (then Nq is a multiple of 4 too and the quad is complete)
-      f32x4 ad = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+    // up == 1: this thread's output quad and its global operands -- the loads go out before the accumulators are
+    // staged, so their latency overlaps the LDS traffic and the barrier
+    const bool plain = p.up == 1 && !p.fir;
+    const int eq = (tid % C4) * 4, er = tid / C4;
+    const bool e_on = plain && er < BM && m0 + er <= m_hi && n0 + eq < p.Nq;
+    const int m = m0 + er;
+    const size_t eidx = ybase + (size_t)m * p.Tout + n0 + eq;
+    int e_n = p.Nq - (n0 + eq);
+    if (e_n > 4) e_n = 4;
+    const bool vec4 = (p.Tout & 3) == 0;  // (then Nq is a multiple of 4 too and the quad is complete)
+    f32x4 ad = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+    float bi = 0.f, ga = 1.f, be = 0.f;
+    if (e_on) {
       if (vec4) {
         if (p.add) ad = *reinterpret_cast<const f32x4*>(p.add + eidx);
         if (p.res) rs = *reinterpret_cast<const f32x4*>(p.res + eidx);
@@ -683,8 +738,30 @@ struct DirectEpilogue {
           if (p.res && j < e_n) rs[j] = p.res[eidx + j];
         }
       }
-      const float bi = p.bias[m];
-      const float ga = filmb ? filmb[m] : 1.f, be = filmb ? filmb[p.Cout + m] : 0.f;
+      bi = p.bias[m];
+      if (filmb) { ga = filmb[m]; be = filmb[p.Cout + m]; }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+        Es[(kw * BM + row) * EP + 32 * j + l31] = acc[j][r];
+      }
+    // LDS-only hand-over: wait for the ds_writes, not for the global loads above (__syncthreads would)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (p.fir) {
+      switch (p.up) {
+        case 2: fir_up<2>(p, Es, tid, m0, n0, ybase, insc); break;
+        case 3: fir_up<3>(p, Es, tid, m0, n0, ybase, insc); break;
+        case 4: fir_up<4>(p, Es, tid, m0, n0, ybase, insc); break;
+        case 5: fir_up<5>(p, Es, tid, m0, n0, ybase, insc); break;
+        default: fir_up<8>(p, Es, tid, m0, n0, ybase, insc); break;
+      }
+      return;
+    }
+    if (p.up == 1) {
+      if (!e_on) return;
       f32x4 v = *reinterpret_cast<const f32x4*>(&Es[er * EP + eq]);
 #pragma unroll
       for (int kk = 1; kk < WK; kk++) v += *reinterpret_cast<const f32x4*>(&Es[(kk * BM + er) * EP + eq]);
@@ -775,7 +852,7 @@ __device__ __forceinline__ void direct_mma(float (&av)[NA], float (&bv)[NB], flo
 
 template <int KW, int TN, int GP>
 __global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
-  constexpr int D = 4, BM = 32, BN = 32 * TN;
+  constexpr int D = 4;
   constexpr int NA = GP * KW, NB = GP * KW * TN;  // A / B dwords per group
   static_assert(D * (NA + NB) <= 60, "loads in flight must fit vmcnt");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -783,7 +860,9 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
   const int kw = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile_m, tile_n;
   if (!direct_tile(p, tile_m, tile_n)) return;
-  const int n0 = tile_n * BN, m0 = tile_m * BM, b = blockIdx.z;
+  // (tile_bn / tile_bm / tile_halo: BN, 32, 0 -- except with the fused up-path FIR, whose tiles overlap by a frame on
+  // either side and hold whole output channels only, see DirectEpilogue)
+  const int n0 = tile_n * p.tile_bn - p.tile_halo, m0 = tile_m * p.tile_bm, b = blockIdx.z;
   if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 
   const int lhalf = lane >> 5, l31 = lane & 31;
@@ -820,22 +899,38 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
     for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
 #define OU_ISSUE(g, d) direct_issue<KW, TN, GP>(av[d], bv[d], (g), kw, Tin, Mp, CK, lck, avo, bvo, rx, rw)
 #define OU_MMA(d, out) direct_mma<NA, NB, TN, out>(av[d], bv[d], acc, alpha)
+  // tuning only (OU_TS): per-wave phase stamps -- {start (10 ns ticks), cycles: prologue, first data, main loop, drain,
+  // epilogue, -, end (ticks)}
+  const bool ts_on = p.tstamps != nullptr;
+  long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, r0 = 0;
+  if (ts_on) { r0 = (long long)__builtin_amdgcn_s_memrealtime(); c0 = __builtin_readcyclecounter(); }
   OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
+  if (ts_on) c1 = __builtin_readcyclecounter();
 
   // ---- main loop: rounds of D groups; the last round issues nothing
   const int NR = NG / D;
   for (int r = 0; r + 1 < NR; r++) {
     const int g = r * D;
-    OU_MMA(0, 3); OU_ISSUE(g + 4, 0);
+    OU_MMA(0, 3);
+    if (ts_on && r == 0) c2 = __builtin_readcyclecounter();
+    OU_ISSUE(g + 4, 0);
     OU_MMA(1, 3); OU_ISSUE(g + 5, 1);
     OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
     OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
   }
+  if (ts_on) c3 = __builtin_readcyclecounter();
   OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
+  if (ts_on) c4 = __builtin_readcyclecounter();
 #undef OU_ISSUE
 #undef OU_MMA
 
   DirectEpilogue<TN>::run(p, acc, smem, tid, kw, b, m0, n0);
+  if (ts_on && lane == 0) {
+    const long long c5 = __builtin_readcyclecounter();
+    long long* o = p.tstamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + kw) * 8;
+    o[0] = r0; o[1] = c1 - c0; o[2] = (NR > 1 ? c2 : c4) - c1; o[3] = NR > 1 ? c3 - c2 : 0; o[4] = c4 - c3; o[5] = c5 - c4;
+    o[6] = 0; o[7] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
   if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
@@ -1011,6 +1106,26 @@ static hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t 
   if (a.force_cfg == 106) tn = 1;
   void (*kern)(ConvArgs) = nullptr;
   int variant = 0;
+  int bm_step = 32, halo = 0;
+  long gm_fir = gm;
+  if (a.fir) {  // fused up-path FIR: whole output channels per tile, one halo frame either side
+    if ((a.up != 2 && a.up != 3 && a.up != 4 && a.up != 5 && a.up != 8) || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.fir_len != 2 * a.up + 1 || a.add || a.film)
+      return hipErrorNotSupported;
+    bm_step = (32 / a.up) * a.up;
+    halo = 1;
+    gm_fir = (a.M + bm_step - 1) / bm_step;
+    const long b62 = gm_fir * ((a.Nq + 61) / 62) * a.B;
+    tn = (a.force_cfg == 105 || (a.force_cfg < 0 && b62 >= (long)num_cu * 15 / 16)) ? 2 : 1;
+    if (a.force_cfg == 106) tn = 1;
+    // The halo costs tiles (62 of 64 / 30 of 32 columns, whole channels only).  All blocks of these launches start
+    // together -- 2 (64-column) or 4 (32-column) resident per CU -- so a launch takes ceil(blocks / slots) rounds, and
+    // one more round costs more than the separate FIR pass saves (measured, PP16 B = 1: 512 -> 528 blocks at the
+    // T/32 level: 10.8 + 6.3 us unfused, 17.9 us fused).  Fuse only when the round count stays.
+    const long slots = (long)num_cu * (tn == 2 ? 2 : 4);
+    const long fused = gm_fir * ((a.Nq + 32 * tn - 3) / (32 * tn - 2)) * a.B;
+    const long plain = gm * ((a.Nq + 32 * tn - 1) / (32 * tn)) * a.B;
+    if (a.force_cfg < 0 && (fused + slots - 1) / slots > (plain + slots - 1) / slots) return hipErrorNotSupported;
+  }
   if (a.stride == 1) {
     if (a.KW != 1 && a.KW != 3 && a.KW != 5) return hipErrorInvalidConfiguration;
     for (const DirectCfg& c : kDirectCfgs) {
@@ -1033,12 +1148,13 @@ static hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t 
       break;
     }
   }
-  if (!kern) return hipErrorInvalidConfiguration;
+  if (!kern) return a.fir ? hipErrorNotSupported : hipErrorInvalidConfiguration;
   ConvArgs aa = a;
   const int BN = 32 * tn;
   aa.magic_up = a.up == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.up) + 1u;
-  aa.grid_n = (a.Nq + BN - 1) / BN;
-  aa.grid_m = (int)gm;
+  aa.tile_bm = bm_step; aa.tile_bn = BN - 2 * halo; aa.tile_halo = halo;
+  aa.grid_n = (a.Nq + aa.tile_bn - 1) / aa.tile_bn;
+  aa.grid_m = (int)gm_fir;
   {
     const double xb = (double)a.Cin * a.Nq * a.stride, wb = (double)a.M * a.Cin * a.KW;
     aa.xcd_map = 0;
@@ -1646,19 +1762,35 @@ __global__ __launch_bounds__(1024) void pad_normalize_kernel(const float* __rest
   __shared__ double shd[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* xb = mix + (size_t)b * T_raw;
+  // (one CU per utterance and three dependent passes: the loops are unrolled by hand so that 8 loads are in flight per
+  // thread -- same elements per thread, same order of the double sums as the plain loop)
+  constexpr int U = 8;
   double s = 0, sq = 0;
-  for (int t = tid; t < T_raw; t += 1024) {
-    double v = xb[t];
-    s += v;
-    sq += v * v;
+  {
+    int t = tid;
+    for (; t + (U - 1) * 1024 < T_raw; t += U * 1024) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = xb[t + u * 1024];
+#pragma unroll
+      for (int u = 0; u < U; u++) { const double d = v[u]; s += d; sq += d * d; }
+    }
+    for (; t < T_raw; t += 1024) { const double d = xb[t]; s += d; sq += d * d; }
   }
   s = block_sum(s, shd);
   sq = block_sum(sq, shd);
   const float mean = (float)(s / T_pad);  // norm.py:62  (mean over the padded signal)
   double ss = 0;
-  for (int t = tid; t < T_raw; t += 1024) {
-    double d = (double)(xb[t] - mean);
-    ss += d * d;
+  {
+    int t = tid;
+    for (; t + (U - 1) * 1024 < T_raw; t += U * 1024) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = xb[t + u * 1024];
+#pragma unroll
+      for (int u = 0; u < U; u++) { const double d = (double)(v[u] - mean); ss += d * d; }
+    }
+    for (; t < T_raw; t += 1024) { const double d = (double)(xb[t] - mean); ss += d * d; }
   }
   ss = block_sum(ss, shd);
   ss += (double)(T_pad - T_raw) * (double)(0.f - mean) * (double)(0.f - mean);
@@ -1666,6 +1798,7 @@ __global__ __launch_bounds__(1024) void pad_normalize_kernel(const float* __rest
   sd = fmaxf(sd, 1e-5f);
   const float gain = level / sd;
   float* yb = y + (size_t)b * T_pad;
+#pragma unroll 8
   for (int t = tid; t < T_pad; t += 1024) {
     int tr = t - pad_left;
     float v = (tr >= 0 && tr < T_raw) ? xb[tr] : 0.f;
@@ -1703,9 +1836,11 @@ __global__ __launch_bounds__(1024) void post_kernel(const float* __restrict__ x,
     g = stats[b * 4 + 2] / x_rms;
   }
   float mx = 0.f;
+#pragma unroll 8
   for (int t = tid; t < T_raw; t += 1024) mx = fmaxf(mx, fabsf(xb[t] * g));
   mx = block_max(mx, shf);
   const bool div = peak_guard && mx > 1.0f;  // universe.py:356-357
+#pragma unroll 8
   for (int t = tid; t < T_raw; t += 1024) {
     float v = xb[t];
     if (keep_rms) v = v * g;
@@ -2481,16 +2616,30 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
             m = a < m ? a : m;
           }
           if (__builtin_amdgcn_ballot_w64(m != want) == 0ull) break;  // wave-uniform: the wave needs all H values anyway
-          // every wave polls all H granules: 32 line requests per wave and round.  Fine for the few clusters of a batch-1
-          // call (~10-25 % of the L2 request rate); with dozens of clusters the polls alone saturate the L2 channels and
-          // progress collapses (measured: OR16, B = 16 -> multi-second stalls), which is why launch_gru() keeps larger
-          // batches on the polling-wave kernel.  Back off if a wait gets long anyway.
+          // every wave polls all H granules: 32 line requests per wave and round -- a few per cent of the L2 request
+          // rate for the two clusters of a batch-1 call; with dozens of clusters the polling-wave kernel (one poller per
+          // workgroup) is ahead again, see the version rule in ou_api.cpp.  Back off if a wait gets long.
           ++spins;
           if ((spins & 63u) == 0u) __builtin_amdgcn_s_sleep(4);
+          // Safety net: a plain store carries no visibility deadline.  Under load -- a second process on the device
+          // (tests/test_gpu_distributed.py: 1 run in 4 timed out), or dozens of clusters (OR16, B = 16: multi-second stalls)
+          // -- a publish was seen to stay invisible to the other CUs for good.  Everybody ends up waiting then, the wave
+          // whose store is missing too: after ~0.5 ms of waiting every wave repeats its last publish (tag epoch + step) as
+          // a system-scope write-through store.  Never taken in a healthy batch-1 run.
+          if ((spins & 1023u) == 1023u && fin) {
+            const unsigned long long gran = ((unsigned long long)want << 32) | (unsigned)__float_as_int(hprev);
+            unsigned long long* dst = xq + (size_t)(step & 1) * H + unit;
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(gran) : "memory");
+          }
           if (spins > GRU_SPIN_LIMIT) {
             atomicOr(p.err, 4u);  // diagnostics: who waited for what
             p.err[12] = (unsigned)cluster; p.err[13] = (unsigned)g; p.err[14] = (unsigned)step; p.err[15] = m; p.err[16] = want;
             p.err[17] = xcc; p.err[18] = plain ? 1u : 0u; p.err[19] = (unsigned)bid;
+            {  // has the workgroup been moved since the rendezvous?  (context save / restore under a second process)
+              unsigned now;
+              asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(now));
+              p.err[11] = 0x100u | (now & 0xFu);
+            }
             step = T;
             break;
           }

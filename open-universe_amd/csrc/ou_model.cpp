@@ -47,8 +47,8 @@ std::string finish_conv(ConvL& L, Alloc& a) {
 // separate 6.5 us FIR pass is cheaper on every level (down: 17-24 vs 21-42 us, up: 17-22 vs 24-38 us), so the default
 // is 0; the plan and the packed blob depend on it, so it has to be the same when packing and when creating the model.
 static int fir_fold() {
-  static const int v = [] { const char* e = getenv("OU_FIR_FOLD"); return e ? atoi(e) : 0; }();
-  return v;
+  const char* e = getenv("OU_FIR_FOLD");
+  return e ? atoi(e) : 0;
 }
 
 std::string make_conv(ConvL& L, Alloc& a, const std::string& name, int kind, int cin, int cout, int k, int rate,

@@ -123,10 +123,11 @@ class Universe:
         self._status_event = None
         v = int(self._status_host[0])
         if v:
+            diag = self._ws[:80].view(torch.int32).cpu().tolist()  # who waited for what (see gru_ring_kernel)
             self._status_host.zero_()
             self._ws[:4].zero_()  # the device word is sticky until cleared
-            raise RuntimeError(f"device-side timeout in the GRU cluster exchange (status word {v}); "
-                               "the output of that call is invalid")
+            raise RuntimeError(f"device-side timeout in the GRU cluster exchange (status word {v}, diagnostics "
+                               f"{diag[8:20]}); the output of that call is invalid")
 
     def _poll_deferred_status(self):
         """Free-running mode: look at the status copy of an EARLIER call once its event has completed."""

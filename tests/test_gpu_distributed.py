@@ -76,7 +76,13 @@ def _run(cmd, timeout=900):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:  # keep the whole story: pytest's assertion message truncates it
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "failed_subprocess.txt"), "a") as f:
+            f.write(f"==== {' '.join(map(str, cmd))}\n---- stdout\n{r.stdout}\n---- stderr\n{r.stderr}\n")
+    return r
 
 
 def test_cli_under_two_ranks_equals_one_rank(tmp_path):

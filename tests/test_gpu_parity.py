@@ -367,9 +367,9 @@ def test_oracle_score_mode_vs_oracle_with_shared_noise(monkeypatch):
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 2, 23517), ("PP24", 1, 30011), ("OR16", 3, 9000)])
 def test_direct_conv_kernels_match_lds_kernels(name, B, T, monkeypatch):
-    """The register-direct split-K kernels (stride 1: k1 / k3 / k5 and the 3-tap phase GEMMs of the FIR-folded up convs;
-    strided: k = s = r and the 3r-tap FIR-folded down convs) against the LDS-tiled kernel on the same packed weights
-    (OU_CONV_DIRECT=0): same K split over the 8 waves, different order inside a wave's slice -- fp32 rounding apart.
+    """The register-direct split-K kernels (stride 1: k1 / k3 / k5 and the phase GEMMs of the up convs with their fused
+    FIR epilogue; strided: k = s = r) against the LDS-tiled kernel on the same packed weights (OU_CONV_DIRECT=0): same K
+    split over the 8 waves, different order inside a wave's slice -- fp32 rounding apart.
     Ragged lengths put partial tiles and the zero-padded halo at both ends of every level."""
     model, spec, sd = get_model(name)
     mix = synth_mix(spec, B, T)
@@ -377,9 +377,42 @@ def test_direct_conv_kernels_match_lds_kernels(name, B, T, monkeypatch):
     nz = noise_list(37, 3, B, Tp)
     monkeypatch.setenv("OU_CONV_DIRECT", "0")
     ref = run_enhance(model, mix, nz, n_steps=3)
-    n_ref = model.launch_stats()
     monkeypatch.delenv("OU_CONV_DIRECT")
     out = run_enhance(model, mix, nz, n_steps=3)
-    assert model.launch_stats() == n_ref
     for b in range(B):
         record(f"direct_vs_lds.{name}.{b}", O.si_sdr(ref[b], out[b]), 100)
+
+
+@pytest.mark.parametrize("name,B,T", [("PP16", 2, 23517), ("PP24", 1, 30011), ("PP16", 1, 64000)])
+def test_fused_up_fir_epilogue_is_bit_identical_to_the_fir_pass(name, B, T, monkeypatch):
+    """Up path: FIR + bias + residual fused into the transposed conv's epilogue (overlapping tiles, one halo frame) vs
+    the separate bandwidth pass after it: same summation order, so the whole enhance is bit-identical -- with fewer
+    launches."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(41, 2, B, Tp)
+    monkeypatch.setenv("OU_FUSE_UPFIR", "0")
+    ref = run_enhance(model, mix, nz, n_steps=2)
+    n_ref = model.launch_stats()
+    monkeypatch.delenv("OU_FUSE_UPFIR")
+    out = run_enhance(model, mix, nz, n_steps=2)
+    n_out = model.launch_stats()
+    assert torch.equal(ref, out)
+    assert sum(n_out) < sum(n_ref), (n_out, n_ref)
+
+
+def test_folded_fir_weights_match_separate_fir_pass(monkeypatch):
+    """OU_FIR_FOLD=3: the packer folds the anti-alias FIRs into the rate-change conv weights (3r-tap strided convs, 3-tap
+    phase GEMMs); the plan and the blob differ, the arithmetic only in the order of the fp32 sums."""
+    model, spec, sd = get_model("PP16")
+    B, T = 2, 16000
+    mix = synth_mix(spec, B, T)
+    nz = noise_list(43, 2, B, T + (spec.tot_ds - T % spec.tot_ds))
+    ref = run_enhance(model, mix, nz, n_steps=2)
+    monkeypatch.setenv("OU_FIR_FOLD", "3")
+    folded = type(model)(spec, state_dict=sd, device="cuda:0")
+    out = run_enhance(folded, mix, nz, n_steps=2)
+    assert sum(folded.launch_stats()) < sum(model.launch_stats())
+    for b in range(B):
+        record(f"fir_fold.{b}", O.si_sdr(ref[b], out[b]), 100)

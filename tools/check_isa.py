@@ -5,8 +5,8 @@ between the load and the s_waitcnt that covers it -- a register copy made by the
 the register -- reads or clobbers data in flight, and the result then depends on the register allocation of the day.
 This walks the control-flow graph of the device ISA of every kernel whose name matches, keeps the queue of outstanding
 VMEM operations per path (loads return in order; `s_waitcnt vmcnt(N)` retires all but the newest N) and reports any
-instruction that reads or writes a VGPR whose load is still in flight (operand rings and the epilogue prefetches);
-stores and atomics are counted for vmcnt.  Paths are explored depth-first through both
+instruction that reads or writes a VGPR whose inline-asm load is still in flight; the compiler's own loads, stores and
+atomics are counted for vmcnt only (the compiler waits for those itself).  Paths are explored depth-first through both
 arms of every conditional branch; a block is re-entered until its entry state repeats.
 
 Usage: python tools/check_isa.py file.s [name-pattern ...]      exit status 1 when a hazard is found
@@ -28,7 +28,12 @@ def regs(tok):
 def parse(lines):
     """-> (instrs, labels): instrs = [(lineno, op, args, text)], labels = {name: index into instrs}"""
     instrs, labels = [], {}
+    in_asm = False
     for ln, text in lines:
+        if "#ASMSTART" in text:
+            in_asm = True
+        elif "#ASMEND" in text:
+            in_asm = False
         t = text.split(";")[0].strip()
         if not t or t.startswith("."):
             m = re.match(r"^(\.LBB\w+):", t)
@@ -38,7 +43,7 @@ def parse(lines):
         if t.endswith(":"):
             continue
         parts = t.replace(",", " ").split()
-        instrs.append((ln, parts[0], parts[1:], t))
+        instrs.append((ln, parts[0], parts[1:], t, in_asm))
     return instrs, labels
 
 
@@ -52,7 +57,7 @@ def check(instrs, labels, max_visits=6):
         pending = list(pending)
         while pc < len(instrs):
             steps += 1
-            ln, op, args, t = instrs[pc]
+            ln, op, args, t, in_asm = instrs[pc]
             if op == "s_endpgm":
                 break
             if op == "s_waitcnt":
@@ -91,7 +96,9 @@ def check(instrs, labels, max_visits=6):
             if hit:
                 bad[ln] = (t, sorted(hit))
             if is_load:
-                dst = frozenset(regs(args[0])) if (args and "lds" not in args) else frozenset()
+                # only inline-asm loads are invisible to the compiler's own wait-count insertion; its own loads are
+                # covered by the waits it places (extra asm loads in the queue can only make those waits longer)
+                dst = frozenset(regs(args[0])) if (in_asm and args and "lds" not in args) else frozenset()
                 pending.append(dst)
             elif is_store:
                 pending.append(frozenset())
