@@ -172,6 +172,7 @@ struct Runner {
     if (dry || !ok()) return out;
     ConvArgs a;
     a.x = in.p; a.w = W(L.w_off); a.bias = W(L.b_off); a.y = out.p;
+    if (L.KWP) a.wd = W(L.wd_off);
     a.in_scale = e.in_scale;
     a.act = (L.act && e.act) ? 1 : 0;
     a.alpha_val = a.act ? h->alphas[L.a_off] : 0.f;
@@ -184,7 +185,7 @@ struct Runner {
     a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
     { const char* d = std::getenv("OU_DBG"); a.dbg = d ? std::atoi(d) : 0; }
     { const char* d = std::getenv("OU_XCD_MAP"); a.force_xcd_map = d ? std::atoi(d) : -1; }
-    { const char* d = std::getenv("OU_CONV_DIRECT"); a.direct = d ? std::atoi(d) : 1; }
+    { const char* d = std::getenv("OU_CONV_DIRECT"); a.direct = d ? std::atoi(d) : 2; }
     a.tstamps = h->tstamps;
     int cfg = -1;
     if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {

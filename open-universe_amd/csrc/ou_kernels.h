@@ -13,6 +13,7 @@ namespace ou {
 struct ConvArgs {
   const float* x = nullptr;       // (B, Cin, Tin)
   const float* w = nullptr;       // packed [Cin/CK][KW][CK][Mp]
+  const float* wd = nullptr;      // second copy, taps innermost: [Cin][Mp][4 (k3) / 8 (k5)] (conv_direct2_kernel) or null
   const float* bias = nullptr;    // [Cout]
   float* y = nullptr;             // (B, Cout, Tout)
   const float* in_scale = nullptr;  // [B] or null
@@ -33,7 +34,8 @@ struct ConvArgs {
   int xcd_map = 0;                     // filled by launch_conv: block -> tile mapping (see the kernel)
   int force_cfg = -1, force_sc = 0;    // tuning overrides (ou_bench_conv)
   int force_xcd_map = -1;              // tuning: 0 / 1 / 2
-  int direct = 1;                      // 0: never use the register-direct split-K kernel (OU_CONV_DIRECT=0)
+  int direct = 2;                      // OU_CONV_DIRECT: 0 = never use the register-direct split-K kernels, 1 = only the
+                                       // first generation (dword loads), 2 = wide-load variant where a layer has `wd`
   // Anti-alias FIR of the up path fused into the epilogue (direct kernel, up > 1, KW == 1 only; launch_conv returns
   // hipErrorNotSupported otherwise and the caller runs launch_fir after a plain launch):
   //   y = FIR_{2 up + 1}(u) + bias ; y = res ? (y + res) * res_scale : y,   u = the transposed conv's output WITHOUT bias

@@ -506,7 +506,9 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   // (>= 2 blocks of 64 x 128 per CU without splitting K) stay on the LDS-tiled configs.
   if (a.direct != 0 && (a.force_cfg < 0 || a.force_cfg >= 100)) {
     const long wide = (long)((a.M + 63) / 64) * ((a.Nq + 127) / 128) * a.B;
-    const bool deep = (a.Nq <= 16384 && wide < 3L * num_cu) || a.force_cfg >= 100;
+    // (longer rows only for the wide-load variant: a 64-channel k5 conv at T = 32 080 runs 19 vs 24 us on it)
+    const bool wide_ok = a.wd && a.direct >= 2 && a.stride == 1 && a.up == 1;
+    const bool deep = ((a.Nq <= 16384 || wide_ok) && wide < 3L * num_cu) || a.force_cfg >= 100;
     if (deep) {
       hipError_t e = launch_conv_direct(a, num_cu, stream, cfg_out);
       if (e != hipErrorInvalidConfiguration) return e;
@@ -640,7 +642,7 @@ __device__ __forceinline__ u32x4 direct_desc(const void* base, unsigned bytes) {
 //            multiples, scalar otherwise: the deep levels have T = 401, 2005);
 //   up  > 1: transposed conv as `up` phase GEMMs (row m = co*up + ph -> sample t = q*up + ph): element e of the tile's
 //            (co, t) range, consecutive threads = consecutive samples.
-template <int TN>
+template <int TN, bool IL = false>  // IL: accumulator j holds columns TN n + j (conv_direct2_kernel), else 32 j + n
 struct DirectEpilogue {
   static constexpr int WK = 8, NT = 512, BM = 32, BN = 32 * TN, EP = BN + 4, C4 = BN / 4;
 
@@ -741,13 +743,21 @@ struct DirectEpilogue {
       bi = p.bias[m];
       if (filmb) { ga = filmb[m]; be = filmb[p.Cout + m]; }
     }
-#pragma unroll
-    for (int j = 0; j < TN; j++)
+    if constexpr (IL && TN == 2) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-        Es[(kw * BM + row) * EP + 32 * j + l31] = acc[j][r];
+        *reinterpret_cast<f32x2*>(&Es[(kw * BM + row) * EP + 2 * l31]) = f32x2{acc[0][r], acc[1][r]};
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+          Es[(kw * BM + row) * EP + 32 * j + l31] = acc[j][r];
+        }
+    }
     // LDS-only hand-over: wait for the ds_writes, not for the global loads above (__syncthreads would)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (p.fir) {
@@ -934,6 +944,153 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
   if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
+// One ring slot of conv_direct2_kernel after its wait: window -> (edge fix-up) -> PReLU -> KW x TN MFMAs.
+template <int KW, int TN>
+__device__ __forceinline__ void direct2_mma(const f32x4& a4, float a1, const f32x4& b4, float b1, const f32x2& b2,
+                                            floatx16 (&acc)[TN], float alpha, bool edge, int sh, unsigned vmask) {
+  constexpr int W = KW + TN - 1, PAD = (KW - 1) / 2;
+  const float L[6] = {b4.x, b4.y, b4.z, b4.w, W == 5 ? b1 : b2.x, b2.y};
+  float X[W];
+  if (edge) {  // block-uniform: first / last column tiles only
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+      float v = L[i];  // sh == 0
+#pragma unroll
+      for (int s = 1; s <= PAD; s++) v = sh == s ? (i - s >= 0 ? L[i - s >= 0 ? i - s : 0] : 0.f) : v;
+      X[i] = ((vmask >> i) & 1u) ? v : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < W; i++) X[i] = L[i];
+  }
+#pragma unroll
+  for (int i = 0; i < W; i++) X[i] = X[i] >= 0.f ? X[i] : alpha * X[i];
+  const float A[5] = {a4.x, a4.y, a4.z, a4.w, a1};
+#pragma unroll
+  for (int k = 0; k < KW; k++)
+#pragma unroll
+    for (int q = 0; q < TN; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k], X[q + k], acc[q], 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_direct2_kernel: the stride-1 k3 / k5 direct kernel with WIDE operand loads.
+// The first direct kernel is bound by vector-memory instruction issue, not by MFMA or bytes: a CU retires one
+// buffer_load_dword wave instruction per ~8.4 cycles whatever the data (tools/ubench/vmem_issue.hip: dword and dwordx2
+// 31-43 B/clk/CU, dwordx4 58-75 B/clk/CU), and with 1.5 load instructions per MFMA (64-column tiles) the 16 waves of a
+// CU spend ~9.7 k cycles issuing loads next to 12.3 k cycles of MFMAs -- the 36 prologue loads alone hold every wave for
+// 4.8 k cycles before its first MFMA (tools/direct_ts.py).  Here one 16-byte load per operand feeds all taps:
+//   A: a second copy of the weights with the taps innermost ([ci][m][KWP], KWP = 4 / 8): lane (m, half) gets all KW
+//      taps of channel 2I + half with one dwordx4 (+ one dword for k5);
+//   B: lane (n, half) loads the KW + TN - 1 consecutive samples x[2I + half][n0 + TN n - pad ...] it needs for ALL taps
+//      of its TN adjacent output columns (column n0 + TN n + q reads window element q + k for tap k): one dwordx4
+//      (+ dword / dwordx2 for k5).  Output columns are interleaved over the TN accumulators instead of blocked -- a
+//      permutation the epilogue undoes for free (8-byte LDS writes).
+//   k3, 64 columns: 2 load instructions per 6 MFMAs (was 9); k5: 4 per 10 (was 15).
+// Windows that leave [0, Tin) (first / last column tiles only, block-uniform branch): lanes that would start before the
+// row load from its start instead and shift their elements; elements outside the row are zeroed -- a row-crossing
+// 16-byte load returns the neighbouring row's samples, not zeros.  Same K order per output element as
+// conv_direct_kernel (pairs in ring order, taps ascending): bit-identical results.
+// ---------------------------------------------------------------------------------------------------------
+template <int KW, int TN>
+__global__ __launch_bounds__(512) void conv_direct2_kernel(ConvArgs p) {
+  constexpr int D = 4, W = KW + TN - 1, KWP = KW == 3 ? 4 : 8, PAD = (KW - 1) / 2;
+  constexpr int B2 = W - 4;                    // elements in the second B load: 0 (none), 1 (dword), 2 (dwordx2)
+  constexpr int A2 = KW - 4 > 0 ? KW - 4 : 0;  // elements in the second A load: 0 / 1
+  constexpr int LPS = 1 + (A2 ? 1 : 0) + 1 + (B2 > 0 ? 1 : 0);  // load instructions per ring slot (= channel pair)
+  static_assert(KW == 3 || KW == 5, "k3 / k5");
+  static_assert(B2 >= -1 && B2 <= 2 && D * LPS <= 60, "window / vmcnt");
+  constexpr int BN = 32 * TN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile_m, tile_n;
+  if (!direct_tile(p, tile_m, tile_n)) return;
+  const int n0 = tile_n * BN, m0 = tile_m * 32, b = blockIdx.z;
+  if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const int lhalf = lane >> 5, l31 = lane & 31;
+  const int Tin = p.Tin, Mp = p.Mp;
+  const float alpha = p.act ? p.alpha_val : 1.0f;
+  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  const u32x4 rw = direct_desc(p.wd, (unsigned)p.Cin * (unsigned)Mp * (unsigned)KWP * 4u);
+  const int avo = ((lhalf * Mp) + m0 + l31) * KWP * 4;
+  // this lane's window: samples t0 .. t0 + W - 1 of row 2I + half; `sh` = samples cut off in front of the row
+  const int t0 = n0 + TN * l31 - PAD;
+  const int sh = t0 < 0 ? -t0 : 0;
+  const int bvo = (t0 + sh < Tin) ? (lhalf * Tin + t0 + sh) * 4 : (int)0x80000000;
+  const bool edge = __builtin_amdgcn_readfirstlane((n0 < PAD || n0 + BN + KW - 1 - PAD > Tin) ? 1 : 0) != 0;
+  unsigned vmask = 0;  // bit i: window element i is inside the row
+#pragma unroll
+  for (int i = 0; i < W; i++) vmask |= (t0 + i >= 0 && t0 + i < Tin) ? (1u << i) : 0u;
+
+  const int NG = p.Cin >> 4;  // channel pairs per wave (launcher: a multiple of D)
+  f32x4 a4[D], b4[D];
+  float a1[D];   // k5: tap 4
+  float b1[D];   // window element 4 (5-element windows)
+  f32x2 b2[D];   // window elements 4, 5 (6-element windows)
+#pragma unroll
+  for (int d0 = 0; d0 < D; d0++) {
+    a4[d0] = f32x4{0.f, 0.f, 0.f, 0.f}; b4[d0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    a1[d0] = 0.f; b1[d0] = 0.f; b2[d0] = f32x2{0.f, 0.f};
+  }
+  floatx16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+#define OU_ISSUE(g_, d)                                                                                              \
+  {                                                                                                                  \
+    const int ci = 2 * (kw + 8 * (g_));                                                                              \
+    const int aso = ci * Mp * KWP * 4, xso = ci * Tin * 4;                                                           \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(a4[d]) : "v"(avo), "s"(rw), "s"(aso));            \
+    if constexpr (A2 == 1)                                                                                           \
+      asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:16" : "+v"(a1[d]) : "v"(avo), "s"(rw), "s"(aso));  \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(b4[d]) : "v"(bvo), "s"(rx), "s"(xso));            \
+    if constexpr (B2 == 1)                                                                                           \
+      asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:16" : "+v"(b1[d]) : "v"(bvo), "s"(rx), "s"(xso));   \
+    if constexpr (B2 == 2)                                                                                           \
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:16" : "+v"(b2[d]) : "v"(bvo), "s"(rx), "s"(xso)); \
+  }
+#define OU_MMA(d, out)                                                                                               \
+  {                                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS));                                                          \
+    asm volatile("" : "+v"(a4[d]));                                                                                  \
+    asm volatile("" : "+v"(b4[d]));                                                                                  \
+    if constexpr (A2 == 1) asm volatile("" : "+v"(a1[d]));                                                           \
+    if constexpr (B2 == 1) asm volatile("" : "+v"(b1[d]));                                                           \
+    if constexpr (B2 == 2) asm volatile("" : "+v"(b2[d]));                                                           \
+    direct2_mma<KW, TN>(a4[d], a1[d], b4[d], b1[d], b2[d], acc, alpha, edge, sh, vmask);                             \
+  }
+  const bool ts_on = p.tstamps != nullptr;
+  long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, r0 = 0;
+  if (ts_on) { r0 = (long long)__builtin_amdgcn_s_memrealtime(); c0 = __builtin_readcyclecounter(); }
+  OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
+  if (ts_on) c1 = __builtin_readcyclecounter();
+  const int NR = NG / D;
+  for (int r = 0; r + 1 < NR; r++) {
+    const int g = r * D;
+    OU_MMA(0, 3);
+    if (ts_on && r == 0) c2 = __builtin_readcyclecounter();
+    OU_ISSUE(g + 4, 0);
+    OU_MMA(1, 3); OU_ISSUE(g + 5, 1);
+    OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
+    OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
+  }
+  if (ts_on) c3 = __builtin_readcyclecounter();
+  OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
+  if (ts_on) c4 = __builtin_readcyclecounter();
+#undef OU_ISSUE
+#undef OU_MMA
+  DirectEpilogue<TN, true>::run(p, acc, smem, tid, kw, b, m0, n0);
+  if (ts_on && lane == 0) {
+    const long long c5 = __builtin_readcyclecounter();
+    long long* o = p.tstamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + kw) * 8;
+    o[0] = r0; o[1] = c1 - c0; o[2] = (NR > 1 ? c2 : c4) - c1; o[3] = NR > 1 ? c3 - c2 : 0; o[4] = c4 - c3; o[5] = c5 - c4;
+    o[6] = 0; o[7] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Strided variant of the direct kernel: Conv1d with stride R and KW = G*R taps, pad = (G - 1)/2 * R -- the rate-change
 // (down) convs: k = s = r (G = 1), or 3r taps with the binomial anti-alias FIR folded into the weights (G = 3, see the
@@ -1100,9 +1257,13 @@ static hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t 
   if ((long)a.Cin * a.Tin * 4 >= (1L << 31) || (long)a.Cin * a.KW * a.Mp * 4 >= (1L << 31)) return hipErrorInvalidConfiguration;
   const int npw = a.Cin / 16;  // channel pairs per wave
   const long gm = (a.M + 31) / 32;
-  // 64-column tiles when they still give about one block per CU (fewer A loads per MFMA), else 32 columns
-  const long b64 = gm * ((a.Nq + 63) / 64) * a.B;
-  int tn = (a.force_cfg == 105 || (a.force_cfg < 0 && b64 >= (long)num_cu * 15 / 16)) ? 2 : 1;
+  // 64- or 32-column tiles: all blocks of these launches start together, so a launch takes about ceil(blocks / CUs)
+  // block times, and a 64-column block costs two 32-column ones.  Ties go to 64 columns (half the A traffic).
+  // Measured (PP16, B = 1): 504 / 256 blocks of 64 columns beat 1008 / 504 of 32 by 5-10 %, 336 (GRU input projection) and
+  // 280 (first up conv) lose to 624 / 520 by 20 %.
+  const long b64 = gm * ((a.Nq + 63) / 64) * a.B, b32 = gm * ((a.Nq + 31) / 32) * a.B;
+  int tn = 2 * ((b64 + num_cu - 1) / num_cu) <= (b32 + num_cu - 1) / num_cu ? 2 : 1;
+  if (a.force_cfg == 105) tn = 2;
   if (a.force_cfg == 106) tn = 1;
   void (*kern)(ConvArgs) = nullptr;
   int variant = 0;
@@ -1114,8 +1275,9 @@ static hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t 
     bm_step = (32 / a.up) * a.up;
     halo = 1;
     gm_fir = (a.M + bm_step - 1) / bm_step;
-    const long b62 = gm_fir * ((a.Nq + 61) / 62) * a.B;
-    tn = (a.force_cfg == 105 || (a.force_cfg < 0 && b62 >= (long)num_cu * 15 / 16)) ? 2 : 1;
+    const long b62 = gm_fir * ((a.Nq + 61) / 62) * a.B, b30 = gm_fir * ((a.Nq + 29) / 30) * a.B;
+    tn = 2 * ((b62 + num_cu - 1) / num_cu) <= (b30 + num_cu - 1) / num_cu ? 2 : 1;
+    if (a.force_cfg == 105) tn = 2;
     if (a.force_cfg == 106) tn = 1;
     // The halo costs tiles (62 of 64 / 30 of 32 columns, whole channels only).  All blocks of these launches start
     // together -- 2 (64-column) or 4 (32-column) resident per CU -- so a launch takes ceil(blocks / slots) rounds, and
@@ -1126,7 +1288,13 @@ static hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t 
     const long plain = gm * ((a.Nq + 32 * tn - 1) / (32 * tn)) * a.B;
     if (a.force_cfg < 0 && (fused + slots - 1) / slots > (plain + slots - 1) / slots) return hipErrorNotSupported;
   }
-  if (a.stride == 1) {
+  if (a.stride == 1 && a.wd && a.direct >= 2 && !a.fir && a.up == 1 && (a.KW == 3 || a.KW == 5) && npw % 4 == 0 &&
+      a.pad == (a.KW - 1) / 2 && (long)a.Cin * a.Mp * 8 * 4 < (1L << 31)) {
+    // wide-load variant (taps-innermost weight copy)
+    kern = a.KW == 3 ? (tn == 2 ? conv_direct2_kernel<3, 2> : conv_direct2_kernel<3, 1>)
+                     : (tn == 2 ? conv_direct2_kernel<5, 2> : conv_direct2_kernel<5, 1>);
+    variant = 56 + 10 * tn;  // 66 / 76
+  } else if (a.stride == 1) {
     if (a.KW != 1 && a.KW != 3 && a.KW != 5) return hipErrorInvalidConfiguration;
     for (const DirectCfg& c : kDirectCfgs) {
       if (c.KW != a.KW || c.TN != tn || npw % (c.GP * 4)) continue;

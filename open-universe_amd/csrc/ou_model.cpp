@@ -39,6 +39,11 @@ std::string finish_conv(ConvL& L, Alloc& a) {
   L.b_off = a.take(L.Cout);
   L.a_off = a.take(1);
   if (L.fir_mode == 1 || L.fir_mode == 2) { L.fir_off = a.take(L.fir_len); L.fbias_off = a.take(L.Cout); }
+  // layers the wide-load direct kernel can take (deep levels at small batch): taps-innermost copy of the weights
+  if (L.stride == 1 && L.up == 1 && (L.KW == 3 || L.KW == 5) && L.Cin % 64 == 0 && L.pad == (L.KW - 1) / 2) {
+    L.KWP = L.KW == 3 ? 4 : 8;
+    L.wd_off = a.take((size_t)L.Cin * L.Mp * L.KWP);
+  }
   return "";
 }
 
@@ -373,6 +378,11 @@ struct Packer {
         for (int mm = 0; mm < L.M; mm++) dst[mm] = (float)W[((size_t)mm * L.Cin + ci) * KW + k];
       }
     }
+    if (L.KWP)  // (the blob starts zeroed: taps KW .. KWP - 1 and rows M .. Mp - 1 stay 0)
+      for (int ci = 0; ci < L.Cin; ci++)
+        for (int mm = 0; mm < L.M; mm++)
+          for (int k = 0; k < KW; k++)
+            blob[L.wd_off + ((size_t)ci * Mp + mm) * L.KWP + k] = (float)W[((size_t)mm * L.Cin + ci) * KW + k];
   }
 
   void pack_conv(const ConvL& L) {

@@ -23,6 +23,8 @@ struct ConvL {
   int CK = 2;             // input-channel chunk (power of two, divides Cin)
   int rate = 1;           // original rate-change factor (down/up/st convs)
   int act = 0;            // PReLU prologue
+  size_t wd_off = 0;      // stride-1 k3 / k5 layers: second copy of the weights with the taps innermost, [Cin][Mp][KWP]
+  int KWP = 0;            // ... 4 (k3) / 8 (k5); 0 = no such copy
   size_t w_off = 0;       // float offsets into the blob
   size_t b_off = 0;       // bias[Cout]
   size_t a_off = 0;       // prelu slope (1 float) when act

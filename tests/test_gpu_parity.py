@@ -383,6 +383,35 @@ def test_direct_conv_kernels_match_lds_kernels(name, B, T, monkeypatch):
         record(f"direct_vs_lds.{name}.{b}", O.si_sdr(ref[b], out[b]), 100)
 
 
+@pytest.mark.parametrize("name,B,T", [("PP16", 2, 23517), ("PP24", 1, 30011), ("PP16", 1, 32000), ("PP16", 3, 777),
+                                      ("OR16", 2, 9000)])
+def test_wide_load_direct_kernel_is_bit_identical_to_the_dword_one(name, B, T, monkeypatch):
+    """conv_direct2_kernel (one 16-byte load per operand feeds all taps, taps-innermost weight copy, interleaved output
+    columns) vs conv_direct_kernel (OU_CONV_DIRECT=1): same K order per output element, so the whole enhance is
+    bit-identical.  Ragged / tiny lengths exercise the shifted and masked windows of the first and last column tiles."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(47, 2, B, Tp)
+    monkeypatch.setenv("OU_CONV_DIRECT", "1")
+    ref = run_enhance(model, mix, nz, n_steps=2)
+    monkeypatch.delenv("OU_CONV_DIRECT")
+    out = run_enhance(model, mix, nz, n_steps=2)
+    assert torch.equal(ref, out)  # (T <= 32 768: both generations take the same layers)
+
+
+def test_wide_load_direct_kernel_at_the_headline_size(monkeypatch):
+    """4 s at 16 kHz: the wide-load kernel also takes the 64-channel k5 convs at T/2 = 32 080 (LDS kernel otherwise)."""
+    model, spec, sd = get_model("PP16")
+    mix = synth_mix(spec, 1, 64000)
+    nz = noise_list(49, 2, 1, 64160)
+    monkeypatch.setenv("OU_CONV_DIRECT", "1")
+    ref = run_enhance(model, mix, nz, n_steps=2)
+    monkeypatch.delenv("OU_CONV_DIRECT")
+    out = run_enhance(model, mix, nz, n_steps=2)
+    record("direct2_vs_direct1.PP16.64000", O.si_sdr(ref[0], out[0]), 100)
+
+
 @pytest.mark.parametrize("name,B,T", [("PP16", 2, 23517), ("PP24", 1, 30011), ("PP16", 1, 64000)])
 def test_fused_up_fir_epilogue_is_bit_identical_to_the_fir_pass(name, B, T, monkeypatch):
     """Up path: FIR + bias + residual fused into the transposed conv's epilogue (overlapping tiles, one halo frame) vs
