@@ -279,7 +279,8 @@ def main():
         recs = model.profile_read(max_records=32768)
         model.profile(False)
         # records: (ms, algorithmic flops, algorithmic bytes, variant); variant < 50: conv_mfma_kernel tile configs,
-        # 50-99: conv_direct_kernel variants, >= 100: conv_chain_kernel (fused ConvBlock body).
+        # 66 / 76: conv_direct2_kernel, other 50-99: conv_direct_kernel / conv_direct_strided_kernel variants,
+        # >= 100: conv_chain_kernel (fused ConvBlock body).
         def summarise(rr):
             if not rr:
                 return None
@@ -293,11 +294,14 @@ def main():
                     "tflops": fl_ / (ms_ * 1e-3) / 1e12, "gbs": by_ / (ms_ * 1e-3) / 1e9,
                     "algorithmic_bytes_per_launch": by_ / len(rr)}
         KERNELS = {
-            "direct": "ou::conv_direct_kernel (register-direct split-K fp32-MFMA Conv1d, deep levels)",
+            "direct2": "ou::conv_direct2_kernel (register-direct split-K fp32-MFMA Conv1d, wide operand loads: k3 / k5 layers)",
+            "direct": "ou::conv_direct_kernel / conv_direct_strided_kernel (register-direct split-K: 1x1, phase-GEMM and "
+                      "rate-change convs)",
             "lds": "ou::conv_mfma_kernel (LDS-tiled fp32-MFMA implicit-GEMM Conv1d, wide levels / strided convs)",
             "chain": "ou::conv_chain_kernel (fused ConvBlock body, C = 32 / 64 levels)",
         }
-        groups = {"direct": summarise([r for r in recs if 50 <= r[3] < 100]),
+        groups = {"direct2": summarise([r for r in recs if r[3] in (66, 76)]),
+                  "direct": summarise([r for r in recs if 50 <= r[3] < 100 and r[3] not in (66, 76)]),
                   "lds": summarise([r for r in recs if r[3] < 50]),
                   "chain": summarise([r for r in recs if r[3] >= 100])}
         groups = {k: v for k, v in groups.items() if v}

@@ -502,13 +502,16 @@ hipError_t init_conv_kernels() {
 static hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out);
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
   if (a.Cin % a.CK || a.CK < 2 || (a.CK & (a.CK - 1)) || a.Mp % 64 || a.Nq <= 0) return hipErrorInvalidValue;
-  // Deep levels (what the 8-wave split-K configs below were built for): the register-direct kernel.  Wide levels
-  // (>= 2 blocks of 64 x 128 per CU without splitting K) stay on the LDS-tiled configs.
+  // Deep levels (what the 8-wave split-K configs below were built for): the register-direct kernels.  Wide levels
+  // (many blocks of 64 x 128 per CU without splitting K) stay on the LDS-tiled configs.
   if (a.direct != 0 && (a.force_cfg < 0 || a.force_cfg >= 100)) {
     const long wide = (long)((a.M + 63) / 64) * ((a.Nq + 127) / 128) * a.B;
     // (longer rows only for the wide-load variant: a 64-channel k5 conv at T = 32 080 runs 19 vs 24 us on it)
     const bool wide_ok = a.wd && a.direct >= 2 && a.stride == 1 && a.up == 1;
-    const bool deep = ((a.Nq <= 16384 || wide_ok) && wide < 3L * num_cu) || a.force_cfg >= 100;
+    // up to 8 blocks of 64 x 128 per CU (measured: PP16 B = 8 33.3 -> 32.3 ms, OR16 B = 16 63.4 -> 60.2 ms when the limit
+    // goes from 3 to 6-12; beyond that nothing moves: those layers are not direct-capable anyway)
+    static const long deep_factor = [] { const char* e = getenv("OU_DEEP_FACTOR"); return e ? atol(e) : 8L; }();
+    const bool deep = ((a.Nq <= 16384 || wide_ok) && wide < deep_factor * num_cu) || a.force_cfg >= 100;
     if (deep) {
       hipError_t e = launch_conv_direct(a, num_cu, stream, cfg_out);
       if (e != hipErrorInvalidConfiguration) return e;
@@ -2643,7 +2646,8 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
   const unsigned epoch = __hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
   const int T = p.T;
   const bool ts_on = p.tstamps != nullptr;
-  long long c_poll = 0, c_comp = 0;
+  long long c_poll = 0, c_comp = 0, r_start = 0, r_loop = 0;
+  if (ts_on) r_start = (long long)__builtin_amdgcn_s_memrealtime();
   if (cluster < nclusters) {
     const int dir = cluster & 1, b = cluster >> 1;
     const int ul = tid / LPU, cg = tid % LPU;
@@ -2733,6 +2737,7 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
     const int dt = dir ? -1 : 1;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // weights landed: no vmcnt(0) inside the loop on their account
 
+    if (ts_on) r_loop = (long long)__builtin_amdgcn_s_memrealtime();
     for (int step = 0; step < T; step++, t += dt) {
       long long q0 = 0, q1 = 0;
       if (ts_on) q0 = __builtin_readcyclecounter();
@@ -2855,7 +2860,9 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
     }
     if (ts_on && lane == 0) {
       long long* o = p.tstamps + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 8;
-      o[0] = c_comp; o[1] = c_poll; o[2] = 0; o[3] = T; o[4] = 0; o[5] = 0; o[6] = 0;
+      // 10 ns ticks: kernel entry -> first step (weights, rendezvous, first chunks), the T steps
+      o[0] = c_comp; o[1] = c_poll; o[2] = 0; o[3] = T; o[4] = r_loop - r_start;
+      o[5] = (long long)__builtin_amdgcn_s_memrealtime() - r_loop; o[6] = r_start;
     }
   }
   // ---- epoch hand-over: the last block to finish advances the epoch for the next launch on this exchange area

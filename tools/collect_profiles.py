@@ -15,18 +15,19 @@ for n in sorted(os.listdir(src)):
         json.loads(lines[-1])
         open(os.path.join(dst, f"{tag}_{n}"), "w").write(lines[-1] + "\n")
 for n in sorted(os.listdir(src)):
-    if n.startswith("kstats_") or n.startswith("pmc_sq_") or n.startswith("gru_ts") or n.startswith("layers"):
+    if n.startswith(("kstats_", "pmc_sq_", "gru_ts", "layers", "direct_ts", "direct_sweep", "ubench_")):
         shutil.copy(os.path.join(src, n), os.path.join(dst, f"{tag}_{n}"))
 
-FAMS = {"direct": "conv_direct", "lds": "conv_mfma_kernel", "chain": "conv_chain_kernel", "gru_ring": "gru_ring_kernel",
-        "gru_cluster": "gru_cluster_kernel"}
+FAMS = {"direct2": ("conv_direct2_kernel",), "direct": ("conv_direct_kernel", "conv_direct_strided_kernel"),
+        "lds": ("conv_mfma_kernel",), "chain": ("conv_chain_kernel",), "gru_ring": ("gru_ring_kernel",),
+        "gru_cluster": ("gru_cluster_kernel",)}
 
 
 def fam_avg(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        for fam, pat in FAMS.items():
-            if pat in r["Kernel_Name"]:
+        for fam, pats in FAMS.items():
+            if any(pat in r["Kernel_Name"] for pat in pats):
                 agg[fam].append(float(r["Counter_Value"]))
     return {k: {"dispatches": len(v), "avg": sum(v) / len(v)} for k, v in agg.items()}
 

@@ -21,4 +21,10 @@ for blk in (0, 1, 8, 9):
               [[round(float(x) / 401) for x in ts[blk, w, [0, 1, 2, 4, 5, 6]]] for w in (0, 1, 7)])
     else:
         print("v2 block", blk, "per-step cycles per wave [compute (matvec..publish), gather (poll until all tags)]:",
-              [[round(float(x) / 401) for x in ts[blk, w, [0, 1]]] for w in (0, 1, 2, 3)])
+              [[round(float(x) / 401) for x in ts[blk, w, [0, 1]]] for w in (0, 1, 2, 3)],
+              "| us: entry -> first step", [round(float(ts[blk, w, 4]) / 100, 1) for w in (0, 1, 2, 3)],
+              "steps", [round(float(ts[blk, w, 5]) / 100, 1) for w in (0, 1, 2, 3)])
+if v != "1":
+    st = ts[:, :, 6]
+    on = st > 0
+    print("kernel entry spread over the participating waves: %.1f us" % ((st[on].max() - st[on].min()).item() / 100))
