@@ -63,7 +63,7 @@ struct ou_handle {
   struct ProfRec { double flops, bytes; int cfg; };
   std::vector<ProfRec> prof;
   size_t prof_used = 0;
-  unsigned long long* prof_dev = nullptr;  // [kProfSlots][2] device-side {min start, ~max end} ticks
+  unsigned long long* prof_dev = nullptr;  // [kProfSlots][32] device-side {16 x min start, 16 x ~max end} ticks
   int fuse_mode = -1;  // OU_FUSE: -1 auto (cost model), 0 never, 2 / 3 force that depth where the shape allows
   int fuse_nc = 0;     // OU_FUSE_NC: force 128 / 256 columns per tile
 };
@@ -195,7 +195,7 @@ struct Runner {
       rec.flops = 2.0 * L.M * (double)Nq * L.Cin * kref * B;
       rec.bytes = 4.0 * ((double)B * ((double)L.Cin * in.T + (double)L.Cout * Tout) + (double)L.M * L.Cin * kref);
       rec.cfg = -1;
-      a.prof = h->prof_dev + 2 * h->prof_used;
+      a.prof = h->prof_dev + 32 * h->prof_used;
       h->prof.push_back(rec);
       h->prof_used++;
     }
@@ -336,7 +336,7 @@ struct Runner {
           // activations: block input (also the residual) once, output once, the cond add when present
           rec.bytes = 4.0 * B * (double)Bk.C * hu.T * (2 + (depth == 2 ? 1 : 0) + (ca.add ? 1 : 0)) + wbytes;
           rec.cfg = -1;
-          ca.prof = h->prof_dev + 2 * h->prof_used;
+          ca.prof = h->prof_dev + 32 * h->prof_used;
           h->prof.push_back(rec);
           h->prof_used++;
         }
@@ -1084,9 +1084,9 @@ int ou_profile_enable(ou_handle* h, int32_t on) {
   h->prof.clear();
   if (on) {
     // measurement buffer: owned by the library, allocated outside any forward call
-    if (!h->prof_dev && hipMalloc((void**)&h->prof_dev, kProfSlots * 16) != hipSuccess)
+    if (!h->prof_dev && hipMalloc((void**)&h->prof_dev, kProfSlots * 256) != hipSuccess)
       return fail(h, OU_EHIP, "hipMalloc(profile buffer) failed");
-    if (hipMemset(h->prof_dev, 0xFF, kProfSlots * 16) != hipSuccess) return fail(h, OU_EHIP, "hipMemset failed");
+    if (hipMemset(h->prof_dev, 0xFF, kProfSlots * 256) != hipSuccess) return fail(h, OU_EHIP, "hipMemset failed");
   }
   return OU_OK;
 }
@@ -1096,14 +1096,19 @@ int ou_profile_read(ou_handle* h, int32_t max_records, float* ms, double* flops,
   if (!h || !n_records) return OU_EINVAL;
   int n = (int)h->prof_used;
   if (n > max_records) n = max_records;
-  std::vector<unsigned long long> host((size_t)2 * (n > 0 ? n : 1));
+  std::vector<unsigned long long> host((size_t)32 * (n > 0 ? n : 1));
   if (n > 0) {
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(host.data(), h->prof_dev, (size_t)n * 16, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(host.data(), h->prof_dev, (size_t)n * 256, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(h, OU_EHIP, hipGetErrorString(e));
   }
   for (int i = 0; i < n; i++) {
-    const unsigned long long t0 = host[2 * i], t1 = ~host[2 * i + 1];
+    unsigned long long t0 = ~0ull, t1 = 0ull;
+    for (int w = 0; w < 16; w++) {
+      const unsigned long long a = host[32 * i + w], b = ~host[32 * i + 16 + w];
+      if (a < t0) t0 = a;
+      if (b > t1) t1 = b;
+    }
     if (ms) ms[i] = (t1 >= t0) ? (float)((double)(t1 - t0) * 1e-5) : 0.f;  // 100 MHz constant clock: 10 ns ticks
     if (flops) flops[i] = h->prof[i].flops;
     if (bytes) bytes[i] = h->prof[i].bytes;

@@ -44,7 +44,8 @@ struct ConvArgs {
   int tile_bm = 32, tile_bn = 0, tile_halo = 0;  // filled by launch_conv_direct: rows / columns a tile advances by, left halo
   int dbg = 0;                         // phase ablation switches (tuning only)
   long long* tstamps = nullptr;        // per-wave phase cycle counts (tuning only)
-  unsigned long long* prof = nullptr;  // measurement: {min block start, ~max block end} in s_memrealtime ticks (10 ns)
+  unsigned long long* prof = nullptr;  // measurement: 16 x min block start, 16 x ~max block end (slot = block id & 15: 500
+                                       // same-address atomics in half a microsecond stall an L2 channel), 10 ns ticks
 };
 // returns hipSuccess or the launch error; `cfg_out` (optional) receives the tile configuration index used
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out = nullptr);

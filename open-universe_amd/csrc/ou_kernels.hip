@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
   const int nstages = p.Cin / SCK;
   const int nI_ = SCK >> 1;               // channel pairs per stage
 
-  if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
   long long tsv[8];
   const bool ts_on = p.tstamps != nullptr;
   if (ts_on) tsv[0] = __builtin_readcyclecounter();
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
       p.y[idx] = v;
     }
   }
-  if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
   if (ts_on && lane == 0) {
     long long* o = p.tstamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * (CONV_NT / 64) + wave) * 8;
     o[0] = tsv[1] - tsv[0]; o[1] = tsv[2] - tsv[1]; o[2] = tsv[3] - tsv[2]; o[3] = tsv[4] - tsv[3];
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
   // (tile_bn / tile_bm / tile_halo: BN, 32, 0 -- except with the fused up-path FIR, whose tiles overlap by a frame on
   // either side and hold whole output channels only, see DirectEpilogue)
   const int n0 = tile_n * p.tile_bn - p.tile_halo, m0 = tile_m * p.tile_bm, b = blockIdx.z;
-  if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
 
   const int lhalf = lane >> 5, l31 = lane & 31;
   const int CK = p.CK, lck = 31 - __clz(CK);
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
     o[0] = r0; o[1] = c1 - c0; o[2] = (NR > 1 ? c2 : c4) - c1; o[3] = NR > 1 ? c3 - c2 : 0; o[4] = c4 - c3; o[5] = c5 - c4;
     o[6] = 0; o[7] = (long long)__builtin_amdgcn_s_memrealtime();
   }
-  if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 // One ring slot of conv_direct2_kernel after its wait: window -> (edge fix-up) -> PReLU -> KW x TN MFMAs.
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(512) void conv_direct2_kernel(ConvArgs p) {
   int tile_m, tile_n;
   if (!direct_tile(p, tile_m, tile_n)) return;
   const int n0 = tile_n * BN, m0 = tile_m * 32, b = blockIdx.z;
-  if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
   const int lhalf = lane >> 5, l31 = lane & 31;
   const int Tin = p.Tin, Mp = p.Mp;
   const float alpha = p.act ? p.alpha_val : 1.0f;
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(512) void conv_direct2_kernel(ConvArgs p) {
     o[0] = r0; o[1] = c1 - c0; o[2] = (NR > 1 ? c2 : c4) - c1; o[3] = NR > 1 ? c3 - c2 : 0; o[4] = c4 - c3; o[5] = c5 - c4;
     o[6] = 0; o[7] = (long long)__builtin_amdgcn_s_memrealtime();
   }
-  if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(512) void conv_direct_strided_kernel(ConvArgs p) {
   int tile_m, tile_n;
   if (!direct_tile(p, tile_m, tile_n)) return;
   const int n0 = tile_n * BN, m0 = tile_m * BM, b = blockIdx.z;
-  if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
   const int lhalf = lane >> 5, l31 = lane & 31;
   const int CK = p.CK, lck = 31 - __clz(CK);
   const int Tin = p.Tin, Mp = p.Mp;
@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(512) void conv_direct_strided_kernel(ConvArgs p) {
 #undef OU_ISSUE
 #undef OU_MMA
   DirectEpilogue<TN>::run(p, acc, smem, tid, kw, b, m0, n0);
-  if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 struct DirectCfg {
@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(64 * NWV) void conv_chain_kernel(ChainArgs p, int T
   const int lhalf = lane >> 5, l31 = lane & 31;
   const int tile = blockIdx.x % ntiles, b = blockIdx.x / ntiles;
   const int D = p.depth, T = p.T;
-  if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
   const bool ts_on = p.tstamps != nullptr;
   long long tsv[3] = {0, 0, 0}, t_mma = 0, t_epi = 0, t_bar = 0, t_iss = 0, t_ws = 0;
   if (ts_on) tsv[0] = __builtin_readcyclecounter();
@@ -1596,7 +1596,7 @@ __global__ __launch_bounds__(64 * NWV) void conv_chain_kernel(ChainArgs p, int T
     o[0] = tsv[1] - tsv[0]; o[1] = tsv[2] - tsv[1]; o[2] = t_mma; o[3] = t_epi; o[4] = t_bar;
     o[5] = __builtin_readcyclecounter() - tsv[0]; o[6] = t_iss; o[7] = t_ws;
   }
-  if (p.prof && tid == 0) atomicMin(p.prof + 1, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 struct ChainVariant {
@@ -2575,6 +2575,19 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
         }
         if (ok) break;
         if (++spins > GRU_SPIN_LIMIT) { abort_flag = 1; break; }
+        // safety net as in gru_ring_kernel: a plain publish has no visibility deadline; after a long wait (~1 ms; the gate
+        // lanes have written this step's values to LDS long before) repeat this workgroup's own granules as system-scope
+        // write-through stores
+        if (plain && (spins & 1023u) == 1023u) {
+#pragma unroll
+          for (int k = 0; k < HB; k++)
+            if ((k * 64 + lane) / UPW == g) {
+              const float hv = *reinterpret_cast<volatile float*>(&hbuf[cur ^ 1][k * 64 + lane]);
+              const unsigned long long gran = ((unsigned long long)tag << 32) | (unsigned)__float_as_int(hv);
+              unsigned long long* dst = src + k * 64;
+              asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(gran) : "memory");
+            }
+        }
       }
 #pragma unroll
       for (int k = 0; k < HB; k++)
