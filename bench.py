@@ -278,7 +278,8 @@ def main():
         torch.cuda.synchronize()
         recs = model.profile_read(max_records=32768)
         model.profile(False)
-        # records: (ms, algorithmic flops, algorithmic bytes, variant); variant < 50: conv_mfma_kernel tile configs,
+        # records: (ms, algorithmic flops, algorithmic bytes, variant); variant < 40: conv_mfma_kernel tile configs,
+        # 40-49: rate_down_kernel,
         # 66 / 76: conv_direct2_kernel, other 50-99: conv_direct_kernel / conv_direct_strided_kernel variants,
         # >= 100: conv_chain_kernel (fused ConvBlock body).
         def summarise(rr):
@@ -298,11 +299,13 @@ def main():
             "direct": "ou::conv_direct_kernel / conv_direct_strided_kernel (register-direct split-K: 1x1, phase-GEMM and "
                       "rate-change convs)",
             "lds": "ou::conv_mfma_kernel (LDS-tiled fp32-MFMA implicit-GEMM Conv1d, wide levels / strided convs)",
+            "rate": "ou::rate_down_kernel (first rate-change conv with the anti-alias FIR fused, K = 64)",
             "chain": "ou::conv_chain_kernel (fused ConvBlock body, C = 32 / 64 levels)",
         }
         groups = {"direct2": summarise([r for r in recs if r[3] in (66, 76)]),
                   "direct": summarise([r for r in recs if 50 <= r[3] < 100 and r[3] not in (66, 76)]),
-                  "lds": summarise([r for r in recs if r[3] < 50]),
+                  "lds": summarise([r for r in recs if r[3] < 40]),
+                  "rate": summarise([r for r in recs if 40 <= r[3] < 50]),
                   "chain": summarise([r for r in recs if r[3] >= 100])}
         groups = {k: v for k, v in groups.items() if v}
         dom = max(groups, key=lambda k: groups[k]["ms_per_enhance"])  # the dominant kernel = most time per enhance

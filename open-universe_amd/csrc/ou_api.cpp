@@ -161,6 +161,8 @@ struct Runner {
     const float* fir = nullptr;
     int fir_len = 0;
     const float* fir_bias = nullptr;
+    // small-K rate-change conv of a wide level on rate_down_kernel (`fir` = the filter applied BEFORE the conv, or null)
+    bool rate_down = false;
   };
   bool unsupported = false;
 
@@ -179,7 +181,8 @@ struct Runner {
     a.add = e.add; a.add_scale = e.add_scale;
     a.film = e.film; a.film_bstride = e.film_bstride;
     a.res = e.res; a.res_scale = e.res_scale;
-    if (e.fir) { a.fir = e.fir; a.fir_len = e.fir_len; a.bias = e.fir_bias; }
+    if (e.fir && !e.rate_down) { a.fir = e.fir; a.fir_len = e.fir_len; a.bias = e.fir_bias; }
+    if (e.rate_down) { a.fir = e.fir; a.fir_len = e.fir ? e.fir_len : 0; }
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
     a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
@@ -200,7 +203,9 @@ struct Runner {
       h->prof_used++;
     }
     unsupported = false;
-    {
+    if (e.rate_down) {
+      chk(launch_rate_down(a, st, &cfg), L.name.c_str());
+    } else {
       const hipError_t le = launch_conv(a, h->num_cu, st, &cfg);
       if (le == hipErrorNotSupported && e.fir) {  // the caller falls back to conv + launch_fir
         if (a.prof) { h->prof.pop_back(); h->prof_used--; }
@@ -358,7 +363,21 @@ struct Runner {
     BlockOut o;
     o.v = v; o.c1 = c1; o.h_next = v;
     if (Bk.dir == 1) {  // blocks.py:401-410
-      if (Bk.rc.fir_mode == 1) {
+      bool small = false;
+      if (Bk.rc.fir_mode <= 1) {  // wide levels: FIR + strided conv in one launch (pure function of the layer shape)
+        const char* senv = std::getenv("OU_RATE_SMALL");
+        ConvArgs probe;
+        probe.up = Bk.rc.up; probe.stride = Bk.rc.stride; probe.KW = Bk.rc.KW; probe.pad = Bk.rc.pad; probe.Tin = v.T;
+        probe.Nq = v.T / Bk.rc.stride; probe.M = Bk.rc.M; probe.Cin = Bk.rc.Cin;
+        probe.fir = Bk.rc.fir_mode == 1 ? h->W : nullptr; probe.fir_len = Bk.rc.fir_len;
+        small = (!senv || std::atoi(senv) != 0) && rate_down_supported(probe);
+      }
+      if (small) {
+        Epi e;
+        e.rate_down = true;
+        if (Bk.rc.fir_mode == 1) { e.fir = W(Bk.rc.fir_off); e.fir_len = Bk.rc.fir_len; }
+        o.h_next = conv(Bk.rc, v, nm + ".h", e);
+      } else if (Bk.rc.fir_mode == 1) {
         Tensor xf = alloc(nm + ".fir", v.C, v.T);
         if (!dry && ok())
           chk(launch_fir(v.p, W(Bk.rc.fir_off), Bk.rc.fir_len, h->alphas[Bk.rc.a_off], 1, nullptr, nullptr, 1.f, xf.p, B,

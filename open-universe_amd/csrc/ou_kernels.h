@@ -50,6 +50,11 @@ struct ConvArgs {
 // returns hipSuccess or the launch error; `cfg_out` (optional) receives the tile configuration index used
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out = nullptr);
 hipError_t init_conv_kernels();  // raises the dynamic-LDS limit of every instantiation
+// Small-K rate-change conv of the wide levels with the anti-alias FIR fused: y = conv_{k=s=r}(FIR(prelu(x))) + bias
+// (a.fir = taps or null, a.fir_len = 2r + 1; a.act / a.alpha_val = the PReLU).  hipErrorNotSupported = use launch_fir +
+// launch_conv.
+bool rate_down_supported(const ConvArgs& a);
+hipError_t launch_rate_down(const ConvArgs& a, hipStream_t st, int* cfg_out = nullptr);
 
 // ---- small VALU kernels ------------------------------------------------------------------------------------
 // Per-step scalars of the sampler / EDM wrapper (universe.py:175-209, 333-343), one row per batch element

@@ -1680,6 +1680,156 @@ hipError_t launch_chain(const ChainArgs& a, int num_cu, hipStream_t st, int* var
 }
 
 // =========================================================================================================
+// Small-K rate-change convs of the wide levels, with the anti-alias FIR fused (blocks.py:205-227)
+//   down:  y = conv_{k=s=R}(FIR_{2R+1}(prelu(x))) + bias        K = Cin R <= 96, M = Cout <= 96
+// At T = 64 160 the first rate-change conv is a 0.26 GFLOP GEMM with K = 64: bandwidth- and latency-sized work that used
+// to take a FIR pass (6.5 us) + a generic conv launch (11.4 us) + a dispatch gap; here 11.6 us in one launch.  (The next
+// level -- K = 256, M = 128, 251 workgroups with one wave per SIMD -- came out at 19.6 us against 10.6 + 6.5: its phases
+// run back to back with nothing to overlap them, so it stays on the FIR pass + the strided direct kernel.)
+// One workgroup owns BQ output frames and ALL output channels, so nothing is split or reduced across waves:
+//   1. every thread loads runs of the input, applies PReLU and the FIR in registers (same tap order as fir_kernel) and
+//      writes the filtered tile to LDS once;
+//   2. the whole weight matrix of the layer sits in registers (K/2 A operands per lane, issued before step 1);
+//   3. K/2 MFMAs per wave on B operands read from LDS; bias in the epilogue, stores straight from the accumulators.
+// =========================================================================================================
+template <int R, int MT, int NWN, int K2>
+__global__ __launch_bounds__(64 * MT * NWN) void rate_down_kernel(ConvArgs p) {
+  constexpr int NW = MT * NWN, NT = 64 * NW, BQ = 32 * NWN, SP = BQ * R, ROW = SP + 4, NCH = SP / 4;
+  static_assert(SP % 4 == 0, "runs of 4 samples");
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // xf[Cin][ROW]
+  const int tid = threadIdx.x, lane = tid & 63, lhalf = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % MT, wn = wave / MT;
+  const int q0 = blockIdx.x * BQ, b = blockIdx.y;
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const int Cin = p.Cin, Tin = p.Tin, Mp = p.Mp, CK = p.CK, lck = 31 - __clz(CK);
+  // ---- filtered input tile -> LDS.  Work item = (channel, run of 4 output samples); the raw windows of IB items are
+  // loaded first (wide loads where the window is inside the row), then filtered: with one wave per SIMD nothing else
+  // hides a dependent load -> FIR -> store chain per item.
+  const bool fir = p.fir != nullptr;
+  float f[2 * R + 1];
+#pragma unroll
+  for (int j = 0; j <= 2 * R; j++) f[j] = fir ? p.fir[j] : 0.f;
+  const float alpha = p.alpha_val;
+  const bool act = p.act != 0;
+  const float* xb = p.x + (size_t)b * Cin * Tin;
+  constexpr int CIN = 2 * K2 / R, ITEMS = CIN * NCH / NT, IB = ITEMS < 4 ? ITEMS : 4, WIN = 4 + 2 * R;
+  static_assert(CIN * NCH % NT == 0 && ITEMS % IB == 0, "items per thread");
+  // (the K/2 A operands -- the layer's whole weight matrix -- are requested right after the first batch of input
+  // windows: loads return in order, so the filter only waits for the windows and the weights land behind it)
+  float a[K2];
+#pragma unroll 1
+  for (int i0 = 0; i0 < ITEMS; i0 += IB) {
+    float v[IB][WIN];
+#pragma unroll
+    for (int u = 0; u < IB; u++) {
+      const int item = tid + (i0 + u) * NT;
+      const int ci = item / NCH, c = item - ci * NCH;
+      const int ts = q0 * R + 4 * c - (fir ? R : 0);  // first sample of the window (a multiple of 2 / of 4 for R = 4)
+      const int nwin = fir ? WIN : 4;
+      const float* xr = xb + (size_t)ci * Tin;
+      if (ts >= 0 && ts + nwin <= Tin) {
+        if (!fir) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(xr + ts);
+          v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < WIN; i += 2) {
+            const f32x2 q = *reinterpret_cast<const f32x2*>(xr + ts + i);
+            v[u][i] = q.x; v[u][i + 1] = q.y;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < WIN; i++) {
+          const int t = ts + i;
+          v[u][i] = (i < nwin && t >= 0 && t < Tin) ? xr[t] : 0.f;
+        }
+      }
+    }
+    if (i0 == 0) {
+      // K index 2 ks + half = (ci, tap), packed row ((ci / CK) R + tap) CK + ci % CK
+#pragma unroll
+      for (int ks = 0; ks < K2; ks++) {
+        const int idx = 2 * ks + lhalf, ci = idx / R, tap = idx - ci * R;
+        const int row = (((ci >> lck) * R + tap) << lck) + (ci & (CK - 1));
+        a[ks] = p.w[(size_t)row * Mp + 32 * wm + l31];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < IB; u++) {
+      const int item = tid + (i0 + u) * NT;
+      const int ci = item / NCH, c = item - ci * NCH;
+#pragma unroll
+      for (int i = 0; i < WIN; i++) v[u][i] = (act && v[u][i] < 0.f) ? alpha * v[u][i] : v[u][i];  // blocks.py:213
+      f32x4 o;
+      if (fir) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float acc = 0.f;
+#pragma unroll
+          for (int i = 0; i <= 2 * R; i++) acc = fmaf(f[i], v[u][j + i], acc);
+          o[j] = acc;
+        }
+      } else {
+        o = f32x4{v[u][0], v[u][1], v[u][2], v[u][3]};
+      }
+      *reinterpret_cast<f32x4*>(&smem[ci * ROW + 4 * c]) = o;
+    }
+  }
+  __syncthreads();
+  // ---- K/2 MFMAs per wave
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+  const float* bs = smem + (32 * wn + l31) * R;
+#pragma unroll
+  for (int ks = 0; ks < K2; ks++) {
+    const int idx = 2 * ks + lhalf, ci = idx / R, tap = idx - ci * R;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], bs[ci * ROW + tap], acc, 0, 0, 0);
+  }
+  // ---- epilogue
+  const int q = q0 + 32 * wn + l31;
+  if (q < p.Nq) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+      if (m < p.M) p.y[((size_t)b * p.Cout + m) * p.Nq + q] = acc[r] + p.bias[m];
+    }
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+struct RateDownCfg {
+  int R, M, Cin;
+  void (*kern)(ConvArgs);
+  int threads, bq;
+};
+static const RateDownCfg kRateDownCfgs[] = {
+    {2, 64, 32, rate_down_kernel<2, 2, 2, 32>, 256, 64},    // PP16 / OR16: 32 -> 64 channels, T -> T/2
+    {2, 96, 48, rate_down_kernel<2, 3, 1, 48>, 192, 32},    // PP24: 48 -> 96
+};
+bool rate_down_supported(const ConvArgs& a) {
+  if (a.up != 1 || a.stride != a.KW || a.pad != 0 || a.Tin != a.Nq * a.stride || a.add || a.film || a.res || a.in_scale)
+    return false;
+  if (a.fir && a.fir_len != 2 * a.stride + 1) return false;
+  for (const RateDownCfg& c : kRateDownCfgs)
+    if (c.R == a.stride && c.M == a.M && c.Cin == a.Cin) return true;
+  return false;
+}
+hipError_t launch_rate_down(const ConvArgs& a, hipStream_t st, int* cfg_out) {
+  if (!rate_down_supported(a)) return hipErrorNotSupported;
+  for (const RateDownCfg& c : kRateDownCfgs) {
+    if (c.R != a.stride || c.M != a.M || c.Cin != a.Cin) continue;
+    const size_t smem = (size_t)a.Cin * (c.bq * c.R + 4) * 4;
+    if (cfg_out) *cfg_out = 40 + c.R;
+    hipLaunchKernelGGL(c.kern, dim3((a.Nq + c.bq - 1) / c.bq, a.B), dim3(c.threads), smem, st, a);
+    return hipGetLastError();
+  }
+  return hipErrorNotSupported;
+}
+
+// =========================================================================================================
 // small VALU kernels
 // =========================================================================================================
 __device__ __forceinline__ float prelu(float v, float a) { return v >= 0.f ? v : a * v; }

@@ -445,3 +445,21 @@ def test_folded_fir_weights_match_separate_fir_pass(monkeypatch):
     assert sum(folded.launch_stats()) < sum(model.launch_stats())
     for b in range(B):
         record(f"fir_fold.{b}", O.si_sdr(ref[b], out[b]), 100)
+
+
+@pytest.mark.parametrize("name,B,T", [("PP16", 2, 23517), ("PP24", 1, 30011), ("OR16", 1, 64000)])
+def test_fused_first_rate_change_conv_matches_fir_pass_plus_conv(name, B, T, monkeypatch):
+    """rate_down_kernel (PReLU -> FIR -> k = s = r conv of the first level in one launch, no split-K) vs the FIR pass + the
+    generic strided conv (OU_RATE_SMALL=0): same filter tap order, different K order in the conv."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(53, 2, B, Tp)
+    monkeypatch.setenv("OU_RATE_SMALL", "0")
+    ref = run_enhance(model, mix, nz, n_steps=2)
+    n_ref = model.launch_stats()
+    monkeypatch.delenv("OU_RATE_SMALL")
+    out = run_enhance(model, mix, nz, n_steps=2)
+    assert sum(model.launch_stats()) < sum(n_ref) or not spec.score.use_antialiasing
+    for b in range(B):
+        record(f"rate_down.{name}.{b}", O.si_sdr(ref[b], out[b]), 100)
