@@ -130,7 +130,7 @@ void json_conv(std::ostringstream& os, const ConvL& L, bool& first) {
      << ",\"M\":" << L.M << ",\"Mp\":" << L.Mp << ",\"CK\":" << L.CK << ",\"rate\":" << L.rate << ",\"act\":" << L.act
      << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"a_off\":" << L.a_off
      << ",\"fir_mode\":" << L.fir_mode << ",\"fir_len\":" << L.fir_len << ",\"fir_off\":" << L.fir_off
-     << ",\"fbias_off\":" << L.fbias_off << "}";
+     << ",\"fbias_off\":" << L.fbias_off << ",\"wd_off\":" << L.wd_off << ",\"KWP\":" << L.KWP << "}";
 }
 void json_block(std::ostringstream& os, const BlockL& B, bool& first) {
   if (B.dir) json_conv(os, B.rc, first);

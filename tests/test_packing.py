@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 import restatement as O
-from helpers import emulate_conv, get_spec, plan_convs
+from helpers import emulate_conv, get_spec, plan_convs, unpack_conv
 from open_universe_amd import _lib
 from open_universe_amd import state_dict as S
 
@@ -65,6 +65,27 @@ def test_pack_all_convs(built_lib, name):
             assert torch.allclose(y, ref, atol=2e-5, rtol=1e-4), nm
         n_checked += 1
     assert n_checked == len(convs) and n_checked > 60
+
+
+def test_taps_innermost_weight_copy_equals_the_tap_major_one(built_lib):
+    """Stride-1 k3 / k5 layers with Cin % 64 == 0 carry a second copy [Cin][Mp][4 | 8] for conv_direct2_kernel: same
+    numbers as the [Cin/CK][KW][CK][Mp] layout, zero in the padding taps and rows."""
+    spec = get_spec("PP16m")
+    sd = S.synthetic_state_dict(spec, seed=5)
+    blob, plan = _lib.pack_weights(spec, sd)
+    n = 0
+    for nm, L in plan_convs(plan).items():
+        if not L["KWP"]:
+            assert not (L["stride"] == 1 and L["up"] == 1 and L["KW"] in (3, 5) and L["Cin"] % 64 == 0), nm
+            continue
+        assert L["KW"] in (3, 5) and L["KWP"] == (4 if L["KW"] == 3 else 8) and L["Cin"] % 64 == 0
+        Cin, KW, KWP, Mp, M = L["Cin"], L["KW"], L["KWP"], L["Mp"], L["M"]
+        W, _, _ = unpack_conv(blob, L)                                     # [M][Cin][KW]
+        wd = blob[L["wd_off"]: L["wd_off"] + Cin * Mp * KWP].view(Cin, Mp, KWP)
+        assert torch.equal(wd[:, :M, :KW].permute(1, 0, 2), W), nm
+        assert not wd[:, :, KW:].any() and not wd[:, M:, :].any(), nm
+        n += 1
+    assert n >= 20
 
 
 def test_pack_errors(built_lib):
