@@ -602,13 +602,15 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
 //     B fragment (tap, pair I, tile j): lane (n, half) <- x[2I + half][n0 + 32 j + n + tap - pad]
 //                                       2 x 128 B; the KW shifted reads of a row hit the same L1 lines
 //   as a 4-deep ring of register groups (one group = GP channel pairs x KW taps): the loads of group g + 4 are issued
-//   right after the MFMAs of group g, so ~40-60 loads are in flight per wave at any time; the compiler's own
-//   s_waitcnt placement (loads return in order) turns the ring into counted vmcnt waits with no hand-written
-//   bookkeeping.  Zero padding = per-lane offsets past the buffer bounds (computed once per block).  No LDS, no
-//   barrier and ~1 scalar instruction per load in the main loop; LDS only for the cross-wave reduction of the epilogue
-//   (shared with conv_mfma_kernel's fused epilogue: bias, cond add, FiLM, residual).
+//   right after the MFMAs of group g, so ~40-60 loads are in flight per wave at any time.  Loads and their counted
+//   s_waitcnt vmcnt(N) are inline asm (see conv_direct_kernel; tools/check_isa.py verifies the generated code).  Zero
+//   padding = per-lane offsets past the buffer bounds (computed once per block).  No LDS, no barrier and ~1 scalar
+//   instruction per load in the main loop; LDS only for the cross-wave reduction of the epilogue (bias, cond add, FiLM,
+//   residual, optionally the up-path FIR).
 //   Same K order per output element as conv_mfma_kernel's split-K configs (pairs kw, kw + 8, ... tap-inner vs tap-outer
 //   differs) -- results agree to fp32 rounding, not bit-wise.
+//   Family: conv_direct_kernel (this scheme; now the 1x1 / phase-GEMM layers), conv_direct2_kernel (k3 / k5: one 16-byte
+//   load per operand feeds all taps), conv_direct_strided_kernel (rate-change convs).
 // =========================================================================================================
 // Block -> output tile of the direct kernels (same XCD-aware mappings as conv_mfma_kernel).  false: padding block.
 __device__ __forceinline__ bool direct_tile(const ConvArgs& p, int& tile_m, int& tile_n) {
