@@ -403,13 +403,15 @@ struct Runner {
     GruArgs a;
     a.gx = gx.p; a.whh = W(G.whh_off); a.bhn = W(G.bhn_off); a.out = out.p; a.res = res; a.res_scale = res_scale;
     a.xchg = xchg; a.err = errw; a.epoch = epoch; a.B = B; a.T = in.T; a.H = G.H;
-    // kernel generation: the ring kernel (every wave gathers h straight from L2) is the latency-optimal one; its poll
-    // traffic grows with the number of clusters, so it takes the launches of up to 256 workgroups (PP16: B <= 8) and the
-    // polling-wave kernel the rest (measured: 12.4 / 19.4 / 34.0 vs 13.2 / 20.2 / 34.6 ms per PP16 enhance at B = 2 / 4 /
-    // 8; OR16 B = 16 and PP24 B = 8: 65.1 / 112.7 vs 63.4 / 111.3 ms)
+    // kernel generation: the ring kernel (every wave gathers h straight from L2) is the latency-optimal one and serves
+    // batch 1 (two clusters).  With more clusters its plain publishes are occasionally not seen by the other CUs until
+    // the safety net re-stores them ~0.5 ms later (gru_ring_kernel): harmless for the result, but PP24 at B = 4 (8 clusters
+    // of 24 workgroups) lost 50 ms per enhance to such stalls in one run out of two, and the gain it could make there
+    // (PP16: 12.4 / 19.4 / 34.0 vs 13.2 / 20.2 / 34.6 ms at B = 2 / 4 / 8) is small -- so batches > 1 use the polling-wave
+    // kernel, whose publishes are followed by a workgroup barrier (vmcnt(0)) every step.
     {
       const char* f = std::getenv("OU_GRU_V");
-      a.version = f ? std::atoi(f) : (2 * B * (G.H / 16) <= 256 ? 2 : 1);
+      a.version = f ? std::atoi(f) : (B == 1 ? 2 : 1);
     }
     { const char* f = std::getenv("OU_GRU_BMAX"); a.force_bmax = f ? std::atoi(f) : 0; }
     if (std::getenv("OU_GRU_TS")) a.tstamps = (long long*)(base + cap - (1u << 20));

@@ -2863,6 +2863,7 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
         same = !fail && (unsigned)v == xcc;
       }
       plain = __builtin_amdgcn_ballot_w64(!same) == 0ull && !p.agent_stores;
+      if (!plain && tid == 0) atomicAdd(p.err + 30, 1u);  // diagnostics: workgroups whose cluster spans XCDs
       if (fail) { atomicOr(p.err, 2u); p.err[8] = (unsigned)cluster; p.err[9] = (unsigned)g; p.err[10] = epoch; }
     }
 
@@ -2964,10 +2965,28 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
           // -- a publish was seen to stay invisible to the other CUs for good.  Everybody ends up waiting then, the wave
           // whose store is missing too: after ~0.5 ms of waiting every wave repeats its last publish (tag epoch + step) as
           // a system-scope write-through store.  Never taken in a healthy batch-1 run.
-          if ((spins & 1023u) == 1023u && fin) {
-            const unsigned long long gran = ((unsigned long long)want << 32) | (unsigned)__float_as_int(hprev);
-            unsigned long long* dst = xq + (size_t)(step & 1) * H + unit;
-            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(gran) : "memory");
+          if ((spins & 1023u) == 1023u) {
+            if (fin) {
+              const unsigned long long gran = ((unsigned long long)want << 32) | (unsigned)__float_as_int(hprev);
+              unsigned long long* dst = xq + (size_t)(step & 1) * H + unit;
+              asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(gran) : "memory");
+            }
+            // diagnostics (status words 20..31): activations; the first one records who missed which granule
+            if (m != want) {
+              int stale = -1;
+              unsigned stag = 0;
+#pragma unroll
+              for (int k = 0; k < NC / 2; k++) {
+                const int col = cg * 4 + 4 * LPU * (k >> 1) + 2 * (k & 1);
+                if (hv[k].y != want && stale < 0) { stale = col; stag = hv[k].y; }
+                if (hv[k].w != want && stale < 0) { stale = col + 1; stag = hv[k].w; }
+              }
+              if (atomicAdd(p.err + 20, 1u) == 0u) {
+                p.err[21] = (unsigned)cluster; p.err[22] = (unsigned)g; p.err[23] = (unsigned)(tid >> 6);
+                p.err[24] = (unsigned)step; p.err[25] = (unsigned)stale; p.err[26] = stag; p.err[27] = want;
+                p.err[28] = spins; p.err[29] = xcc;
+              }
+            }
           }
           if (spins > GRU_SPIN_LIMIT) {
             atomicOr(p.err, 4u);  // diagnostics: who waited for what

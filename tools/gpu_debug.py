@@ -94,13 +94,13 @@ def run(name, B=2, T=None, n_steps=4, seed=0):
 
 
 
-def timing(name="PP16", B=1, T=64000, n_steps=8, iters=5):
+def timing(name="PP16", B=1, T=64000, n_steps=8, iters=5, check=0):
     spec = get_spec(name)
     sd = S.synthetic_state_dict(spec, seed=0)
     model = Universe(spec, state_dict=sd, device="cuda:0")
     mix = synth_mix(spec, B, T).cuda()
     rng = torch.Generator(device="cuda").manual_seed(1028282)
-    model.check_status = False
+    model.check_status = bool(check)
     for _ in range(2):
         model.enhance(mix, n_steps=n_steps, rng=rng)
     torch.cuda.synchronize()
@@ -114,6 +114,10 @@ def timing(name="PP16", B=1, T=64000, n_steps=8, iters=5):
     med = ts[len(ts) // 2]
     print(f"TIMING {name} B={B} T={T} N={n_steps}: median {med*1e3:.2f} ms  min {ts[0]*1e3:.2f} ms  "
           f"RTF {B*T/spec.fs/med:.1f}x  utt/s {B/med:.2f}  launches {model.launch_stats()}")
+    if os.environ.get("OU_STALL_DIAG"):
+        d = model._ws[:128].view(torch.int32).cpu().tolist()
+        print("   all iterations ms:", [round(t * 1e3, 1) for t in ts], "| ring-GRU net activations", d[20], "first:",
+              d[21:30], "non-plain workgroups", d[30])
 
 
 if __name__ == "__main__":
