@@ -414,6 +414,9 @@ def main():
             "free_running": {"value": audio_s / dt_async, "ms_per_step": 1e3 * dt_async / args.steps,
                              "note": "model.check_status = False: no host sync inside the timed loop, status checked after it"},
             "host_enqueue": host_enqueue,
+            "gru_exchange": dict(model.gru_exchange_stats(),
+                                 note="hand-offs the GRU clusters had to repeat / waves that finished a pass with "
+                                      "system-scope publishes (DESIGN.md 4.4), whole process; both 0 on a healthy device"),
             "roofline": roofline,
         }
         if not args.no_cpu_baseline:

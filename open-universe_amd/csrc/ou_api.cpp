@@ -418,6 +418,7 @@ struct Runner {
     { const char* f = std::getenv("OU_GRU_UPW"); a.force_upw = f ? std::atoi(f) : 0; }
     { const char* f = std::getenv("OU_GRU_BACKOFF"); a.poll_backoff = f ? std::atoi(f) : 0; }
     { const char* f = std::getenv("OU_GRU_AGENT_STORES"); a.agent_stores = f ? std::atoi(f) : 0; }
+    { const char* f = std::getenv("OU_GRU_DBG"); a.dbg = f ? std::atoi(f) : 0; }
     chk(launch_gru(a, h->num_cu, st), G.name.c_str());
     return out;
   }

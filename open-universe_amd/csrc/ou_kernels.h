@@ -168,6 +168,8 @@ struct GruArgs {
   int B = 1, T = 0, H = 0;
   int poll_backoff = 0;  // tuning: 0/1/2 x ~512 cycles of sleep before the first poll
   int agent_stores = 0;  // 1: publish with agent-scope stores even when the cluster shares one XCD
+  int dbg = 0;           // experiments (OU_GRU_DBG): bit 0 = no republish safety net, bit 1 = system-scope publishes from the start,
+                         // bit 2 = fault injection: one workgroup drops its publishes of step 50
   int force_bmax = 0;  // testing: cap the utterances per launch (forces the chunked path at small batches)
   int force_upw = 0;  // tuning: 16 / 32 / 64 hidden units per workgroup (0: chosen from the batch size)
 };

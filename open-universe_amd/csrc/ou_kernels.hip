@@ -2843,6 +2843,7 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
     const bool has_res = p.res != nullptr;
 
     // one-time rendezvous (also proves that every member of the cluster is resident): member g posts {xcc, epoch}
+    bool sysmode = (p.dbg & 2) != 0;  // system-scope publishes for the rest of this launch, see the safety net
     bool plain = false;
     unsigned xcc;
     {
@@ -2938,7 +2939,16 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
               asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0"
                            : "=v"(hv[2 * i + 1]) : "v"(src), "n"(4 * LPU * i * 8 + 16) : "memory");
             }
+          } else if (p.poll_backoff == 4) {  // experiment: system-scope polls
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+              asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0 sc1"
+                           : "=v"(hv[2 * i]) : "v"(src), "n"(4 * LPU * i * 8) : "memory");
+              asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0 sc1"
+                           : "=v"(hv[2 * i + 1]) : "v"(src), "n"(4 * LPU * i * 8 + 16) : "memory");
+            }
           } else {
+            if (p.poll_backoff == 5 && (spins & 15u) == 15u) asm volatile("buffer_inv sc1" ::: "memory");  // experiment
 #pragma unroll
             for (int i = 0; i < NI; i++) {
               asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1"
@@ -2963,14 +2973,19 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
           // Safety net: a plain store carries no visibility deadline.  Under load -- a second process on the device
           // (tests/test_gpu_distributed.py: 1 run in 4 timed out), or dozens of clusters (OR16, B = 16: multi-second stalls)
           // -- a publish was seen to stay invisible to the other CUs for good.  Everybody ends up waiting then, the wave
-          // whose store is missing too: after ~0.5 ms of waiting every wave repeats its last publish (tag epoch + step) as
-          // a system-scope write-through store.  Never taken in a healthy batch-1 run.
-          if ((spins & 1023u) == 1023u) {
+          // whose store is missing too: after ~0.1 ms of waiting (256 poll rounds; a healthy wait is 2-4) every wave repeats
+          // its last publish (tag epoch + step) as a system-scope write-through store.  Never taken in a healthy run.
+          if ((spins & 255u) == 255u && !(p.dbg & 1)) {
             if (fin) {
               const unsigned long long gran = ((unsigned long long)want << 32) | (unsigned)__float_as_int(hprev);
               unsigned long long* dst = xq + (size_t)(step & 1) * H + unit;
               asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(gran) : "memory");
             }
+            // ... and for the rest of this launch the wave publishes that way in the first place: when the effect shows
+            // up it lasts (one GRU pass out of 574 in a profiled run needed a recovery on almost every step: 46 ms
+            // instead of 0.28), whereas a system-scope publish costs about one more hop per step (0.39 ms per pass).
+            // Everybody is waiting when this happens, so the whole cluster switches together.  Status word 31 counts.
+            if (!sysmode) { sysmode = true; atomicAdd(p.err + 31, 1u); }
             // diagnostics (status words 20..31): activations; the first one records who missed which granule
             if (m != want) {
               int stale = -1;
@@ -3035,7 +3050,10 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
           const unsigned long long gran =
               ((unsigned long long)(epoch + (unsigned)step + 1u) << 32) | (unsigned)__float_as_int(hnew);
           unsigned long long* dst = xq + (size_t)((step + 1) & 1) * H + unit;
-          if (plain) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
+          if ((p.dbg & 4) && step == 50 && g == 1) {
+            // fault injection (tests): workgroup 1 "loses" its publishes of step 50 -- the safety net has to bring them back
+          } else if (sysmode) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(gran) : "memory");
+          else if (plain) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
           else __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         p.out[orow + t] = has_res ? (hnew + rs) * p.res_scale : hnew;

@@ -155,6 +155,15 @@ class Universe:
         if self._status_event is not None:
             self._raise_on_status()
 
+    def gru_exchange_stats(self):
+        """Health of the GRU clusters' L2 hand-offs on the current workspace: `recoveries` = publishes that had to be
+        repeated by the safety net (each costs ~0.1 ms), `system_scope` = waves that finished their GRU pass with
+        system-scope publishes after such a recovery (slower steps, no more recoveries).  Both 0 on a healthy device."""
+        if self._ws is None:
+            return {"recoveries": 0, "system_scope": 0}
+        d = self._ws[:128].view(torch.int32).cpu().tolist()
+        return {"recoveries": int(d[20]), "system_scope": int(d[31])}
+
     def tensor(self, name):
         """Debug: view of a named intermediate of the last call inside the workspace -> (B, C, T) tensor."""
         off, C, T = c_size_t(), c_int32(), c_int32()

@@ -54,3 +54,21 @@ def test_ring_kernel_epoch_wrap(monkeypatch):
     assert int(hdr[3]) == 0 and int(hdr[5]) == 0                      # block counters back at zero
     assert torch.equal(ref, run_enhance(model, mix, nz, n_steps=3))
     model._ws_key = None
+
+
+def test_ring_kernel_recovers_a_lost_publish(monkeypatch):
+    """Fault injection (OU_GRU_DBG=4): one workgroup of every cluster drops its publishes of step 50.  The safety net --
+    every waiting wave repeats its last publish as a system-scope store after 256 poll rounds and keeps publishing that
+    way for the rest of the launch -- has to bring the pass to the same result, bit for bit, without a timeout."""
+    model, spec, sd = get_model("PP16")
+    mix = synth_mix(spec, 1, 32000)
+    nz = noise_list(61, 2, 1, 32160)
+    ref = run_enhance(model, mix, nz, n_steps=2)
+    base = model.gru_exchange_stats()
+    monkeypatch.setenv("OU_GRU_DBG", "4")
+    out = run_enhance(model, mix, nz, n_steps=2)
+    monkeypatch.delenv("OU_GRU_DBG")
+    after = model.gru_exchange_stats()
+    assert torch.equal(ref, out)
+    assert after["recoveries"] > base["recoveries"] and after["system_scope"] > base["system_scope"]
+    assert torch.equal(run_enhance(model, mix, nz, n_steps=2), ref)  # and the next launch is back on the fast path

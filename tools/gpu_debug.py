@@ -117,7 +117,7 @@ def timing(name="PP16", B=1, T=64000, n_steps=8, iters=5, check=0):
     if os.environ.get("OU_STALL_DIAG"):
         d = model._ws[:128].view(torch.int32).cpu().tolist()
         print("   all iterations ms:", [round(t * 1e3, 1) for t in ts], "| ring-GRU net activations", d[20], "first:",
-              d[21:30], "non-plain workgroups", d[30])
+              d[21:30], "non-plain workgroups", d[30], "system-scope mode", d[31])
 
 
 if __name__ == "__main__":
