@@ -12,6 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
@@ -2800,7 +2801,7 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
   constexpr int H = 64 * HB, NT = 256, LPU = NT / UPW, NC = H / LPU, NI = NC / 4, NWG = H / UPW;
   constexpr int CSTRIDE = 2 * H + 64;  // granules per cluster: two parity buffers + rendezvous slots
   static_assert(LPU == 8 || LPU == 16 || LPU == 32, "8, 16 or 32 lanes per hidden unit");
-  static_assert(NC % 4 == 0 && NWG > 1 && NWG <= 64, "column blocks / rendezvous slots");
+  static_assert(NC % 4 == 0 && NWG > 1 && NWG < 64, "column blocks / rendezvous slots (slot 63 = the mode flag)");
   const int tid = threadIdx.x, lane = tid & 63;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
@@ -2905,6 +2906,8 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // weights landed: no vmcnt(0) inside the loop on their account
 
     if (ts_on) r_loop = (long long)__builtin_amdgcn_s_memrealtime();
+    bool fast_pub = plain && !sysmode;                                   // plain-store publishes
+    const int inject_step = ((p.dbg & 4) && g == 1) ? 50 : -1;           // fault injection (tests)
     for (int step = 0; step < T; step++, t += dt) {
       long long q0 = 0, q1 = 0;
       if (ts_on) q0 = __builtin_readcyclecounter();
@@ -2975,7 +2978,16 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
           // -- a publish was seen to stay invisible to the other CUs for good.  Everybody ends up waiting then, the wave
           // whose store is missing too: after ~0.1 ms of waiting (256 poll rounds; a healthy wait is 2-4) every wave repeats
           // its last publish (tag epoch + step) as a system-scope write-through store.  Never taken in a healthy run.
-          if ((spins & 255u) == 255u && !(p.dbg & 1)) {
+          if (__builtin_expect((spins & 15u) != 15u, 1)) continue;
+          // a wait that long is unusual (a healthy one takes 2-4 rounds): has somebody raised the cluster's mode flag?
+          bool flagged = false;
+          if (!sysmode && !(p.dbg & 1)) {
+            u32x2 mflag;
+            asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=v"(mflag) : "v"(xq + 2 * H + 63) : "memory");
+            flagged = __builtin_amdgcn_readfirstlane(mflag.y) == epoch;
+          }
+          if (((spins & 255u) == 255u || flagged) && !(p.dbg & 1)) {
             if (fin) {
               const unsigned long long gran = ((unsigned long long)want << 32) | (unsigned)__float_as_int(hprev);
               unsigned long long* dst = xq + (size_t)(step & 1) * H + unit;
@@ -2984,24 +2996,20 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
             // ... and for the rest of this launch the wave publishes that way in the first place: when the effect shows
             // up it lasts (one GRU pass out of 574 in a profiled run needed a recovery on almost every step: 46 ms
             // instead of 0.28), whereas a system-scope publish costs about one more hop per step (0.39 ms per pass).
-            // Everybody is waiting when this happens, so the whole cluster switches together.  Status word 31 counts.
-            if (!sysmode) { sysmode = true; atomicAdd(p.err + 31, 1u); }
-            // diagnostics (status words 20..31): activations; the first one records who missed which granule
-            if (m != want) {
-              int stale = -1;
-              unsigned stag = 0;
-#pragma unroll
-              for (int k = 0; k < NC / 2; k++) {
-                const int col = cg * 4 + 4 * LPU * (k >> 1) + 2 * (k & 1);
-                if (hv[k].y != want && stale < 0) { stale = col; stag = hv[k].y; }
-                if (hv[k].w != want && stale < 0) { stale = col + 1; stag = hv[k].w; }
-              }
-              if (atomicAdd(p.err + 20, 1u) == 0u) {
-                p.err[21] = (unsigned)cluster; p.err[22] = (unsigned)g; p.err[23] = (unsigned)(tid >> 6);
-                p.err[24] = (unsigned)step; p.err[25] = (unsigned)stale; p.err[26] = stag; p.err[27] = want;
-                p.err[28] = spins; p.err[29] = xcc;
+            // The cluster's flag granule (slot 63 of the rendezvous area, = this launch's epoch) makes every other wave
+            // -- they are all waiting, and look at the flag every 16 rounds -- switch right away instead of after a
+            // 256-round wait of its own (64 waves x 0.1 ms otherwise).  Status word 31 counts the triggers.
+            if (!sysmode) {
+              sysmode = true;
+              fast_pub = false;
+              if (lane == 0 && !flagged) {  // tell the rest of the cluster: flag granule = this launch's epoch
+                const unsigned long long fl = ((unsigned long long)epoch << 32) | 1u;
+                asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(xq + 2 * H + 63), "v"(fl) : "memory");
+                atomicAdd(p.err + 31, 1u);
               }
             }
+            // status word 20 counts the recoveries (one per wave and event)
+            if (lane == 0) atomicAdd(p.err + 20, 1u);
           }
           if (spins > GRU_SPIN_LIMIT) {
             atomicOr(p.err, 4u);  // diagnostics: who waited for what
@@ -3050,11 +3058,16 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
           const unsigned long long gran =
               ((unsigned long long)(epoch + (unsigned)step + 1u) << 32) | (unsigned)__float_as_int(hnew);
           unsigned long long* dst = xq + (size_t)((step + 1) & 1) * H + unit;
-          if ((p.dbg & 4) && step == 50 && g == 1) {
+          // (one branch on the fast path: this store is on the critical path of every step)
+          if (__builtin_expect(fast_pub && step != inject_step, 1)) {
+            asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
+          } else if (step == inject_step) {
             // fault injection (tests): workgroup 1 "loses" its publishes of step 50 -- the safety net has to bring them back
-          } else if (sysmode) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(gran) : "memory");
-          else if (plain) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
-          else __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else if (sysmode) {
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(gran) : "memory");
+          } else {
+            __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
         p.out[orow + t] = has_res ? (hnew + rs) * p.res_scale : hnew;
       }
