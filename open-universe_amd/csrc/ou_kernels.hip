@@ -2794,6 +2794,30 @@ __device__ __forceinline__ void gather_wait(u32x4 (&hv)[N]) {
   else static_assert(N == 2, "gather_wait: unsupported register count");
 }
 
+// Experiment (OU_GRU_DBG bit 3), out of line so that the hot loop does not change: when a hand-off has not arrived after
+// 256 poll rounds, look at the first stale granule of this lane's columns once more with three kinds of loads and leave
+// what they return in status words 21..29 (first event only).
+__device__ __attribute__((noinline)) void gru_stale_probe(const unsigned long long* buf, int col0, int ncol, int lstride,
+                                                          unsigned want, unsigned* err, unsigned who) {
+  for (int i = 0; i < ncol; i++) {
+    const unsigned long long* g = buf + col0 + (i >> 2) * lstride + (i & 3);
+    u32x2 a, b, c;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(g) : "memory");
+    if (a.y == want) continue;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(b) : "v"(g) : "memory");
+    const unsigned long long v = __hip_atomic_fetch_or(const_cast<unsigned long long*>(g), 0ull, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+    c = u32x2{(unsigned)v, (unsigned)(v >> 32)};
+    if (atomicAdd(err + 21, 1u) == 0u) {
+      err[22] = who; err[23] = (unsigned)(col0 + (i >> 2) * lstride + (i & 3)); err[24] = want;
+      err[25] = a.y; err[26] = b.y; err[27] = c.y;
+      asm volatile("buffer_inv sc1\n\tglobal_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(g) : "memory");
+      err[28] = a.y;
+    }
+    return;
+  }
+}
+
 constexpr unsigned GRU_EPOCH_WRAP = 0x7F000000u;  // past this the last block of a launch clears the exchange area
 
 template <int HB, int UPW>
@@ -2988,6 +3012,9 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
             flagged = __builtin_amdgcn_readfirstlane(mflag.y) == epoch;
           }
           if (((spins & 255u) == 255u || flagged) && !(p.dbg & 1)) {
+            if ((p.dbg & 8) && !flagged)
+              gru_stale_probe(xq + (size_t)(step & 1) * H, cg * 4, NC, 4 * LPU, want, p.err,
+                              ((unsigned)cluster << 16) | ((unsigned)g << 8) | (unsigned)(tid >> 6));
             if (fin) {
               const unsigned long long gran = ((unsigned long long)want << 32) | (unsigned)__float_as_int(hprev);
               unsigned long long* dst = xq + (size_t)(step & 1) * H + unit;

@@ -162,7 +162,11 @@ class Universe:
         if self._ws is None:
             return {"recoveries": 0, "system_scope": 0}
         d = self._ws[:128].view(torch.int32).cpu().tolist()
-        return {"recoveries": int(d[20]), "system_scope": int(d[31])}
+        out = {"recoveries": int(d[20]), "system_scope": int(d[31])}
+        if d[21]:  # OU_GRU_DBG=8: what three kinds of loads saw in the first stale granule (see gru_stale_probe)
+            out["probe"] = {"events": d[21], "who": d[22], "granule": d[23], "want": d[24], "sc1": d[25], "sc0sc1": d[26],
+                            "atomic": d[27], "sc1_after_inv": d[28]}
+        return out
 
     def tensor(self, name):
         """Debug: view of a named intermediate of the last call inside the workspace -> (B, C, T) tensor."""
