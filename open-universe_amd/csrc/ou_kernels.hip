@@ -1105,49 +1105,12 @@ __global__ __launch_bounds__(512) void conv_direct2_kernel(ConvArgs p) {
 // lanes of a half wave -- a lane-strided dword per tap would cost R times the cache-line traffic.  One ring slot =
 // (channel pair, tap block): R A dwords + the wide B loads, R x TN MFMAs.
 // ---------------------------------------------------------------------------------------------------------
-template <int R>
-struct StridedRun {  // R consecutive floats as 16 / 8 / 4-byte pieces
-  static constexpr int N4 = R / 4, N2 = (R % 4) / 2, N1 = R % 2;
-  f32x4 q[N4 ? N4 : 1];
-  f32x2 d[N2 ? N2 : 1];
-  float s[N1 ? N1 : 1];
-  __device__ __forceinline__ void clear() {
-    for (int i = 0; i < (N4 ? N4 : 1); i++) q[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < (N2 ? N2 : 1); i++) d[i] = f32x2{0.f, 0.f};
-    s[0] = 0.f;
-  }
-  __device__ __forceinline__ float get(int k) const {
-    if (k < 4 * N4) return q[k / 4][k % 4];
-    if (k < 4 * N4 + 2 * N2) return d[(k - 4 * N4) / 2][(k - 4 * N4) % 2];
-    return s[0];
-  }
-};
-template <int R>
-__device__ __forceinline__ void strided_load(StridedRun<R>& v, int voff, u32x4 rsrc, int soff) {
-  constexpr int N4 = StridedRun<R>::N4, N2 = StridedRun<R>::N2, N1 = StridedRun<R>::N1;
-#pragma unroll
-  for (int i = 0; i < N4; i++)
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "+v"(v.q[i]) : "v"(voff), "s"(rsrc), "s"(soff), "n"(16 * i));
-#pragma unroll
-  for (int i = 0; i < N2; i++)
-    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4" : "+v"(v.d[i]) : "v"(voff), "s"(rsrc), "s"(soff), "n"(16 * N4 + 8 * i));
-  if constexpr (N1 == 1)
-    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "+v"(v.s[0]) : "v"(voff), "s"(rsrc), "s"(soff), "n"(16 * N4 + 8 * N2));
-}
-template <int R>
-__device__ __forceinline__ void strided_touch(StridedRun<R>& v) {  // "valid past this point" for the register allocator
-#pragma unroll
-  for (int i = 0; i < StridedRun<R>::N4; i++) asm volatile("" : "+v"(v.q[i]));
-#pragma unroll
-  for (int i = 0; i < StridedRun<R>::N2; i++) asm volatile("" : "+v"(v.d[i]));
-  if constexpr (StridedRun<R>::N1 == 1) asm volatile("" : "+v"(v.s[0]));
-}
-
 template <int R, int G, int TN>
 __global__ __launch_bounds__(512) void conv_direct_strided_kernel(ConvArgs p) {
   constexpr int WK = 8, D = 4, BM = 32, BN = 32 * TN, KW = R * G;
-  constexpr int NLD = StridedRun<R>::N4 + StridedRun<R>::N2 + StridedRun<R>::N1;  // load instructions per run
-  constexpr int LPG = R + TN * NLD;                                               // ... per ring slot
+  constexpr int N4 = R / 4, N2 = (R % 4) / 2, N1 = R % 2;  // a run of R samples as 16 / 8 / 4-byte loads
+  constexpr int NLD = N4 + N2 + N1;                          // load instructions per run
+  constexpr int LPG = R + TN * NLD;                          // ... per ring slot
   static_assert(D * LPG <= 60, "loads in flight must fit vmcnt");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1175,44 +1138,62 @@ __global__ __launch_bounds__(512) void conv_direct_strided_kernel(ConvArgs p) {
     }
   const int NS = (p.Cin >> 4) * G;  // ring slots per wave: (pair, tap block), tap block fastest (launcher: multiple of D)
   float av[D][R];
-  StridedRun<R> bv[D][TN];
+  f32x4 bq[D][TN][N4 ? N4 : 1];
+  f32x2 bd[D][TN];
+  float bs[D][TN];
 #pragma unroll
   for (int d0 = 0; d0 < D; d0++) {
 #pragma unroll
     for (int k = 0; k < R; k++) av[d0][k] = 0.f;
 #pragma unroll
-    for (int j = 0; j < TN; j++) bv[d0][j].clear();
+    for (int j = 0; j < TN; j++) {
+#pragma unroll
+      for (int i = 0; i < (N4 ? N4 : 1); i++) bq[d0][j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bd[d0][j] = f32x2{0.f, 0.f};
+      bs[d0][j] = 0.f;
+    }
   }
   floatx16 acc[TN];
 #pragma unroll
   for (int j = 0; j < TN; j++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
-  auto slot_pair = [&](int s) { return G == 1 ? s : s / G; };
 #define OU_ISSUE(s_, d)                                                                                     \
   {                                                                                                         \
     const int s = (s_);                                                                                     \
-    const int pr = slot_pair(s), g = s - pr * G;                                                            \
+    const int pr = G == 1 ? s : s / G, g = s - pr * G;                                                      \
     const int ci = 2 * (kw + WK * pr);                                                                      \
     const int wrow = ((ci >> lck) * KW + g * R) * CK + (ci & (CK - 1));                                     \
     _Pragma("unroll") for (int k = 0; k < R; k++)                                                           \
       asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(av[d][k]) : "v"(avo), "s"(rw), "s"((wrow + k * CK) * Mp * 4)); \
-    int bsel[TN];                                                                                           \
     _Pragma("unroll") for (int j = 0; j < TN; j++) {                                                        \
-      bsel[j] = bvo[0][j];                                                                                  \
-      if (G > 1 && g == 1) bsel[j] = bvo[G > 1 ? 1 : 0][j];                                                 \
-      if (G > 2 && g == 2) bsel[j] = bvo[G > 2 ? 2 : 0][j];                                                 \
-      strided_load<R>(bv[d][j], bsel[j], rx, ci * Tin * 4);                                                 \
+      int bsel = bvo[0][j];                                                                                 \
+      if (G > 1 && g == 1) bsel = bvo[G > 1 ? 1 : 0][j];                                                    \
+      if (G > 2 && g == 2) bsel = bvo[G > 2 ? 2 : 0][j];                                                    \
+      const int xso = ci * Tin * 4;                                                                         \
+      _Pragma("unroll") for (int i = 0; i < N4; i++)                                                        \
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "+v"(bq[d][j][i]) : "v"(bsel), "s"(rx), "s"(xso), "n"(16 * i)); \
+      if constexpr (N2 == 1)                                                                                \
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4" : "+v"(bd[d][j]) : "v"(bsel), "s"(rx), "s"(xso), "n"(16 * N4)); \
+      if constexpr (N1 == 1)                                                                                \
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "+v"(bs[d][j]) : "v"(bsel), "s"(rx), "s"(xso), "n"(16 * N4 + 8 * N2)); \
     }                                                                                                       \
   }
 #define OU_MMA(d, out)                                                                                      \
   {                                                                                                         \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPG));                                                 \
     _Pragma("unroll") for (int k = 0; k < R; k++) asm volatile("" : "+v"(av[d][k]));                        \
-    _Pragma("unroll") for (int j = 0; j < TN; j++) strided_touch<R>(bv[d][j]);                              \
+    _Pragma("unroll") for (int j = 0; j < TN; j++) {                                                        \
+      _Pragma("unroll") for (int i = 0; i < N4; i++) asm volatile("" : "+v"(bq[d][j][i]));                  \
+      if constexpr (N2 == 1) asm volatile("" : "+v"(bd[d][j]));                                             \
+      if constexpr (N1 == 1) asm volatile("" : "+v"(bs[d][j]));                                             \
+    }                                                                                                       \
     _Pragma("unroll") for (int k = 0; k < R; k++)                                                           \
       _Pragma("unroll") for (int j = 0; j < TN; j++) {                                                      \
-        const float x = bv[d][j].get(k);                                                                    \
+        float x;                                                                                            \
+        if (k < 4 * N4) x = bq[d][j][k / 4 < N4 ? k / 4 : 0][k % 4];                                        \
+        else if (k < 4 * N4 + 2 * N2) x = bd[d][j][(k - 4 * N4) % 2];                                       \
+        else x = bs[d][j];                                                                                  \
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d][k], x >= 0.f ? x : alpha * x, acc[j], 0, 0, 0); \
       }                                                                                                     \
   }
