@@ -400,7 +400,7 @@ def main():
                 "workload": f"{what}, {args.n_steps} diffusion steps, batch={args.batch} utterance(s) of "
                             + (f"{min(lens)/spec.fs:.1f}-{max(lens)/spec.fs:.1f} s (variable length, right-zero-padded)"
                                if args.varlen else f"{args.seconds:.0f} s") + " per GPU per step",
-                "model": args.model,
+                "network": args.model,  # PP16 = UNIVERSE++ 16 kHz, OR16 = UNIVERSE 16 kHz, PP24 = UNIVERSE++ 24 kHz
                 "n_diffusion_steps": args.n_steps,
                 "batch_per_gpu": args.batch,
                 "samples_per_utterance": T,
