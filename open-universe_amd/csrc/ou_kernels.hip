@@ -1853,14 +1853,15 @@ hipError_t launch_in_conv(const float* x, const float* w, const float* bias, con
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void out_conv_kernel(const float* __restrict__ s, const float* __restrict__ w,
+__global__ __launch_bounds__(512) void out_conv_kernel(const float* __restrict__ s, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const float* __restrict__ alphas,
                                                        const float* x, const float* noise, float* out,
                                                        const StepCoef* coef, int coef_bstride, int edm, int mode, int C,
                                                        int T, int KW) {
-  // block = 64 time quads x 4 channel groups (one wave each); 4 consecutive output samples per thread from one
-  // aligned float4 + the halo scalars per channel row; the 4 partial sums meet in LDS
-  __shared__ float part[4][64][4];
+  // block = 64 time quads x 8 channel groups (one wave each: at batch 1 the grid is one block per CU, and a wave's
+  // channels are a serial chain of loads); 4 consecutive output samples per thread from one aligned float4 + the halo
+  // scalars per channel row; the 8 partial sums meet in LDS
+  __shared__ float part[8][64][4];
   const int b = blockIdx.y;
   const int tq = threadIdx.x & 63, cgp = threadIdx.x >> 6;
   const int t0 = (blockIdx.x * 64 + tq) * 4;
@@ -1868,7 +1869,7 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const float* __restrict__
   const int pad = (KW - 1) / 2;  // <= 3
   const bool vec = (T & 3) == 0;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const int cpg = (C + 3) / 4;
+  const int cpg = (C + 7) / 8;
   if (t0 < T) {
 #pragma unroll 4
     for (int cc = 0; cc < cpg; cc++) {
@@ -1907,10 +1908,11 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const float* __restrict__
 #pragma unroll
   for (int j = 0; j < 4; j++) part[cgp][tq][j] = acc[j];
   __syncthreads();
-  // thread (tq, j = cgp) finishes sample t0 + j
+  // thread (tq, j = cgp < 4) finishes sample t0 + j
   const int j = cgp, t = t0 + j;
-  if (t >= T) return;
-  const float net = ((part[0][tq][j] + part[1][tq][j]) + (part[2][tq][j] + part[3][tq][j])) + bias[0];
+  if (j >= 4 || t >= T) return;
+  const float net = (((part[0][tq][j] + part[1][tq][j]) + (part[2][tq][j] + part[3][tq][j])) +
+                     ((part[4][tq][j] + part[5][tq][j]) + (part[6][tq][j] + part[7][tq][j]))) + bias[0];
   const StepCoef cf = coef[(size_t)b * coef_bstride];
   const size_t i = (size_t)b * T + t;
   const float xv = x ? x[i] : 0.f;
@@ -1932,7 +1934,7 @@ hipError_t launch_out_conv(const float* s, const float* w, const float* bias, co
                            const float* noise, float* out, const StepCoef* coef, int coef_bstride, int edm, int mode,
                            int B, int C, int T, int KW, hipStream_t st) {
   if (KW > 7) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(out_conv_kernel, dim3((T + 255) / 256, B), dim3(256), 0, st, s, w, bias, alphas, x, noise, out,
+  hipLaunchKernelGGL(out_conv_kernel, dim3((T + 255) / 256, B), dim3(512), 0, st, s, w, bias, alphas, x, noise, out,
                      coef, coef_bstride, edm, mode, C, T, KW);
   return hipGetLastError();
 }
