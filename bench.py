@@ -299,7 +299,7 @@ def main():
             "direct": "ou::conv_direct_kernel / conv_direct_strided_kernel (register-direct split-K: 1x1, phase-GEMM and "
                       "rate-change convs)",
             "lds": "ou::conv_mfma_kernel (LDS-tiled fp32-MFMA implicit-GEMM Conv1d, wide levels / strided convs)",
-            "rate": "ou::rate_down_kernel (first rate-change conv with the anti-alias FIR fused, K = 64)",
+            "rate": "ou::rate_down_kernel / rate_up_kernel (outermost rate-change convs with the anti-alias FIR fused, K = 64)",
             "chain": "ou::conv_chain_kernel (fused ConvBlock body, C = 32 / 64 levels)",
         }
         groups = {"direct2": summarise([r for r in recs if r[3] in (66, 76)]),

@@ -163,6 +163,7 @@ struct Runner {
     const float* fir_bias = nullptr;
     // small-K rate-change conv of a wide level on rate_down_kernel (`fir` = the filter applied BEFORE the conv, or null)
     bool rate_down = false;
+    bool rate_up = false;  // the last up conv on rate_up_kernel (`fir` = the filter AFTER the conv or null, fir_bias / res)
   };
   bool unsupported = false;
 
@@ -181,7 +182,7 @@ struct Runner {
     a.add = e.add; a.add_scale = e.add_scale;
     a.film = e.film; a.film_bstride = e.film_bstride;
     a.res = e.res; a.res_scale = e.res_scale;
-    if (e.fir && !e.rate_down) { a.fir = e.fir; a.fir_len = e.fir_len; a.bias = e.fir_bias; }
+    if (e.fir && !e.rate_down) { a.fir = e.fir; a.fir_len = e.fir_len; a.bias = e.fir_bias; }  // (also rate_up)
     if (e.rate_down) { a.fir = e.fir; a.fir_len = e.fir ? e.fir_len : 0; }
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
@@ -205,6 +206,8 @@ struct Runner {
     unsupported = false;
     if (e.rate_down) {
       chk(launch_rate_down(a, st, &cfg), L.name.c_str());
+    } else if (e.rate_up) {
+      chk(launch_rate_up(a, st, &cfg), L.name.c_str());
     } else {
       const hipError_t le = launch_conv(a, h->num_cu, st, &cfg);
       if (le == hipErrorNotSupported && e.fir) {  // the caller falls back to conv + launch_fir
@@ -269,7 +272,22 @@ struct Runner {
                  const float* input_cond, const float* res, bool need_c1 = false, const Tensor* c1_dst = nullptr,
                  const Tensor* v_dst = nullptr) {
     Tensor hu = hin;
-    if (Bk.dir == 2) {
+    bool small_up = false;
+    if (Bk.dir == 2 && (Bk.rc.fir_mode == 0 || Bk.rc.fir_mode == 2)) {  // pure function of the layer shape
+      const char* senv = std::getenv("OU_RATE_SMALL");
+      ConvArgs probe;
+      probe.up = Bk.rc.up; probe.stride = Bk.rc.stride; probe.KW = Bk.rc.KW; probe.pad = Bk.rc.pad; probe.Tin = hin.T;
+      probe.Nq = hin.T; probe.Tout = hin.T * Bk.rc.up; probe.M = Bk.rc.M; probe.Cout = Bk.rc.Cout; probe.Cin = Bk.rc.Cin;
+      probe.fir = Bk.rc.fir_mode == 2 ? h->W : nullptr; probe.fir_len = Bk.rc.fir_len;
+      small_up = (!senv || std::atoi(senv) != 0) && rate_up_supported(probe);
+    }
+    if (small_up) {
+      Epi e;
+      e.rate_up = true;
+      e.res = res; e.res_scale = kInvSqrt2;
+      if (Bk.rc.fir_mode == 2) { e.fir = W(Bk.rc.fir_off); e.fir_len = Bk.rc.fir_len; e.fir_bias = W(Bk.rc.fbias_off); }
+      hu = conv(Bk.rc, hin, nm + ".up", e);
+    } else if (Bk.dir == 2) {
       if (Bk.rc.fir_mode == 2) {
         // PReLU -> transposed conv (r phase GEMMs) -> FIR + bias + residual add: fused into the conv's epilogue where
         // the direct kernel takes the layer, else as one bandwidth pass after it

@@ -55,6 +55,10 @@ hipError_t init_conv_kernels();  // raises the dynamic-LDS limit of every instan
 // launch_conv.
 bool rate_down_supported(const ConvArgs& a);
 hipError_t launch_rate_down(const ConvArgs& a, hipStream_t st, int* cfg_out = nullptr);
+// ... and the last up conv: y = FIR(convT_{k=s=r}(prelu(x))) + bias, then the residual (a.fir = taps or null, a.bias = the
+// bias added after the filter)
+bool rate_up_supported(const ConvArgs& a);
+hipError_t launch_rate_up(const ConvArgs& a, hipStream_t st, int* cfg_out = nullptr);
 
 // ---- small VALU kernels ------------------------------------------------------------------------------------
 // Per-step scalars of the sampler / EDM wrapper (universe.py:175-209, 333-343), one row per batch element

@@ -449,8 +449,9 @@ def test_folded_fir_weights_match_separate_fir_pass(monkeypatch):
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 2, 23517), ("PP24", 1, 30011), ("OR16", 1, 64000)])
 def test_fused_first_rate_change_conv_matches_fir_pass_plus_conv(name, B, T, monkeypatch):
-    """rate_down_kernel (PReLU -> FIR -> k = s = r conv of the first level in one launch, no split-K) vs the FIR pass + the
-    generic strided conv (OU_RATE_SMALL=0): same filter tap order, different K order in the conv."""
+    """rate_down_kernel (PReLU -> FIR -> k = s = r conv of the first level in one launch, no split-K) and rate_up_kernel
+    (PReLU -> transposed conv -> FIR -> bias -> residual of the last level) vs the FIR passes + the generic convs
+    (OU_RATE_SMALL=0): same filter tap order, different K order in the convs."""
     model, spec, sd = get_model(name)
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)

@@ -19,7 +19,7 @@ for n in sorted(os.listdir(src)):
         shutil.copy(os.path.join(src, n), os.path.join(dst, f"{tag}_{n}"))
 
 FAMS = {"direct2": ("conv_direct2_kernel",), "direct": ("conv_direct_kernel", "conv_direct_strided_kernel"),
-        "lds": ("conv_mfma_kernel",), "rate": ("rate_down_kernel",), "chain": ("conv_chain_kernel",), "gru_ring": ("gru_ring_kernel",),
+        "lds": ("conv_mfma_kernel",), "rate": ("rate_down_kernel", "rate_up_kernel"), "chain": ("conv_chain_kernel",), "gru_ring": ("gru_ring_kernel",),
         "gru_cluster": ("gru_cluster_kernel",)}
 
 

@@ -27,7 +27,7 @@ def main(trace_csv, ou_trace_log=None):
         names = [l.split() for l in open(ou_trace_log) if l.startswith("OU_TRACE conv") or l.startswith("OU_TRACE chain")]
         # conv launches of the last enhance, in order, align with the last `per` trace lines
         last = [r for r in seg if any(k in r["Kernel_Name"] for k in ("conv_mfma_kernel", "conv_chain_kernel",
-                                                                      "conv_direct", "rate_down_kernel"))]
+                                                                      "conv_direct", "rate_down_kernel", "rate_up_kernel"))]
         lines = names[-len(last):]
         print(f"per-layer (last enhance, {len(last)} conv launches):")
         seen = set()
