@@ -52,9 +52,11 @@ def synth_mix(fs, B, T, seed0):
 
 
 def cpu_baseline_worker(model_name, n_steps, seconds, budget_s):
-    """Runs in a child process: the oracle timed on the host cores (torch's default intra-op thread count).
-    Bounded sample: one utterance; for more than 8 diffusion steps the cost is measured at 2 and at 8 steps and
-    extended linearly (one enhance = 1 conditioner pass + n score passes, all passes identical)."""
+    """Runs in a child process: the oracle timed on the host cores.  The intra-op thread count is SWEPT (8 / 16 / 32 /
+    64 / 128, capped by the logical CPUs): batch-1 convolutions of this size do not scale to a whole two-socket host --
+    oversubscribed they run several times slower than on 8-16 threads -- and the best setting is what is reported, with
+    the whole sweep beside it.  Bounded sample: one utterance; for more than 8 diffusion steps the cost is measured at 2
+    and at 8 steps and extended linearly (one enhance = 1 conditioner pass + n score passes, all passes identical)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import restatement as O
     import open_universe_amd  # noqa: F401
@@ -63,7 +65,7 @@ def cpu_baseline_worker(model_name, n_steps, seconds, budget_s):
 
     spec = C.spec_from_config(C.builtin_config(model_name))
     sd = S.synthetic_state_dict(spec, seed=0)
-    cores = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
     T = int(seconds * spec.fs)
     mix = synth_mix(spec.fs, 1, T, 1000)
     sdict = spec.to_dict()
@@ -75,15 +77,25 @@ def cpu_baseline_worker(model_name, n_steps, seconds, budget_s):
         return time.time() - t0
 
     n_meas = min(n_steps, 8)
-    warm = timed(n_meas)  # warm-up
-    times = []
-    while len(times) < 3 and (sum(times) + warm) < budget_s:
+    t_begin = time.time()
+    cands = sorted({min(c, ncpu) for c in (8, 16, 32, 64, 128)})
+    sweep = {}
+    torch.set_num_threads(cands[0])
+    timed(2)  # warm-up (allocator, oneDNN primitive caches)
+    for c in cands:
+        if sweep and time.time() - t_begin > 0.6 * budget_s:
+            break
+        torch.set_num_threads(c)
+        timed(2)  # the thread pool of this setting
+        sweep[c] = timed(n_meas)
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    times = [sweep[best]]
+    while len(times) < 3 and time.time() - t_begin < budget_s:
         times.append(timed(n_meas))
-    if not times:
-        times = [warm]
     times.sort()
     med = times[len(times) // 2]
-    how = f"median of {len(times)} run(s) after 1 warm-up"
+    how = f"median of {len(times)} run(s) at the best thread count"
     if n_meas != n_steps:
         t2 = timed(2)
         per_step = max(0.0, (med - t2) / (n_meas - 2))
@@ -93,15 +105,16 @@ def cpu_baseline_worker(model_name, n_steps, seconds, budget_s):
         "value": seconds / med,
         "unit": "x_realtime",
         "utterances_per_s": 1.0 / med,
-        "cores": cores,
+        "cores": best,
         "kind": "port",
+        "thread_sweep_s_per_enhance": {str(k): round(v, 3) for k, v in sweep.items()},
         "sample": f"1 utterance of {seconds:.0f} s, {model_name}, {n_steps} steps, {how} "
-                  f"({med:.2f} s per enhance, {cores} torch threads of {os.cpu_count()} logical CPUs); "
-                  "oracle/restatement.py (validated against the imported reference)",
+                  f"({med:.2f} s per enhance on {best} torch threads; {ncpu} logical CPUs; thread counts tried: "
+                  f"{sorted(sweep)}); oracle/restatement.py (validated against the imported reference)",
     }))
 
 
-def cpu_baseline(model_name, n_steps, seconds, budget_s=25.0, hard_limit_s=150.0):
+def cpu_baseline(model_name, n_steps, seconds, budget_s=30.0, hard_limit_s=180.0):
     """Bounded CPU sample in a child process, so that a pathological host can never stall the GPU bench."""
     import subprocess
 
@@ -139,8 +152,11 @@ def parse_args(argv=None):
     ap.add_argument("--share-devices", action="store_true",
                     help="allow more ranks than visible GPUs (ranks wrap around the devices, gloo rendezvous): "
                          "exercises the N > 1 path on a 1-GPU box; not a scaling measurement")
+    ap.add_argument("--batch-sweep", default="1,4",
+                    help="also time these per-GPU batch sizes (short loops after the main one): one invocation gives the "
+                         "utterances/s curve of configs[1] (batch 1) and of the batched throughput mode; '' = off")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-budget", type=float, default=25.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
@@ -164,6 +180,24 @@ def timed_loop(step, steps, world, device):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     return dt, out
+
+
+def per_rank_ms(step, steps, world, device):
+    """Every rank's OWN time for `steps` steps (no barrier inside), gathered on all ranks: shows stragglers that the
+    MAX-over-ranks figure hides."""
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    mine = 1e3 * (time.perf_counter() - t0) / steps
+    if world == 1:
+        return [mine]
+    allv = [None] * world
+    torch.distributed.all_gather_object(allv, mine)
+    return [float(v) for v in allv]
 
 
 def main():
@@ -202,7 +236,27 @@ def main():
 
     spec = C.spec_from_config(C.builtin_config(args.model))
     sd = S.synthetic_state_dict(spec, seed=0) if rank == 0 else None
+    torch.cuda.synchronize()
+    t_b0 = time.perf_counter()
     blob = D.broadcast_packed_weights(spec, sd, device)  # ONE broadcast (RCCL over xGMI); no collective in the loop
+    torch.cuda.synchronize()
+    t_pack_bcast = time.perf_counter() - t_b0
+    bcast = None
+    if world > 1:
+        # the collective alone (the first call above also folds / packs on rank 0 and sets the communicator up)
+        xb = blob if torch.distributed.get_backend() == "nccl" else blob.cpu()
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t_b0 = time.perf_counter()
+        torch.distributed.broadcast(xb, src=0)
+        torch.cuda.synchronize()
+        t_b = time.perf_counter() - t_b0
+        # every rank must hold rank 0's bytes: compare a checksum of the blob across the ranks
+        csum = [None] * world
+        torch.distributed.all_gather_object(csum, (float(blob.double().sum().item()), int(blob.numel())))
+        bcast = {"bytes": int(blob.numel() * 4), "seconds": t_b, "GBs": blob.numel() * 4 / t_b / 1e9,
+                 "pack_plus_first_broadcast_s": t_pack_bcast, "identical_on_all_ranks": len(set(csum)) == 1,
+                 "backend": torch.distributed.get_backend()}
     cls = UniverseGAN if spec.kind == "universe_gan" else Universe
     model = cls(spec, packed_weights=blob, device=device)
 
@@ -232,6 +286,23 @@ def main():
     model._status()
     assert torch.isfinite(out).all()
     launches = model.launch_stats()
+    rank_ms = per_rank_ms(step, max(2, args.steps // 2), world, device)
+
+    # ---- other per-GPU batch sizes, same model / length / step count (short loops; every rank takes part) ----
+    batch_sweep = {}
+    for bs in [int(b) for b in args.batch_sweep.split(",") if b.strip()] if not args.varlen else []:
+        if bs == args.batch:
+            batch_sweep[str(bs)] = {"ms_per_step": 1e3 * dt / args.steps,
+                                    "utterances_per_s": args.steps * args.batch * world / dt, "steps": args.steps}
+            continue
+        mix_b = synth_mix(spec.fs, bs, T, 1000 + rank * bs).to(device)
+        rng_b = torch.Generator(device=device).manual_seed(1028282 + rank)
+        step_b = lambda: model.enhance(mix_b, n_steps=args.n_steps, rng=rng_b)  # noqa: E731
+        step_b()
+        k = max(3, args.steps // 2)
+        dt_b, _ = timed_loop(step_b, k, world, device)
+        batch_sweep[str(bs)] = {"ms_per_step": 1e3 * dt_b / k, "utterances_per_s": k * bs * world / dt_b, "steps": k}
+    step()  # back on the headline shape (workspace of the main configuration is current again)
 
     # ---- host side: time to ENQUEUE one enhance (no sync), eager walk of the network vs one hipGraph replay ----
     host_enqueue = None
@@ -410,6 +481,10 @@ def main():
                 "backend": torch.distributed.get_backend() if world > 1 else None,
                 "launches_per_enhance": launches[0],
             },
+            "per_rank_ms_per_step": rank_ms,
+            "weight_broadcast": bcast,
+            "batch_sweep": dict(batch_sweep, note="utterances/s of the whole job at other per-GPU batch sizes (same model, "
+                                                  "length and step count; MAX over ranks like the headline)"),
             "status_mode": "value / ms_per_step: product default (stream sync + device status read after every enhance)",
             "free_running": {"value": audio_s / dt_async, "ms_per_step": 1e3 * dt_async / args.steps,
                              "note": "model.check_status = False: no host sync inside the timed loop, status checked after it"},

@@ -110,7 +110,8 @@ void ou_destroy(ou_handle* h);
 int ou_workspace_bytes(const ou_handle* h, int32_t B, int32_t T, size_t* nbytes);
 /* Once per workspace buffer, before its first use (and after every change of (B, T)): clears the header -- the sticky
  * device status word and the GRU exchange granules (whose tags continue from launch to launch, so the forward calls
- * themselves enqueue no memset).  Enqueued on `stream`. */
+ * themselves enqueue no memset).  Enqueued on `stream`.  The handle remembers (buffer, size, B, T): ou_condition,
+ * ou_score and ou_enhance return OU_EINVAL for a workspace that was not prepared for their shape. */
 int ou_workspace_init(ou_handle* h, int32_t B, int32_t T, void* ws, size_t ws_bytes, ou_stream_t stream);
 
 /* Sampler constants, universe.py:301-311: sigma[n] (fp32, n = 0..n_steps-1), eta, beta. */

@@ -7,12 +7,19 @@ file or every .wav/.mp3/.flac below a folder (folder structure retained), channe
 processing order (so a run is reproducible file by file, exactly like the reference), model-specific arguments
 generated from the signature of `model.enhance`.
 
-Extension (not in the reference, whose loop is serial on one device): launched under `torch.distributed.run` with N
-processes, the files are sharded over the ranks (one GPU each, LPT by duration so the ranks finish together); the
-packed weights are loaded per rank.  Because the reference draws the noise of file k from the generator state
-left by files 0..k-1, a sharded run cannot reproduce the serial noise; with `--per-file-seed` (forced when N > 1)
-file k uses its own generator seeded with `seed + k` (k = index in the sorted file list), which makes the result of
-a file independent of how the list was sharded.
+Extensions (not in the reference, whose loop is serial on one device, one file per `enhance` call):
+* launched under `torch.distributed.run` with N processes, the files are sharded over the ranks (one GPU each, LPT by
+  file size so the ranks finish together); rank 0 reads the checkpoint and the packed weights reach the other ranks
+  with one broadcast (`inference_utils.load_model_sharded`).  Because the reference draws the noise of file k from the
+  generator state left by files 0..k-1, a sharded run cannot reproduce the serial noise; with `--per-file-seed` (forced
+  when N > 1) file k uses its own generator seeded with `seed + k` (k = index in the sorted file list), which makes the
+  result of a file independent of how the list was sharded;
+* `--batch-size K`: up to K consecutive files (in processing order) of the same sample rate and length share one
+  `enhance` call (`Universe.enhance_many`; the channels of a file stay rows of the batch).  The noise is drawn file by
+  file in processing order with the shapes of the serial loop, so the shared generator advances exactly as in the
+  reference and every file gets the noise it would get alone; `--pad-batch` also groups files of different lengths,
+  right-zero-padded to the longest like the reference's `max_collator` (datasets/datamodule.py:24-42; no mask: the
+  padding takes part in the normalisation, as in a reference batch).
 """
 import argparse
 import os
@@ -72,7 +79,30 @@ def build_parser():
     parser.add_argument("--per-file-seed", action="store_true",
                         help="Seed the generator of file k with seed + k instead of sharing one generator across files "
                              "(always on when the files are sharded over several processes)")
+    parser.add_argument("--batch-size", type=int, default=1,
+                        help="Enhance up to this many consecutive files of equal rate and length in one call")
+    parser.add_argument("--pad-batch", action="store_true",
+                        help="With --batch-size: also batch files of different lengths, zero-padded to the longest "
+                             "(reference batch semantics: the padding is not masked)")
     return parser
+
+
+def group_files(todo, infos, batch_size, pad_batch):
+    """Consecutive runs of `todo` (in processing order) that may share one enhance call: same sample rate, same number
+    of samples (any length with pad_batch), at most batch_size files.  infos[k] = (fs, n_samples)."""
+    groups, cur = [], []
+    for item in todo:
+        k = item[0]
+        if cur:
+            k0 = cur[0][0]
+            same = infos[k][0] == infos[k0][0] and (pad_batch or infos[k][1] == infos[k0][1])
+            if not same or len(cur) >= batch_size:
+                groups.append(cur)
+                cur = []
+        cur.append(item)
+    if cur:
+        groups.append(cur)
+    return groups
 
 
 def main(argv=None, model=None):
@@ -92,7 +122,15 @@ def main(argv=None, model=None):
         if not device.startswith("cuda"):
             raise ValueError("Device name should be 'cuda:X' where X is an integer (this build has no CPU path). "
                              f"Provided {device}")
-        model = inference_utils.load_model(args.model, device=device, strict=args.model_strict, hf_token=args.hf_token)
+        if world > 1:
+            from .. import distributed
+
+            distributed.init()  # nccl (= RCCL) with one GPU per rank, gloo when ranks share a device
+            model = inference_utils.load_model_sharded(args.model, device=device, strict=args.model_strict,
+                                                       hf_token=args.hf_token)
+        else:
+            model = inference_utils.load_model(args.model, device=device, strict=args.model_strict,
+                                               hf_token=args.hf_token)
     device = str(getattr(model, "device", args.device))
 
     inference_utils.add_enhance_arguments(model, parser)
@@ -117,25 +155,57 @@ def main(argv=None, model=None):
                            + ", ".join(undecodable[:5]))
     todo = plan_files(files, world, rank)
 
-    done = []
-    for k, path in todo:
+    def out_path(path):
         if dir_proc:
             output_path = args.output / path.relative_to(rel_path)
             output_path.parent.mkdir(exist_ok=True, parents=True)
-        elif args.output.is_dir():
-            output_path = args.output / path.name
-        else:
-            output_path = args.output
-        audio, fs = load(path)
-        audio = audio.to(device)
-        if per_file_seed:
-            rng.manual_seed(args.seed + k)
+            return output_path
+        if args.output.is_dir():
+            return args.output / path.name
+        return args.output
+
+    done = []
+    if args.batch_size <= 1:
+        for k, path in todo:
+            output_path = out_path(path)
+            audio, fs = load(path)
+            audio = audio.to(device)
+            if per_file_seed:
+                rng.manual_seed(args.seed + k)
+            with torch.no_grad():
+                audio = resample(audio, fs, model.fs)
+                enh = model.enhance(audio, **dict(enhance_kwargs, rng=rng))
+                enh = resample(enh, model.fs, fs)
+            save(output_path, enh.cpu(), fs)
+            done.append(output_path)
+        return done
+
+    # --batch-size: files are decoded once up front (their rate / length decide the grouping), enhanced group by group
+    if any(enhance_kwargs.get(key) is not None for key in ("ensemble", "target")):
+        raise ValueError("--batch-size cannot be combined with --ensemble (one call per file needed)")
+    loaded = {k: load(path) for k, path in todo}
+    infos = {k: (fs, int(a.shape[-1])) for k, (a, fs) in loaded.items()}
+    kw = {key: v for key, v in enhance_kwargs.items() if key not in ("rng", "ensemble", "ensemble_stat", "target",
+                                                                    "fake_score_snr")}
+    for group in group_files(todo, infos, args.batch_size, args.pad_batch):
+        fs = infos[group[0][0]][0]
         with torch.no_grad():
-            audio = resample(audio, fs, model.fs)
-            enh = model.enhance(audio, **dict(enhance_kwargs, rng=rng))
-            enh = resample(enh, model.fs, fs)
-        save(output_path, enh.cpu(), fs)
-        done.append(output_path)
+            sigs = [resample(loaded[k][0].to(device), fs, model.fs) for k, _ in group]
+            if per_file_seed:
+                rngs = []
+                for k, _ in group:
+                    g = torch.Generator(device=device)
+                    g.manual_seed(args.seed + k)
+                    rngs.append(g)
+            else:
+                rngs = rng  # one shared generator, drawn from file by file in processing order
+            enhs = model.enhance_many(sigs, rngs, pad_batch=args.pad_batch, **kw)
+            enhs = [resample(e, model.fs, fs) for e in enhs]
+        for (k, path), enh in zip(group, enhs):
+            output_path = out_path(path)
+            save(output_path, enh.cpu(), fs)
+            done.append(output_path)
+            loaded.pop(k, None)
     return done
 
 

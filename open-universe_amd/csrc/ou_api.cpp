@@ -66,6 +66,16 @@ struct ou_handle {
   unsigned long long* prof_dev = nullptr;  // [kProfSlots][32] device-side {16 x min start, 16 x ~max end} ticks
   int fuse_mode = -1;  // OU_FUSE: -1 auto (cost model), 0 never, 2 / 3 force that depth where the shape allows
   int fuse_nc = 0;     // OU_FUSE_NC: force 128 / 256 columns per tile
+  // workspaces that ou_workspace_init has prepared (cleared status word, GRU tag epochs and exchange areas) and the
+  // shape each was prepared for: the forward calls refuse anything else -- an uninitialised buffer would feed the
+  // recurrence kernels a garbage epoch and garbage tags
+  struct WsRec { const void* ws; size_t bytes; int B, T; };
+  std::vector<WsRec> ws_ready;
+  bool ws_ok(const void* ws, size_t bytes, int B, int T) const {
+    for (const WsRec& r : ws_ready)
+      if (r.ws == ws) return r.B == B && r.T == T && r.bytes <= bytes;
+    return false;
+  }
 };
 
 namespace {
@@ -421,21 +431,18 @@ struct Runner {
     GruArgs a;
     a.gx = gx.p; a.whh = W(G.whh_off); a.bhn = W(G.bhn_off); a.out = out.p; a.res = res; a.res_scale = res_scale;
     a.xchg = xchg; a.err = errw; a.epoch = epoch; a.B = B; a.T = in.T; a.H = G.H;
-    // kernel generation: the ring kernel (every wave gathers h straight from L2) is the latency-optimal one and serves
-    // batch 1 (two clusters).  With more clusters its plain publishes are occasionally not seen by the other CUs until
-    // the safety net re-stores them ~0.5 ms later (gru_ring_kernel): harmless for the result, but PP24 at B = 4 (8 clusters
-    // of 24 workgroups) lost 50 ms per enhance to such stalls in one run out of two, and the gain it could make there
-    // (PP16: 12.4 / 19.4 / 34.0 vs 13.2 / 20.2 / 34.6 ms at B = 2 / 4 / 8) is small -- so batches > 1 use the polling-wave
-    // kernel, whose publishes are followed by a workgroup barrier (vmcnt(0)) every step.
+    // kernel generation: the ring kernel (every wave gathers h straight from L2, no polling wave, no workgroup barrier)
+    // for every batch size -- its publishes are agent-scope (sc1) stores by default, the documented form of the hand-off;
+    // OU_GRU_V=1 selects the polling-wave kernel of round 1.
     {
       const char* f = std::getenv("OU_GRU_V");
-      a.version = f ? std::atoi(f) : (B == 1 ? 2 : 1);
+      a.version = f ? std::atoi(f) : 2;
     }
     { const char* f = std::getenv("OU_GRU_BMAX"); a.force_bmax = f ? std::atoi(f) : 0; }
     if (std::getenv("OU_GRU_TS")) a.tstamps = (long long*)(base + cap - (1u << 20));
     { const char* f = std::getenv("OU_GRU_UPW"); a.force_upw = f ? std::atoi(f) : 0; }
     { const char* f = std::getenv("OU_GRU_BACKOFF"); a.poll_backoff = f ? std::atoi(f) : 0; }
-    { const char* f = std::getenv("OU_GRU_AGENT_STORES"); a.agent_stores = f ? std::atoi(f) : 0; }
+    { const char* f = std::getenv("OU_GRU_PLAIN_STORES"); a.agent_stores = (f && std::atoi(f) != 0) ? 0 : 1; }
     { const char* f = std::getenv("OU_GRU_DBG"); a.dbg = f ? std::atoi(f) : 0; }
     chk(launch_gru(a, h->num_cu, st), G.name.c_str());
     return out;
@@ -818,6 +825,8 @@ int ou_schedule(const ou_config* cfg, int32_t n_steps, double epsilon, float* si
 int ou_condition(ou_handle* h, const float* mix_norm, int32_t B, int32_t T, void* ws, size_t ws_bytes, ou_stream_t stream) {
   if (!h || !mix_norm || !ws || B < 1) return fail(h, OU_EINVAL, "bad argument");
   if (T % h->m.tot_ds || T <= 0) return fail(h, OU_EINVAL, "T must be a positive multiple of the total down-sampling factor");
+  if (!h->ws_ok(ws, ws_bytes, B, T))
+    return fail(h, OU_EINVAL, "workspace was not prepared by ou_workspace_init for this (B, T)");
   h->tensors.clear();
   h->n_launch = h->n_conv = 0;
   h->ev_used = 0;
@@ -834,6 +843,8 @@ int ou_score(ou_handle* h, const float* x, const float* sigma_host, float* score
              size_t ws_bytes, ou_stream_t stream) {
   if (!h || !x || !sigma_host || !score_out || !ws) return fail(h, OU_EINVAL, "bad argument");
   if (B != h->cond_B || T != h->cond_T) return fail(h, OU_EINVAL, "ou_score: call ou_condition with the same (B, T) first");
+  if (!h->ws_ok(ws, ws_bytes, B, T))
+    return fail(h, OU_EINVAL, "workspace was not prepared by ou_workspace_init for this (B, T)");
   h->n_launch = h->n_conv = 0;
   Runner r(h, ws, ws_bytes, false, (hipStream_t)stream, B);
   auto keep = h->tensors;
@@ -890,6 +901,8 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
   const int pad = tot - T_raw % tot;  // universe.py:219-223 (a full block when already a multiple)
   const int pad_left = pad / 2;
   const int T = T_raw + pad;
+  if (!h->ws_ok(ws, ws_bytes, B, T))
+    return fail(h, OU_EINVAL, "workspace was not prepared by ou_workspace_init for this (B, T_raw + pad)");
   h->tensors.clear();
   h->n_launch = h->n_conv = 0;
   h->ev_used = 0;
@@ -1036,7 +1049,16 @@ int ou_workspace_init(ou_handle* h, int32_t B, int32_t T, void* ws, size_t ws_by
   // header: status word, coefficient rows, statistics, both GRU exchange areas (everything in front of mel_scale)
   const size_t hdr = (size_t)((char*)P.mel_scale - (char*)ws);
   r.chk(hipMemsetAsync(ws, 0, hdr, r.st), "workspace init");
-  return finish(h, r);
+  const int rc = finish(h, r);
+  if (rc == OU_OK) {
+    // remember (pointer, size, shape); a buffer that comes back at the same address is re-registered by its own init
+    auto& v = h->ws_ready;
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i].ws == ws) { v.erase(v.begin() + i); break; }
+    if (v.size() >= 64) v.erase(v.begin());
+    v.push_back(ou_handle::WsRec{ws, ws_bytes, B, T});
+  }
+  return rc;
 }
 
 int ou_sampler_step(ou_handle* h, float* x, const float* score, const float* z, float c1, float c2, size_t n,

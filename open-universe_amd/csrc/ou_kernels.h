@@ -165,13 +165,15 @@ struct GruArgs {
   const float* res = nullptr;
   float res_scale = 1.f;
   unsigned long long* xchg = nullptr;  // exchange area: 2B clusters x (2H + 64) granules (see gru_granules())
+  unsigned long long* xchg_base = nullptr;  // ring kernel: start and size of the WHOLE area of this GRU layer (filled by
+  size_t xchg_granules = 0;                 // launch_gru; a chunked batch advances `xchg` per sub-launch)
   unsigned* epoch = nullptr;           // version 2: {tag epoch, finished-block count} of this exchange area (device)
   int version = 2;                     // 1: polling-wave kernel (memset per launch), 2: ring kernel (epoch tags)
   unsigned* err = nullptr;             // device status word
   long long* tstamps = nullptr;        // per-wave cycle breakdown (tuning only)
   int B = 1, T = 0, H = 0;
   int poll_backoff = 0;  // tuning: 0/1/2 x ~512 cycles of sleep before the first poll
-  int agent_stores = 0;  // 1: publish with agent-scope stores even when the cluster shares one XCD
+  int agent_stores = 1;  // 1 (default): publish with agent-scope (sc1) stores; 0: plain stores when the cluster shares one XCD
   int dbg = 0;           // experiments (OU_GRU_DBG): bit 0 = no republish safety net, bit 1 = system-scope publishes from the start,
                          // bit 2 = fault injection: one workgroup drops its publishes of step 50
   int force_bmax = 0;  // testing: cap the utterances per launch (forces the chunked path at small batches)

@@ -3092,13 +3092,18 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
             }
           }
           gather_wait(hv);
+          // every tag must EQUAL want: smaller = not yet published; larger cannot happen on a workspace that
+          // ou_workspace_init prepared (tags are monotonic per exchange area), and is refused rather than consumed
           unsigned m = hv[0].y < hv[0].w ? hv[0].y : hv[0].w;
+          unsigned mx = hv[0].y > hv[0].w ? hv[0].y : hv[0].w;
 #pragma unroll
           for (int k = 1; k < NC / 2; k++) {
             const unsigned a = hv[k].y < hv[k].w ? hv[k].y : hv[k].w;
+            const unsigned c = hv[k].y > hv[k].w ? hv[k].y : hv[k].w;
             m = a < m ? a : m;
+            mx = c > mx ? c : mx;
           }
-          if (__builtin_amdgcn_ballot_w64(m != want) == 0ull) break;  // wave-uniform: the wave needs all H values anyway
+          if (__builtin_amdgcn_ballot_w64(m != want || mx != want) == 0ull) break;  // wave-uniform: the wave needs all H values
           // every wave polls all H granules: 32 line requests per wave and round -- a few per cent of the L2 request
           // rate for the two clusters of a batch-1 call; with dozens of clusters the polling-wave kernel (one poller per
           // workgroup) is ahead again, see the version rule in ou_api.cpp.  Back off if a wait gets long.
@@ -3145,10 +3150,33 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
             // status word 20 counts the recoveries (one per wave and event)
             if (lane == 0) atomicAdd(p.err + 20, 1u);
           }
+          // a long wait (~2 ms): leave this workgroup's position in its rendezvous slot -- {epoch, xcc | step << 8}; the
+          // tag stays the epoch, late members still pass the rendezvous -- for whoever ends up reporting a time-out
+          if (spins == 4096u && tid == 0) {
+            const unsigned long long pos = ((unsigned long long)epoch << 32) | (xcc & 0xFFu) | ((unsigned)step << 8);
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(xq + 2 * H + g), "v"(pos) : "memory");
+          }
           if (spins > GRU_SPIN_LIMIT) {
-            atomicOr(p.err, 4u);  // diagnostics: who waited for what
-            p.err[12] = (unsigned)cluster; p.err[13] = (unsigned)g; p.err[14] = (unsigned)step; p.err[15] = m; p.err[16] = want;
-            p.err[17] = xcc; p.err[18] = plain ? 1u : 0u; p.err[19] = (unsigned)bid;
+            // diagnostics (first reporter only): who waited for what, which granule is stale, where the members are
+            if ((atomicOr(p.err, 4u) & 4u) == 0u && lane == 0) {
+              p.err[12] = (unsigned)cluster; p.err[13] = (unsigned)g; p.err[14] = (unsigned)step; p.err[15] = m; p.err[16] = want;
+              p.err[17] = xcc; p.err[18] = plain ? 1u : 0u; p.err[19] = (unsigned)bid;
+              p.err[32] = mx;
+              for (int i = 0; i < NWG && i < 24; i++) {  // step << 8 | xcc of every member that ever waited this long
+                const unsigned long long v = __hip_atomic_load(xq + 2 * H + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p.err[36 + i] = (unsigned)(v >> 32) == epoch ? (unsigned)v : 0xFFFFFFFFu;
+              }
+            }
+            // the stale column as this lane sees it (any lane; the lowest column of the first lane that has one)
+            {
+              int stale = -1;
+#pragma unroll
+              for (int k = NC / 2 - 1; k >= 0; k--) {
+                if (hv[k].w != want) stale = cg * 4 + (k >> 1) * 4 * LPU + (k & 1) * 2 + 1;
+                if (hv[k].y != want) stale = cg * 4 + (k >> 1) * 4 * LPU + (k & 1) * 2;
+              }
+              if (stale >= 0) atomicMax(p.err + 33, (unsigned)(H - stale));  // -> lowest stale column = H - word
+            }
             {  // has the workgroup been moved since the rendezvous?  (context save / restore under a second process)
               unsigned now;
               asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(now));
@@ -3192,15 +3220,18 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
           const unsigned long long gran =
               ((unsigned long long)(epoch + (unsigned)step + 1u) << 32) | (unsigned)__float_as_int(hnew);
           unsigned long long* dst = xq + (size_t)((step + 1) & 1) * H + unit;
-          // (one branch on the fast path: this store is on the critical path of every step)
-          if (__builtin_expect(fast_pub && step != inject_step, 1)) {
-            asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
-          } else if (step == inject_step) {
+          // Default: ONE agent-scope (sc1, write-through) 8-byte store per granule, polled with sc1 loads -- the
+          // documented valid form of a data-tagged hand-off on gfx950 (R2 of the inter-workgroup recipe: no fence, no
+          // flag, the tag is the flag).  Plain stores (OU_GRU_PLAIN_STORES=1, same-XCD clusters only) keep the line in
+          // the XCD's L2 and save ~150 cycles per step, but have no visibility deadline in the memory model.
+          if (__builtin_expect(step == inject_step, 0)) {
             // fault injection (tests): workgroup 1 "loses" its publishes of step 50 -- the safety net has to bring them back
-          } else if (sysmode) {
+          } else if (__builtin_expect(sysmode, 0)) {
             asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(gran) : "memory");
+          } else if (fast_pub) {
+            asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
           } else {
-            __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(gran) : "memory");
           }
         }
         p.out[orow + t] = has_res ? (hnew + rs) * p.res_scale : hnew;
@@ -3223,8 +3254,10 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
       p.epoch[1] = 0u;
       unsigned next = epoch + (unsigned)T;  // stored counter = last tag used
       if (next >= GRU_EPOCH_WRAP) {  // tags must stay monotonic: clear the area and restart (every block is done)
-        const size_t n = (size_t)nclusters * CSTRIDE;
-        for (size_t i = 0; i < n; i++) p.xchg[i] = 0ull;
+        // the whole area of this GRU layer, not just this launch's clusters: the sub-launches of a chunked batch share
+        // it, and a stale high tag left behind a smaller remainder launch would outlive the restart
+        const size_t n = p.xchg_granules ? p.xchg_granules : (size_t)nclusters * CSTRIDE;
+        for (size_t i = 0; i < n; i++) p.xchg_base[i] = 0ull;
         next = 0u;
       }
       __threadfence();
@@ -3234,23 +3267,38 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
 }
 
 template <int HB>
+static void (*gru_ring_entry(int upw))(GruArgs, int) {
+  if constexpr (HB <= 4) {
+    if (upw == 32) return gru_ring_kernel<HB, 32>;
+  }
+  if constexpr (HB >= 2 && HB <= 4) {  // 8 units per workgroup: half the columns (and polls) per lane, twice the workgroups
+    if (upw == 8) return gru_ring_kernel<HB, 8>;
+  }
+  return gru_ring_kernel<HB, 16>;
+}
+// Workgroups of the ring kernel that can be resident per CU (every member of a cluster spins on the others: the whole
+// grid has to be on the machine at once).  The occupancy query can be one block high for kernels near an SGPR
+// allocation step (guide: admitted = min(API, 8, 800 / (ceil(sgpr / 16) * 16 + 16))), so one block of margin is taken
+// off and at most two per CU are relied upon.
+template <int HB>
+static int gru_ring_resident_per_cu(int upw) {
+  static int cache[3] = {0, 0, 0};
+  const int slot = upw == 32 ? 2 : (upw == 8 ? 0 : 1);
+  if (cache[slot] == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(gru_ring_entry<HB>(upw)), 256, 0) !=
+        hipSuccess)
+      nb = 1;
+    cache[slot] = nb >= 3 ? 2 : 1;
+  }
+  return cache[slot];
+}
+template <int HB>
 static hipError_t launch_gru_ring(const GruArgs& c, int upw, int nclusters, hipStream_t st) {
   constexpr int H = 64 * HB;
   const int nwg = H / upw;
   dim3 grid(8 * nwg * ((nclusters + 7) / 8));
-  if constexpr (HB <= 4) {
-    if (upw == 32) {
-      hipLaunchKernelGGL((gru_ring_kernel<HB, 32>), grid, dim3(256), 0, st, c, nclusters);
-      return hipGetLastError();
-    }
-  }
-  if constexpr (HB >= 2 && HB <= 4) {  // 8 units per workgroup: half the columns (and polls) per lane, twice the workgroups
-    if (upw == 8) {
-      hipLaunchKernelGGL((gru_ring_kernel<HB, 8>), grid, dim3(256), 0, st, c, nclusters);
-      return hipGetLastError();
-    }
-  }
-  hipLaunchKernelGGL((gru_ring_kernel<HB, 16>), grid, dim3(256), 0, st, c, nclusters);
+  hipLaunchKernelGGL(gru_ring_entry<HB>(upw), grid, dim3(256), 0, st, c, nclusters);
   return hipGetLastError();
 }
 
@@ -3281,6 +3329,21 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
   if (a.version == 2) upw = (a.force_upw == 32 && a.H <= 256) ? 32 : ((a.force_upw == 8 && a.H >= 128 && a.H <= 256) ? 8 : 16);
   const int nwg = a.H / upw;
   int bmax = batch_cap(upw);
+  if (a.version == 2) {
+    // residency of the ring kernel: grid <= (resident workgroups per CU) x CUs / 2 -- the other half stays free for the
+    // second GRU layer that may run beside this one (conditioner / first score pass); a launch that would not fit is
+    // split into sub-launches, never enqueued oversized (a member that is not resident would be waited for in vain)
+    int per_cu = 1;
+    switch (HB) {
+      case 1: per_cu = gru_ring_resident_per_cu<1>(upw); break;
+      case 2: per_cu = gru_ring_resident_per_cu<2>(upw); break;
+      case 4: per_cu = gru_ring_resident_per_cu<4>(upw); break;
+      case 6: per_cu = gru_ring_resident_per_cu<6>(upw); break;
+      default: return hipErrorInvalidConfiguration;
+    }
+    const int wg_cap = num_cu * per_cu / 2;
+    bmax = (wg_cap / (8 * nwg)) * 8 / 2;  // whole groups of 8 clusters (one per XCD), two clusters per utterance
+  }
   if (a.force_bmax > 0 && a.force_bmax < bmax) bmax = a.force_bmax;
   if (bmax < 1) return hipErrorInvalidConfiguration;
   for (int b0 = 0; b0 < a.B; b0 += bmax) {
@@ -3291,6 +3354,8 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
     if (a.res) c.res = a.res + (size_t)b0 * 2 * a.H * a.T;
     if (a.version == 2) {
       if (!a.epoch) return hipErrorInvalidValue;
+      c.xchg_base = a.xchg;
+      c.xchg_granules = gru_granules(a.B, a.H);
       hipError_t e;
       switch (HB) {
         case 1: e = launch_gru_ring<1>(c, upw, 2 * c.B, st); break;

@@ -25,9 +25,12 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def pick_backend(world):
-    """nccl (RCCL) iff there is one visible GPU per local rank; gloo for CPU hosts and shared-device runs."""
-    if torch.cuda.is_available() and torch.cuda.device_count() >= world:
+def pick_backend(world=None):
+    """nccl (RCCL) iff there is one visible GPU per LOCAL rank; gloo for CPU hosts and shared-device runs.
+    `device_count()` is per node, so it is held against LOCAL_WORLD_SIZE (torchrun sets it; a multi-node job with
+    8 ranks per node and world = 16 is still one GPU per local rank), falling back to the global size."""
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world if world is not None else os.environ.get("WORLD_SIZE", "1")))
+    if torch.cuda.is_available() and torch.cuda.device_count() >= local_world:
         return "nccl"
     return "gloo"
 
@@ -129,21 +132,61 @@ def utterance_generator(device, seed, index):
     return g
 
 
-def enhance_sharded(model, signals, seed=1028282, gather=True, **enhance_kwargs):
+def plan_batches(lengths, indices, batch_size, pad_batch=False):
+    """Group the utterances `indices` (of raw lengths `lengths[i]`) into `enhance` calls of at most `batch_size` rows.
+
+    pad_batch=False: only utterances of EQUAL raw length share a call (same pad, same normalisation window: every row
+    is exactly the utterance it would be alone).  pad_batch=True: the reference's batch semantics for ragged sets
+    (`max_collator`, datasets/datamodule.py:24-42) -- neighbours in length order share a call and are right-zero-padded
+    to the longest of them; the reference has no mask, so the padding is seen by the normalisation, the mel norm and
+    the GRU, and a row is NOT the utterance it would be alone.
+    Deterministic: a pure function of (lengths, indices, batch_size, pad_batch)."""
+    batch_size = max(1, int(batch_size))
+    order = sorted(indices, key=lambda i: (-int(lengths[i]), i))
+    groups = []
+    if pad_batch:
+        for k in range(0, len(order), batch_size):
+            groups.append(order[k:k + batch_size])
+        return groups
+    cur = []
+    for i in order:
+        if cur and (int(lengths[i]) != int(lengths[cur[0]]) or len(cur) == batch_size):
+            groups.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        groups.append(cur)
+    return groups
+
+
+def enhance_sharded(model, signals, seed=1028282, gather=True, batch_size=1, pad_batch=False, **enhance_kwargs):
     """Enhance a list of 1-D signals (any lengths) across the ranks of the current process group.
 
-    Rank r takes its LPT shard (`shard_utterances`), enhances each utterance with its own generator
-    (`utterance_generator`) -- one `enhance` call per utterance, so no cross-utterance padding enters the result and a
-    1-rank run and an N-rank run are bit-identical -- and the results are gathered on rank 0 in the original order
-    (None on the other ranks; with gather=False every rank returns {index: tensor} of its shard)."""
+    Rank r takes its LPT shard (`shard_utterances`) and walks it in `plan_batches` groups: up to `batch_size`
+    utterances per `enhance` call (one call per utterance with the default batch_size=1).  Every utterance draws its
+    noise from its own generator (`utterance_generator`, seed + index) with the shapes a call on that utterance alone
+    would use, so with pad_batch=False the result of an utterance does not depend on the sharding or the grouping
+    beyond fp32 summation order (the conv tilings are chosen from the total column count of a call: batched vs single
+    agree to > 100 dB, same grouping = bit-identical; a 1-rank and an N-rank run with batch_size=1 are bit-identical).
+    Results are gathered on rank 0 in the original order (None on the other ranks; with gather=False every rank
+    returns {index: tensor} of its shard)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     lengths = [int(s.shape[-1]) for s in signals]
     mine = shard_utterances(lengths, world)[rank]
-    outs = []
-    for i in mine:
-        x = signals[i].to(model.device)
-        outs.append(model.enhance(x, rng=utterance_generator(model.device, seed, i), **enhance_kwargs))
+    outs = {}
+    batched_ok = not any(enhance_kwargs.get(k) is not None for k in ("target", "ensemble"))
+    for group in plan_batches(lengths, mine, batch_size if batched_ok else 1, pad_batch):
+        if len(group) == 1:
+            i = group[0]
+            outs[i] = model.enhance(signals[i].to(model.device), rng=utterance_generator(model.device, seed, i),
+                                    **enhance_kwargs)
+            continue
+        res = model.enhance_many([signals[i].to(model.device) for i in group],
+                                 [utterance_generator(model.device, seed, i) for i in group], pad_batch=pad_batch,
+                                 **enhance_kwargs)
+        for i, o in zip(group, res):
+            outs[i] = o
     if not gather:
-        return dict(zip(mine, outs))
-    return gather_outputs(outs, mine, len(signals))
+        return outs
+    return gather_outputs([outs[i] for i in mine], mine, len(signals))

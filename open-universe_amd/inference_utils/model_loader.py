@@ -101,12 +101,8 @@ def read_checkpoint(path):
     return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_tensor_only_pickle)
 
 
-def load_model(ckpt_path, device=None, strict=True, return_config=False, hf_token=None):
-    """Load a model from a checkpoint file or a Huggingface model id `repo[:revision]`.
-
-    Parameters are those of the reference.  `strict` follows model_loader.py:119-130: a checkpoint with an `ema` entry
-    (every published one) is loaded non-strictly; otherwise `strict=True` rejects unexpected keys outside the
-    training-only modules.  Missing inference tensors are fatal in either mode."""
+def _resolve(ckpt_path, hf_token):
+    """-> (checkpoint path, config path): a local file with config.yaml beside it, or a Huggingface id repo[:revision]."""
     if not Path(ckpt_path).exists():
         try:
             from huggingface_hub import hf_hub_download
@@ -122,9 +118,11 @@ def load_model(ckpt_path, device=None, strict=True, return_config=False, hf_toke
     else:
         ckpt_path = Path(ckpt_path)
         config_path = ckpt_to_config_path(ckpt_path)
+    return ckpt_path, config_path
 
-    config = load_config(config_path)
-    spec = spec_from_config(config)
+
+def _inference_weights(spec, ckpt_path, strict):
+    """The tensors `enhance` runs on (EMA weights when the checkpoint has them), after the reference's strictness rule."""
     data = read_checkpoint(ckpt_path)
     if not isinstance(data, dict):
         raise ValueError(f"{ckpt_path} does not hold a checkpoint dictionary")
@@ -137,8 +135,55 @@ def load_model(ckpt_path, device=None, strict=True, return_config=False, hf_toke
         unexpected = [k for k in raw if k not in known and not k.startswith(TRAINING_ONLY_PREFIXES)]
         if unexpected:
             raise RuntimeError(f"Unexpected key(s) in state_dict: {unexpected[:5]}")
+    return sd
+
+
+def load_model(ckpt_path, device=None, strict=True, return_config=False, hf_token=None):
+    """Load a model from a checkpoint file or a Huggingface model id `repo[:revision]`.
+
+    Parameters are those of the reference.  `strict` follows model_loader.py:119-130: a checkpoint with an `ema` entry
+    (every published one) is loaded non-strictly; otherwise `strict=True` rejects unexpected keys outside the
+    training-only modules.  Missing inference tensors are fatal in either mode."""
+    ckpt_path, config_path = _resolve(ckpt_path, hf_token)
+    config = load_config(config_path)
+    spec = spec_from_config(config)
+    sd = _inference_weights(spec, ckpt_path, strict)
     cls = UniverseGAN if spec.kind == "universe_gan" else Universe
     model = cls(spec, state_dict=sd, device=device)
+    model.eval()
+    if return_config:
+        return model, config
+    return model
+
+
+def load_model_sharded(ckpt_path, device=None, strict=True, return_config=False, hf_token=None):
+    """`load_model` for the ranks of an initialised process group (extension; the reference is single-device): every
+    rank reads the small config.yaml, ONLY rank 0 reads the checkpoint, folds and packs it, and the packed blob reaches
+    the other ranks with one broadcast (RCCL over xGMI when every rank owns a GPU, `distributed.broadcast_packed_weights`)."""
+    import torch.distributed as dist
+
+    from ..distributed import broadcast_packed_weights
+
+    ckpt_path, config_path = _resolve(ckpt_path, hf_token)
+    config = load_config(config_path)
+    spec = spec_from_config(config)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    sd, err = None, None
+    if rank == 0:
+        try:
+            sd = _inference_weights(spec, ckpt_path, strict)
+        except Exception as e:  # the other ranks are about to enter a collective: tell them before raising
+            err = e
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        flag = [repr(err) if err is not None else None]
+        dist.broadcast_object_list(flag, src=0)
+        if flag[0] is not None:
+            raise err if err is not None else RuntimeError(f"rank 0 could not load the checkpoint: {flag[0]}")
+    elif err is not None:
+        raise err
+    blob = broadcast_packed_weights(spec, sd, device)
+    cls = UniverseGAN if spec.kind == "universe_gan" else Universe
+    model = cls(spec, packed_weights=blob, device=device)
     model.eval()
     if return_config:
         return model, config

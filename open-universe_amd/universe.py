@@ -62,6 +62,7 @@ class Universe:
         self.check_status = True
         self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._status_event = None
+        self._status_ws = None
         self.training = False
         self._cfg = _lib.make_config(spec)
         if packed_weights is None:
@@ -75,6 +76,7 @@ class Universe:
                                          c_size_t(self._weights.numel() * 4), device.index, byref(self._handle)))
         self._ws = None
         self._ws_key = None
+        self._ws_cache = {}
         self._cond_key = None
 
     # ------------------------------------------------------------------------------------------------
@@ -105,29 +107,59 @@ class Universe:
     def _stream(self):
         return c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    # workspaces kept alive (most recently used last): a directory of files alternates between a handful of
+    # (batch, length) shapes, and a workspace costs an allocation plus ou_workspace_init
+    WS_CACHE_ENTRIES = 4
+    WS_CACHE_BYTES = 16 << 30
+
     def _workspace(self, B, T):
         key = (B, T)
         if self._ws_key != key:
-            n = c_size_t()
-            _lib.check(self._L.ou_workspace_bytes(self._handle, B, T, byref(n)), self._handle)
-            self._ws = None
-            self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
-            with torch.cuda.device(self.device):
-                _lib.check(self._L.ou_workspace_init(self._handle, B, T, c_void_p(self._ws.data_ptr()),
-                                                     c_size_t(n.value), self._stream()), self._handle)
+            cache = self._ws_cache
+            if key in cache:
+                cache[key] = cache.pop(key)  # move to the back
+            else:
+                n = c_size_t()
+                _lib.check(self._L.ou_workspace_bytes(self._handle, B, T, byref(n)), self._handle)
+                while cache and (len(cache) >= self.WS_CACHE_ENTRIES
+                                 or sum(w.numel() for w in cache.values()) + n.value > self.WS_CACHE_BYTES):
+                    cache.pop(next(iter(cache)))
+                self._ws = None
+                ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+                with torch.cuda.device(self.device):
+                    _lib.check(self._L.ou_workspace_init(self._handle, B, T, c_void_p(ws.data_ptr()),
+                                                         c_size_t(n.value), self._stream()), self._handle)
+                cache[key] = ws
+            self._ws = cache[key]
             self._ws_key = key
             self._cond_key = None
         return self._ws
+
+    def reset_workspace(self):
+        """Drop every cached workspace: the next call allocates and initialises a fresh one (tests; after switching
+        between kernel generations that lay the GRU exchange area out differently)."""
+        self._ws_cache.clear()
+        self._ws = None
+        self._ws_key = None
+        self._cond_key = None
+        self._status_ws = None
 
     def _raise_on_status(self):
         self._status_event = None
         v = int(self._status_host[0])
         if v:
-            diag = self._ws[:80].view(torch.int32).cpu().tolist()  # who waited for what (see gru_ring_kernel)
+            ws = self._status_ws if self._status_ws is not None else self._ws
+            diag = ws[:256].view(torch.int32).cpu().tolist()  # who waited for what (see gru_ring_kernel)
             self._status_host.zero_()
-            self._ws[:4].zero_()  # the device word is sticky until cleared
+            ws[:4].zero_()  # the device word is sticky until cleared
+            ws[32 * 4:60 * 4].zero_()
+            # [12..19]: reporting cluster / member / step / min tag seen / tag wanted / XCC / plain stores / block id;
+            # [32] max tag seen, [33] H - lowest stale column, [36..]: (step << 8 | xcc) of every member of that cluster
+            # that was itself stuck in a long wait (0xFFFFFFFF: slot not of this launch)
+            members = [("-" if m == -1 else f"{(m & 0xFFFFFFFF) >> 8}@x{m & 0xFF}") for m in diag[36:60]]
             raise RuntimeError(f"device-side timeout in the GRU cluster exchange (status word {v}, diagnostics "
-                               f"{diag[8:20]}); the output of that call is invalid")
+                               f"{diag[8:20]}, max tag {diag[32] & 0xFFFFFFFF}, H - stale column {diag[33]}, members' "
+                               f"waits {members}); the output of that call is invalid")
 
     def _poll_deferred_status(self):
         """Free-running mode: look at the status copy of an EARLIER call once its event has completed."""
@@ -140,6 +172,7 @@ class Universe:
         if self._ws is None:
             return
         st = torch.cuda.current_stream(self.device)
+        self._status_ws = self._ws
         with torch.cuda.stream(st):
             self._status_host.copy_(self._ws[:4].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
@@ -383,6 +416,54 @@ class Universe:
         elif x_ndim == 2:
             x = x[:, 0, :]
         return x
+
+    @torch.no_grad()
+    def enhance_many(self, signals, rngs=None, pad_batch=False, n_steps=None, epsilon=None, use_aux_signal=False,
+                     keep_rms=False, warm_start=None, **other):
+        """Several independent inputs in ONE `enhance` call (extension; the reference's CLI loops over files one by one,
+        bin/enhance.py:173-192).  `signals`: list of (L,) or (C, L) tensors -- a (C, L) entry is a file whose channels
+        are rows of the batch, as in the reference.  `rngs`: one generator per entry, ONE shared generator, or None.
+        The noise of entry i is drawn from its generator entry by entry, step by step, with the shapes a call on that
+        entry alone would use ((C_i, 1, T), x0 first) -- with a shared generator the draws come in exactly the order
+        of the serial loop, so its state advances as the reference's does.
+        pad_batch=False: all entries must have the same length (every row is the signal it would be alone).
+        pad_batch=True: right-zero-padded to the longest entry like `max_collator` (datasets/datamodule.py:24-42);
+        the reference has no mask, the padding takes part in the normalisation / mel norm / GRU; outputs are cropped.
+        Returns the list of enhanced signals, each with the shape of its input."""
+        for k in ("target", "ensemble", "fake_score_snr"):
+            if other.get(k) is not None:
+                raise ValueError(f"enhance_many does not take `{k}` (call enhance per input)")
+        if not signals:
+            return []
+        rows, dims = [], []
+        for s in signals:
+            if s.ndim not in (1, 2):
+                raise ValueError("enhance_many takes (L,) or (C, L) signals")
+            dims.append(s.ndim)
+            rows.append(self._prep(s if s.ndim == 2 else s[None, :]))
+        lens = [int(r.shape[-1]) for r in rows]
+        l_max = max(lens)
+        if not pad_batch and any(n != l_max for n in lens):
+            raise ValueError("enhance_many: inputs of different lengths need pad_batch=True (reference batch semantics)")
+        n_steps = self.diff_kwargs.n_steps if n_steps is None else int(n_steps)
+        T = l_max + (self.tot_ds - l_max % self.tot_ds)
+        n_start = 0 if warm_start is None else int(warm_start)
+        n_noise = 0 if use_aux_signal else n_steps - n_start
+        per_entry = []
+        for i, r in enumerate(rows):
+            g = rngs[i] if isinstance(rngs, (list, tuple)) else rngs
+            per_entry.append([torch.randn((r.shape[0], 1, T), dtype=torch.float32, device=self.device, generator=g)
+                              for _ in range(n_noise)])
+        noise = [torch.cat([d[n] for d in per_entry], dim=0) for n in range(n_noise)]
+        mix = torch.cat([torch.nn.functional.pad(r, (0, l_max - r.shape[-1])) for r in rows], dim=0)[:, None, :]
+        out = self._enhance(mix, n_steps, epsilon, None, None, None, use_aux_signal, keep_rms, None, "median",
+                            warm_start, noise)
+        res, r0 = [], 0
+        for r, nd, n in zip(rows, dims, lens):
+            o = out[r0:r0 + r.shape[0], 0, :n]
+            r0 += r.shape[0]
+            res.append(o[0] if nd == 1 else o)
+        return res
 
     # ---- hipGraph replay of the hot path ------------------------------------------------------------------------
     def graphed_enhance(self, batch, length, n_steps=None, epsilon=None, keep_rms=False):

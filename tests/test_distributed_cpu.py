@@ -60,3 +60,85 @@ def test_world_size_2_gloo(built_lib):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+class _StubModel:
+    """Stand-in with the two entry points enhance_sharded uses (CPU, no library): out = x + noise from the utterance's
+    own generator -- so a wrong generator, a wrong grouping or a wrong order changes the result."""
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.calls = []
+
+    def enhance(self, x, rng=None, **kw):
+        self.calls.append(1)
+        return x + torch.randn(x.shape, generator=rng)
+
+    def enhance_many(self, sigs, rngs, pad_batch=False, **kw):
+        self.calls.append(len(sigs))
+        if not pad_batch:
+            assert len({int(s.shape[-1]) for s in sigs}) == 1
+        return [s + torch.randn(s.shape, generator=g) for s, g in zip(sigs, rngs)]
+
+
+def _sharded_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import open_universe_amd  # noqa: F401
+    from open_universe_amd import distributed as D
+
+    D.init(backend="gloo")
+    lengths = [700, 300, 700, 300, 500, 300, 700, 300, 100]
+    sigs = [torch.full((n,), float(i)) for i, n in enumerate(lengths)]
+    m = _StubModel()
+    outs = D.enhance_sharded(m, sigs, seed=11, batch_size=4, n_steps=3)
+    if rank == 0:
+        q.put(([o.numpy() for o in outs], m.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_enhance_sharded_batches_and_gathers_world_2():
+    """enhance_sharded(batch_size=4) over two gloo ranks: LPT shards, equal-length groups per rank, per-utterance
+    generators, gather in the original order -- bit-equal to one call per utterance in one process."""
+    sys.path.insert(0, ROOT)
+    import open_universe_amd  # noqa: F401
+    from open_universe_amd import distributed as D
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, calls = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lengths = [700, 300, 700, 300, 500, 300, 700, 300, 100]
+    sigs = [torch.full((n,), float(i)) for i, n in enumerate(lengths)]
+    ref = D.enhance_sharded(_StubModel(), sigs, seed=11, n_steps=3)
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        assert torch.equal(torch.from_numpy(a), b)
+    assert max(calls) >= 2  # rank 0 really batched something
+    # grouping rules
+    assert D.plan_batches([5, 5, 7, 5, 7, 3], range(6), 2) == [[2, 4], [0, 1], [3], [5]]
+    assert D.plan_batches([5, 5, 7, 5, 7, 3], range(6), 2, pad_batch=True) == [[2, 4], [0, 1], [3, 5]]
+    assert D.plan_batches([5, 5, 5], range(3), 1) == [[0], [1], [2]]
+
+
+def test_pick_backend_uses_the_local_world_size(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import open_universe_amd  # noqa: F401
+    from open_universe_amd import distributed as D
+
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert D.pick_backend(16) == "nccl"  # 2 nodes x 8 GPUs: one GPU per LOCAL rank
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "16")
+    assert D.pick_backend(16) == "gloo"  # 16 ranks sharing 8 GPUs of one node
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    assert D.pick_backend(2) == "nccl" and D.pick_backend(9) == "gloo"

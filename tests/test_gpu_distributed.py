@@ -18,13 +18,19 @@ from open_universe_amd import state_dict as S
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LENGTHS = [4100, 2900, 3555, 1600, 5200]
+# batched sharded path: groups of equal length exist (3 x 4100, 4 x 2900), plus singletons
+LENGTHS_B = [4100, 2900, 4100, 2900, 3555, 2900, 4100, 2900, 1600]
 
 
 def _signals(spec):
     return [synth_mix(spec, 1, L, seed=60 + i)[0] for i, L in enumerate(LENGTHS)]
 
 
-def _worker(rank, world, port, q):
+def _signals_b(spec):
+    return [synth_mix(spec, 1, L, seed=160 + i)[0] for i, L in enumerate(LENGTHS_B)]
+
+
+def _worker(rank, world, port, q, batched=False):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
@@ -41,7 +47,10 @@ def _worker(rank, world, port, q):
     sd = S.synthetic_state_dict(spec, seed=0) if rank == 0 else None     # only rank 0 has the checkpoint
     blob = D.broadcast_packed_weights(spec, sd, device)
     model = UniverseGAN(spec, packed_weights=blob, device=device)
-    outs = D.enhance_sharded(model, _signals(spec), seed=77, n_steps=3)
+    if batched:
+        outs = D.enhance_sharded(model, _signals_b(spec), seed=77, n_steps=3, batch_size=4)
+    else:
+        outs = D.enhance_sharded(model, _signals(spec), seed=77, n_steps=3)
     if rank == 0:
         q.put([o.numpy() for o in outs])
     dist.barrier()
@@ -70,6 +79,44 @@ def test_two_ranks_on_one_gpu_equal_single_process():
         assert a.shape == (L,) and torch.equal(torch.from_numpy(a), b)
     shards = D.shard_utterances(LENGTHS, 2)
     assert sorted(shards[0] + shards[1]) == list(range(len(LENGTHS))) and len(shards[0]) == 3  # LPT deal
+
+
+def test_two_ranks_batched_shards():
+    """enhance_sharded(batch_size=4): every rank groups the equal-length utterances of its shard into one `enhance`
+    call (per-utterance generators, the shapes of a single call).  The result of an utterance does not depend on the
+    grouping or the sharding beyond fp32 summation order (the conv tilings are chosen from the total column count of a
+    call): >= 100 dB against the one-call-per-utterance run, and the same grouping is bit-reproducible."""
+    import restatement as O
+    from helpers import record
+    from open_universe_amd import UniverseGAN
+    from open_universe_amd import distributed as D
+
+    spec = get_spec("PP16m")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = D.free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model = UniverseGAN(spec, state_dict=S.synthetic_state_dict(spec, seed=0), device="cuda:0")
+    sigs = _signals_b(spec)
+    singles = D.enhance_sharded(model, sigs, seed=77, n_steps=3)                 # one call per utterance
+    batched = D.enhance_sharded(model, sigs, seed=77, n_steps=3, batch_size=4)   # 1 rank, groups of up to 4
+    again = D.enhance_sharded(model, sigs, seed=77, n_steps=3, batch_size=4)
+    groups = D.plan_batches(LENGTHS_B, list(range(len(LENGTHS_B))), 4)
+    assert sorted(len(g) for g in groups) == [1, 1, 3, 4]
+    for i, L in enumerate(LENGTHS_B):
+        assert got[i].shape == (L,) and batched[i].shape == (L,)
+        assert torch.equal(batched[i], again[i])  # same grouping: bit-identical
+        record(f"sharded.batched_vs_single.{i}", O.si_sdr(singles[i].cpu(), batched[i].cpu()), 100)
+        record(f"sharded.2rank_batched_vs_single.{i}", O.si_sdr(singles[i].cpu(), torch.from_numpy(got[i])), 100)
+    # ragged mode (reference batch semantics: right zero padding, no mask): runs, keeps lengths, differs from singles
+    padded = D.enhance_sharded(model, sigs, seed=77, n_steps=3, batch_size=4, pad_batch=True)
+    assert [int(o.shape[-1]) for o in padded] == LENGTHS_B and all(torch.isfinite(o).all() for o in padded)
 
 
 def _run(cmd, timeout=900):
@@ -116,6 +163,56 @@ def test_cli_under_two_ranks_equals_one_rank(tmp_path):
         assert torch.equal(a, b), rel
 
 
+def test_cli_batch_size_matches_file_by_file(tmp_path):
+    """--batch-size: consecutive files of equal rate and length share one enhance call; the shared generator is drawn
+    from file by file in processing order, so every file sees the noise of the serial loop (bin/enhance.py:147-192) and
+    the outputs agree with the file-by-file run to fp32 summation order."""
+    import restatement as O
+    from helpers import record
+    from open_universe_amd import audio as A
+    from open_universe_amd import config as C
+
+    spec = get_spec("PP16s")
+    mdl = tmp_path / "model"
+    mdl.mkdir()
+    with open(mdl / "config.yaml", "w") as f:
+        yaml.safe_dump(C.builtin_config("PP16", **{"score_model.n_channels": 8}), f)
+    torch.save(S.checkpoint_from_state_dict(spec, S.synthetic_state_dict(spec, seed=0), ema_jitter=0.01), mdl / "weights.ckpt")
+    src = tmp_path / "in"
+    src.mkdir()
+    lens = [3000, 3000, 3000, 4200, 4200, 2100]
+    for i, L in enumerate(lens):
+        A.save(src / f"f{i}.wav", synth_mix(spec, 2 if i == 1 else 1, L, seed=190 + i), 16000)  # f1 is stereo
+    base = [sys.executable, "-m", "open_universe_amd.bin.enhance", str(src)]
+    tail = ["--model", str(mdl / "weights.ckpt"), "--n_steps", "3", "--seed", "5"]
+    r1 = _run(base + [str(tmp_path / "out1")] + tail)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = _run(base + [str(tmp_path / "out2")] + tail + ["--batch-size", "4"])
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    for i in range(len(lens)):
+        a, _ = A.load(tmp_path / "out1" / f"f{i}.wav")
+        b, _ = A.load(tmp_path / "out2" / f"f{i}.wav")
+        assert a.shape == b.shape
+        record(f"cli.batched_vs_serial.f{i}", O.si_sdr(a.reshape(-1), b.reshape(-1)), 90)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_bench_two_gpus_over_rccl():
+    """The day-one multi-GPU run: `bench.py --gpus 2` on two real devices must take the nccl (= RCCL) branch, put every
+    rank on its own GPU, hand every rank rank 0's packed blob (checksum compared across ranks) and report per-rank
+    times, the broadcast rate and the batch-1 / batch-4 utterance rates in one line."""
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+              "--profile-steps", "1"])
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["config"]["backend"] == "nccl"
+    assert res["config"]["devices"] == ["rank0:cuda:0", "rank1:cuda:1"]
+    wb = res["weight_broadcast"]
+    assert wb["backend"] == "nccl" and wb["identical_on_all_ranks"] and wb["GBs"] > 1.0
+    assert len(res["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in res["per_rank_ms_per_step"])
+    assert res["batch_sweep"]["1"]["utterances_per_s"] > 0 and res["batch_sweep"]["4"]["utterances_per_s"] > 0
+
+
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher: two ranks, n_gpus = 2 in the JSON line, per-rank device ids."""
     r = _run([sys.executable, "bench.py", "--gpus", "2", "--share-devices", "--steps", "2", "--warmup", "1",
@@ -125,3 +222,5 @@ def test_bench_spawns_its_own_ranks():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["config"]["devices"] == ["rank0:cuda:0", "rank1:cuda:0"]
     assert res["config"]["backend"] == "gloo" and res["value"] > 0
+    assert res["weight_broadcast"]["identical_on_all_ranks"] and len(res["per_rank_ms_per_step"]) == 2
+    assert set(res["batch_sweep"]) >= {"1", "4"}

@@ -21,15 +21,15 @@ def test_ring_kernel_matches_polling_wave_kernel(name, B, monkeypatch):
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(29, 3, B, Tp)
     monkeypatch.setenv("OU_GRU_V", "1")
-    model._ws_key = None  # the two generations lay the exchange area out differently: fresh (cleared) workspace each
+    model.reset_workspace()  # the two generations lay the exchange area out differently: fresh (cleared) workspace each
     ref = run_enhance(model, mix, nz, n_steps=3)
     monkeypatch.setenv("OU_GRU_V", "2")
-    model._ws_key = None
+    model.reset_workspace()
     out = run_enhance(model, mix, nz, n_steps=3)
     out2 = run_enhance(model, mix, nz, n_steps=3)
     assert torch.equal(out, out2)  # consecutive launches (advancing epochs) are deterministic
     record(f"gru.ring_vs_v1.{name}.b{B}", O.si_sdr(ref, out), 90)
-    model._ws_key = None
+    model.reset_workspace()
 
 
 def test_ring_kernel_epoch_wrap(monkeypatch):
@@ -37,7 +37,7 @@ def test_ring_kernel_epoch_wrap(monkeypatch):
     exchange area and restarts.  Poke the stored epochs close to the limit and run across it."""
     monkeypatch.setenv("OU_GRU_V", "2")
     model, spec, sd = get_model("PP16m")
-    model._ws_key = None
+    model.reset_workspace()
     B, T = 2, spec.tot_ds * 25
     mix = synth_mix(spec, B, T - 3)
     nz = noise_list(31, 3, B, T)
@@ -53,7 +53,7 @@ def test_ring_kernel_epoch_wrap(monkeypatch):
     assert 0 <= int(hdr[2]) < 10 ** 6 and 0 <= int(hdr[4]) < 10 ** 6  # wrapped and restarted
     assert int(hdr[3]) == 0 and int(hdr[5]) == 0                      # block counters back at zero
     assert torch.equal(ref, run_enhance(model, mix, nz, n_steps=3))
-    model._ws_key = None
+    model.reset_workspace()
 
 
 def test_ring_kernel_recovers_a_lost_publish(monkeypatch):

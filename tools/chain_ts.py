@@ -18,6 +18,9 @@ def ws_with_slack(B, T):
         n = c_size_t()
         _lib.check(model._L.ou_workspace_bytes(model._handle, B, T, byref(n)), model._handle)
         model._ws = torch.zeros(n.value + (32 << 20), dtype=torch.uint8, device=model.device)
+        from ctypes import c_void_p
+        _lib.check(model._L.ou_workspace_init(model._handle, B, T, c_void_p(model._ws.data_ptr()), c_size_t(model._ws.numel()),
+                                              model._stream()), model._handle)
         model._ws_key = (B, T)
         model._cond_key = None
     return model._ws
