@@ -172,6 +172,14 @@ int ou_transform_inverse(const float* spec, int32_t B, int32_t n_frames, const f
                          int32_t transform_type, float abs_exponent, float factor, int32_t length, float* y,
                          float* scratch, ou_stream_t stream);
 
+/* How the GRU clusters publish the hidden state (score.py:83-89,116 / condition.py:173-179,212 as a multi-workgroup
+ * recurrence): 0 (default) = plain stores inside a cluster whose workgroups share one XCD (its L2 is their point of
+ * coherence; verified by a rendezvous at every launch), agent-scope stores otherwise; 1 = agent-scope (sc1,
+ * write-through) stores always (+0.1 ms per 401-frame pass).  Both forms are backed by a bounded-spin safety net that
+ * repeats a publish system-scope and counts the event in the workspace header (words 20 / 31); a host wrapper should
+ * switch to 1 for good the first time that counter moves. */
+int ou_set_gru_publish_mode(ou_handle* h, int32_t agent_scope);
+
 /* After the stream has been synchronised: OU_OK, or OU_ESYNC if a device-side timeout flag was raised.  The status
  * word (first 4 bytes of the workspace) is sticky: it stays raised until ou_workspace_init() / this call clears it. */
 int ou_check_device_status(ou_handle* h, void* ws);

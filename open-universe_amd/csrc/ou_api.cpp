@@ -71,6 +71,7 @@ struct ou_handle {
   // recurrence kernels a garbage epoch and garbage tags
   struct WsRec { const void* ws; size_t bytes; int B, T; };
   std::vector<WsRec> ws_ready;
+  int gru_agent_stores = 0;  // ou_set_gru_publish_mode
   bool ws_ok(const void* ws, size_t bytes, int B, int T) const {
     for (const WsRec& r : ws_ready)
       if (r.ws == ws) return r.B == B && r.T == T && r.bytes <= bytes;
@@ -176,6 +177,7 @@ struct Runner {
     bool rate_up = false;  // the last up conv on rate_up_kernel (`fir` = the filter AFTER the conv or null, fir_bias / res)
   };
   bool unsupported = false;
+  bool gru_shared = false;  // GRU launches enqueued now may run beside another GRU layer (overlapped conditioner / score pass)
 
   Tensor conv(const ConvL& L, const Tensor& in, const std::string& name, const Epi& e, const Tensor* dst = nullptr) {
     int Nq, Tout;
@@ -199,7 +201,7 @@ struct Runner {
     a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
     { const char* d = std::getenv("OU_DBG"); a.dbg = d ? std::atoi(d) : 0; }
     { const char* d = std::getenv("OU_XCD_MAP"); a.force_xcd_map = d ? std::atoi(d) : -1; }
-    { const char* d = std::getenv("OU_CONV_DIRECT"); a.direct = d ? std::atoi(d) : 2; }
+    { const char* d = std::getenv("OU_CONV_DIRECT"); a.direct = d ? std::atoi(d) : 3; }
     a.tstamps = h->tstamps;
     int cfg = -1;
     if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {
@@ -246,6 +248,13 @@ struct Runner {
     { const char* f = std::getenv("OU_FUSE"); h->fuse_mode = f ? std::atoi(f) : -1; }
     { const char* f = std::getenv("OU_FUSE_NC"); h->fuse_nc = f ? std::atoi(f) : 0; }
     if (h->fuse_mode == 0) return 0;
+    // Throughput regime: with >= ~2 wave tiles per SIMD the three convs run unfused on conv_direct3_kernel at 70-100 TFLOP/s
+    // each, ahead of the fused body's ~75 (measured end to end: PP16 B = 4 19.2 -> 18.4 ms, OR16 B = 16 57.7 -> 55.5 ms, B = 8
+    // even); below that the fused launch wins (B = 1: 24 us for all three convs).
+    if (h->fuse_mode < 0 && Bk.C % 16 == 0 && Bk.c1.KWP && Bk.c2.KWP && Bk.c3.KWP) {
+      const char* d = std::getenv("OU_CONV_DIRECT");
+      if ((!d || std::atoi(d) >= 3) && direct3_tiles_per_simd(Bk.C, T, B, h->num_cu) >= 1.9) return 0;
+    }
     auto shape = [&](int depth) {
       ChainArgs ca;
       ca.depth = depth; ca.B = B; ca.C = Bk.C; ca.T = T; ca.Mp = Bk.c1.Mp; ca.force_nc = h->fuse_nc;
@@ -438,11 +447,18 @@ struct Runner {
       const char* f = std::getenv("OU_GRU_V");
       a.version = f ? std::atoi(f) : 2;
     }
+    a.shared = gru_shared ? 1 : 0;
     { const char* f = std::getenv("OU_GRU_BMAX"); a.force_bmax = f ? std::atoi(f) : 0; }
     if (std::getenv("OU_GRU_TS")) a.tstamps = (long long*)(base + cap - (1u << 20));
     { const char* f = std::getenv("OU_GRU_UPW"); a.force_upw = f ? std::atoi(f) : 0; }
     { const char* f = std::getenv("OU_GRU_BACKOFF"); a.poll_backoff = f ? std::atoi(f) : 0; }
-    { const char* f = std::getenv("OU_GRU_PLAIN_STORES"); a.agent_stores = (f && std::atoi(f) != 0) ? 0 : 1; }
+    // publishes: plain stores inside a cluster that shares one XCD (the L2 is that XCD's point of coherence; the
+    // rendezvous proves the placement), agent-scope (sc1) stores otherwise or on request -- ou_set_gru_publish_mode(), which
+    // the host wrapper calls for good the first time the safety net of the kernel had to repeat a publish
+    {
+      const char* f = std::getenv("OU_GRU_AGENT_STORES");
+      a.agent_stores = f ? (std::atoi(f) != 0) : h->gru_agent_stores;
+    }
     { const char* f = std::getenv("OU_GRU_DBG"); a.dbg = f ? std::atoi(f) : 0; }
     chk(launch_gru(a, h->num_cu, st), G.name.c_str());
     return out;
@@ -950,7 +966,11 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
   if (!use_aux) {
     r.chk(launch_sigma_embed(P.coef, n_steps, r.W(m.sigma.p_off), m.sigma.simple, m.sigma.n_rff, m.film.D, P.g, st), "sigma");
     r.chk(launch_film(P.g, r.W(m.film.w_off), r.W(m.film.b_off), P.film, n_steps, m.film.rows, m.film.D, st), "film");
-    if (warm_start < 0 && h->overlap) {
+    // (only when two GRU layers fit on the machine side by side: their clusters spin on each other's publishes and must
+    // all be resident)
+    const bool gru_fit = gru_ring_batch_cap(m.s_gru.H, h->num_cu, 1, 0) >= 1 && gru_ring_batch_cap(m.c_gru0.H, h->num_cu, 1, 0) >= 1;
+    if (warm_start < 0 && h->overlap && gru_fit) {
+      r.gru_shared = true;
       r.chk(launch_init_x(noise, nullptr, sigma[n_start], P.x.p, nBT, st), "init x");  // universe.py:325-327
       const size_t save = r.off;
       r.fork(st, 2);
@@ -964,6 +984,7 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
     }
   }
   run_condition(r, P, P.mixn.p, T);
+  r.gru_shared = false;
   if (!r.dry && r.ok() && r.off != mark) return fail(h, OU_EINVAL, "internal: workspace layout mismatch");
   h->cond_B = B;
   h->cond_T = T;
@@ -1059,6 +1080,12 @@ int ou_workspace_init(ou_handle* h, int32_t B, int32_t T, void* ws, size_t ws_by
     v.push_back(ou_handle::WsRec{ws, ws_bytes, B, T});
   }
   return rc;
+}
+
+int ou_set_gru_publish_mode(ou_handle* h, int32_t agent_scope) {
+  if (!h) return fail(h, OU_EINVAL, "bad argument");
+  h->gru_agent_stores = agent_scope ? 1 : 0;
+  return OU_OK;
 }
 
 int ou_sampler_step(ou_handle* h, float* x, const float* score, const float* z, float c1, float c2, size_t n,

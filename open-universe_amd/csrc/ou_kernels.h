@@ -34,8 +34,9 @@ struct ConvArgs {
   int xcd_map = 0;                     // filled by launch_conv: block -> tile mapping (see the kernel)
   int force_cfg = -1, force_sc = 0;    // tuning overrides (ou_bench_conv)
   int force_xcd_map = -1;              // tuning: 0 / 1 / 2
-  int direct = 2;                      // OU_CONV_DIRECT: 0 = never use the register-direct split-K kernels, 1 = only the
-                                       // first generation (dword loads), 2 = wide-load variant where a layer has `wd`
+  int direct = 3;                      // OU_CONV_DIRECT: 0 = never use the register-direct kernels, 1 = only the first
+                                       // generation (dword loads), 2 = + wide-load split-K variant where a layer has `wd`,
+                                       // 3 = + the no-split-K throughput kernel (conv_direct3_kernel) for many-column launches
   // Anti-alias FIR of the up path fused into the epilogue (direct kernel, up > 1, KW == 1 only; launch_conv returns
   // hipErrorNotSupported otherwise and the caller runs launch_fir after a plain launch):
   //   y = FIR_{2 up + 1}(u) + bias ; y = res ? (y + res) * res_scale : y,   u = the transposed conv's output WITHOUT bias
@@ -50,6 +51,7 @@ struct ConvArgs {
 // returns hipSuccess or the launch error; `cfg_out` (optional) receives the tile configuration index used
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out = nullptr);
 hipError_t init_conv_kernels();  // raises the dynamic-LDS limit of every instantiation
+double direct3_tiles_per_simd(int M, int Nq, int B, int num_cu);  // wave tiles per SIMD of the no-split-K throughput kernel
 // Small-K rate-change conv of the wide levels with the anti-alias FIR fused: y = conv_{k=s=r}(FIR(prelu(x))) + bias
 // (a.fir = taps or null, a.fir_len = 2r + 1; a.act / a.alpha_val = the PReLU).  hipErrorNotSupported = use launch_fir +
 // launch_conv.
@@ -176,10 +178,13 @@ struct GruArgs {
   int agent_stores = 1;  // 1 (default): publish with agent-scope (sc1) stores; 0: plain stores when the cluster shares one XCD
   int dbg = 0;           // experiments (OU_GRU_DBG): bit 0 = no republish safety net, bit 1 = system-scope publishes from the start,
                          // bit 2 = fault injection: one workgroup drops its publishes of step 50
+  int shared = 0;      // 1: another GRU layer may be resident at the same time (side streams): size launches to half the chip
   int force_bmax = 0;  // testing: cap the utterances per launch (forces the chunked path at small batches)
   int force_upw = 0;  // tuning: 16 / 32 / 64 hidden units per workgroup (0: chosen from the batch size)
 };
 hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st);
+// utterances one ring-kernel launch can carry with its whole grid resident (0: hidden size not supported)
+int gru_ring_batch_cap(int H, int num_cu, int shared, int force_upw);
 // 8-byte exchange granules needed for a batch of B sequences with hidden size H (both kernel generations)
 inline size_t gru_granules(int B, int H) { return (size_t)2 * B * (2 * H + 64); }
 

@@ -501,11 +501,17 @@ hipError_t init_conv_kernels() {
 }
 
 static hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out);
+static hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out);
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
   if (a.Cin % a.CK || a.CK < 2 || (a.CK & (a.CK - 1)) || a.Mp % 64 || a.Nq <= 0) return hipErrorInvalidValue;
   // Deep levels (what the 8-wave split-K configs below were built for): the register-direct kernels.  Wide levels
   // (many blocks of 64 x 128 per CU without splitting K) stay on the LDS-tiled configs.
-  if (a.direct != 0 && (a.force_cfg < 0 || a.force_cfg >= 100)) {
+  if (a.direct >= 3 && (a.force_cfg < 0 || a.force_cfg >= 200)) {
+    hipError_t e = launch_conv_direct3(a, num_cu, stream, cfg_out);
+    if (e != hipErrorInvalidConfiguration) return e;
+    if (a.force_cfg >= 200) return e;
+  }
+  if (a.direct != 0 && (a.force_cfg < 0 || (a.force_cfg >= 100 && a.force_cfg < 200))) {
     const long wide = (long)((a.M + 63) / 64) * ((a.Nq + 127) / 128) * a.B;
     // (longer rows only for the wide-load variant: a 64-channel k5 conv at T = 32 080 runs 19 vs 24 us on it)
     const bool wide_ok = a.wd && a.direct >= 2 && a.stride == 1 && a.up == 1;
@@ -1211,6 +1217,249 @@ __global__ __launch_bounds__(512) void conv_direct_strided_kernel(ConvArgs p) {
 #undef OU_MMA
   DirectEpilogue<TN>::run(p, acc, smem, tid, kw, b, m0, n0);
   if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_direct3_kernel: stride-1 k3 / k5 convs with MANY output columns (batch x length in the hundreds of thousands) --
+// the throughput regime.  No split-K, no LDS, no barrier, no cross-wave reduction: every WAVE owns a (16 TM) x 64 output
+// tile over the whole reduction and stores it straight from its accumulators.
+//   v_mfma_f32_16x16x4_f32 (same 64 FLOP/clk/SIMD as 32x32x2, 16-row granularity: the 48 / 96 / 192-channel levels of
+//   UNIVERSE++ 24 kHz tile exactly):  A lane (m, kk) = W[m0 + 16 i + m][4 J + kk][tap],  B lane (n, kk) = x[4 J + kk][..],
+//   D lane (n, q) reg r = out[m0 + 16 i + 4 q + r][n0 + 4 n + j]  -- output columns are interleaved over the TN = 4
+//   accumulator tiles (column n0 + 4 n + j), so that
+//     * ONE 16-byte load (+ an 8- / 16-byte one) gives a lane the 4 + KW - 1 consecutive samples it needs for all taps of
+//       its four columns (as in conv_direct2_kernel), one 16-byte load from the taps-innermost weight copy all taps of a row;
+//     * the epilogue stores 16 bytes per lane and row: four adjacent samples, 256 contiguous bytes per 16 lanes.
+//   Per ring slot (4 input channels): TM (k3) / 2 TM (k5) + 2 load instructions for 4 KW TM MFMAs (48 / 80 at TM = 4):
+//   0.13 loads per MFMA, ~16 B/clk/CU of L1 traffic -- the kernel is bound by the matrix pipe, 2 waves per SIMD.
+//   Block = 4 waves = 4 adjacent column tiles; blocks of one column chunk (all row groups) run on ONE XCD back to back
+//   (the activations are fetched into one L2, once), weights are L2-resident everywhere.
+//   Summation order per output: channel groups ascending, taps ascending, the 4 channels of a group in MFMA order -- fixed,
+//   but different from the split-K kernels (results agree to fp32 rounding).
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+template <int KW, int TM, int D>
+__global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
+  constexpr int TN = 4, W = KW + TN - 1, KWP = KW == 3 ? 4 : 8, PAD = (KW - 1) / 2;
+  constexpr int A2 = KW == 5 ? 1 : 0;       // second A load per row tile (tap 4)
+  constexpr int LPS = TM * (1 + A2) + 2;    // load instructions per ring slot
+  static_assert(KW == 3 || KW == 5, "k3 / k5");
+  static_assert(D * LPS <= 60, "loads in flight must fit vmcnt");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // block -> (column chunk, row group): blocks L, L + 8, L + 16, ... (one XCD) walk the row groups of one chunk
+  const int L = blockIdx.x, q8 = L >> 3, rg = q8 % p.grid_m, chunk = (q8 / p.grid_m) * 8 + (L & 7);
+  const int n0 = (chunk * 4 + wv) * 64, m0 = rg * (16 * TM), b = blockIdx.z;
+  if (n0 >= p.Nq) return;  // (whole waves: nothing in this kernel synchronises)
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const int l15 = lane & 15, kk = lane >> 4;
+  const int Tin = p.Tin, Mp = p.Mp;
+  const float alpha = p.act ? p.alpha_val : 1.0f;
+  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  const u32x4 rw = direct_desc(p.wd, (unsigned)p.Cin * (unsigned)Mp * (unsigned)KWP * 4u);
+  const int avo = (kk * Mp + m0 + l15) * KWP * 4;
+  // this lane's window: samples t0 .. t0 + W - 1 of channel 4 J + kk; `sh` = samples cut off in front of the row
+  const int t0 = n0 + TN * l15 - PAD;
+  const int sh = t0 < 0 ? -t0 : 0;
+  const int bvo = (t0 + sh < Tin) ? (kk * Tin + t0 + sh) * 4 : (int)0x80000000;
+  const bool edge = __builtin_amdgcn_readfirstlane((n0 < PAD || n0 + 64 + KW - 1 - PAD > Tin) ? 1 : 0) != 0;
+  unsigned vmask = 0;  // bit i: window element i is inside the row
+#pragma unroll
+  for (int i = 0; i < W; i++) vmask |= (t0 + i >= 0 && t0 + i < Tin) ? (1u << i) : 0u;
+
+  const int NG = p.Cin >> 2;  // ring slots (launcher: a multiple of D)
+  f32x4 a4[D][TM], b4[D], b4b[D];
+  float a1[D][TM];
+  f32x2 b2[D];
+#pragma unroll
+  for (int d0 = 0; d0 < D; d0++) {
+#pragma unroll
+    for (int i = 0; i < TM; i++) { a4[d0][i] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[d0][i] = 0.f; }
+    b4[d0] = f32x4{0.f, 0.f, 0.f, 0.f}; b4b[d0] = f32x4{0.f, 0.f, 0.f, 0.f}; b2[d0] = f32x2{0.f, 0.f};
+  }
+  f32x4acc acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) acc[i][j] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+
+#define OU_ISSUE(g_, d)                                                                                               \
+  {                                                                                                                   \
+    const int aso = (g_) * 4 * Mp * KWP * 4, xso = (g_) * 4 * Tin * 4;                                                \
+    _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                  \
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"                                               \
+                   : "+v"(a4[d][i]) : "v"(avo), "s"(rw), "s"(aso), "n"(i * 16 * KWP * 4));                            \
+      if constexpr (A2 == 1)                                                                                          \
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4"                                               \
+                     : "+v"(a1[d][i]) : "v"(avo), "s"(rw), "s"(aso), "n"(i * 16 * KWP * 4 + 16));                     \
+    }                                                                                                                 \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(b4[d]) : "v"(bvo), "s"(rx), "s"(xso));             \
+    if constexpr (KW == 3)                                                                                            \
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:16" : "+v"(b2[d]) : "v"(bvo), "s"(rx), "s"(xso)); \
+    else                                                                                                              \
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "+v"(b4b[d]) : "v"(bvo), "s"(rx), "s"(xso)); \
+  }
+#define OU_MMA(d, out)                                                                                                \
+  {                                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS));                                                           \
+    _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                  \
+      asm volatile("" : "+v"(a4[d][i]));                                                                              \
+      if constexpr (A2 == 1) asm volatile("" : "+v"(a1[d][i]));                                                       \
+    }                                                                                                                 \
+    asm volatile("" : "+v"(b4[d]));                                                                                   \
+    if constexpr (KW == 3) asm volatile("" : "+v"(b2[d]));                                                            \
+    else asm volatile("" : "+v"(b4b[d]));                                                                             \
+    const float Lw[8] = {b4[d].x, b4[d].y, b4[d].z, b4[d].w, KW == 3 ? b2[d].x : b4b[d].x, KW == 3 ? b2[d].y : b4b[d].y, \
+                         b4b[d].z, b4b[d].w};                                                                         \
+    float X[W];                                                                                                       \
+    if (edge) {                                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < W; i++) {                                                                 \
+        float v = Lw[i];                                                                                              \
+        _Pragma("unroll") for (int s2 = 1; s2 <= PAD; s2++) v = sh == s2 ? (i - s2 >= 0 ? Lw[i - s2 >= 0 ? i - s2 : 0] : 0.f) : v; \
+        X[i] = ((vmask >> i) & 1u) ? v : 0.f;                                                                         \
+      }                                                                                                               \
+    } else {                                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < W; i++) X[i] = Lw[i];                                                     \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < W; i++) X[i] = X[i] >= 0.f ? X[i] : alpha * X[i];                           \
+    _Pragma("unroll") for (int k = 0; k < KW; k++)                                                                    \
+      _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                \
+        const float av = k == 0 ? a4[d][i].x : (k == 1 ? a4[d][i].y : (k == 2 ? a4[d][i].z : (k == 3 ? a4[d][i].w : a1[d][i]))); \
+        _Pragma("unroll") for (int j = 0; j < TN; j++)                                                                \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, X[j + k], acc[i][j], 0, 0, 0);                         \
+      }                                                                                                               \
+  }
+  static_assert(D == 2 || D == 4, "ring depth");
+  if constexpr (D == 4) {
+    OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
+    const int NR = NG / 4;
+    for (int r = 0; r + 1 < NR; r++) {
+      const int g = r * 4;
+      OU_MMA(0, 3); OU_ISSUE(g + 4, 0);
+      OU_MMA(1, 3); OU_ISSUE(g + 5, 1);
+      OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
+      OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
+    }
+    OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
+  } else {
+    OU_ISSUE(0, 0); OU_ISSUE(1, 1);
+    const int NR = NG / 2;
+    for (int r = 0; r + 1 < NR; r++) {
+      const int g = r * 2;
+      OU_MMA(0, 1); OU_ISSUE(g + 2, 0);
+      OU_MMA(1, 1); OU_ISSUE(g + 3, 1);
+    }
+    OU_MMA(0, 1); OU_MMA(1, 0);
+  }
+#undef OU_ISSUE
+#undef OU_MMA
+
+  // ---- epilogue: bias, cond add, FiLM, residual -- straight from the accumulators, 16 bytes per lane and row
+  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+  const size_t ybase = (size_t)b * p.Cout * p.Tout;
+  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+  const int c0 = n0 + TN * l15;
+  int ncol = p.Nq - c0;
+  if (ncol > 4) ncol = 4;
+  const bool vec4 = (p.Tout & 3) == 0 && ncol == 4;
+  if (ncol > 0) {
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+      f32x4 ad[4], rs[4];
+      float bi[4], ga[4], be[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + 16 * i + 4 * kk + r;
+        const bool on = row < p.M;
+        const size_t idx = ybase + (size_t)(on ? row : 0) * p.Tout + c0;
+        ad[r] = f32x4{0.f, 0.f, 0.f, 0.f}; rs[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bi[r] = on ? p.bias[row] : 0.f;
+        ga[r] = 1.f; be[r] = 0.f;
+        if (on && filmb) { ga[r] = filmb[row]; be[r] = filmb[p.Cout + row]; }
+        if (on && vec4) {
+          if (p.add) ad[r] = *reinterpret_cast<const f32x4*>(p.add + idx);
+          if (p.res) rs[r] = *reinterpret_cast<const f32x4*>(p.res + idx);
+        } else if (on) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (p.add && j < ncol) ad[r][j] = p.add[idx + j];
+            if (p.res && j < ncol) rs[r][j] = p.res[idx + j];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + 16 * i + 4 * kk + r;
+        if (row >= p.M) continue;
+        const size_t idx = ybase + (size_t)row * p.Tout + c0;
+        f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        if (p.in_scale) v *= insc;
+        v += bi[r];
+        if (p.add) v = (v + ad[r]) * p.add_scale;
+        if (filmb) v = ga[r] * v + be[r];
+        if (p.res) v = (v + rs[r]) * p.res_scale;
+        if (vec4) {
+          *reinterpret_cast<f32x4*>(p.y + idx) = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (j < ncol) p.y[idx + j] = v[j];
+        }
+      }
+    }
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+struct Direct3Cfg {
+  int KW, TM, D;
+  void (*kern)(ConvArgs);
+};
+#define OU_D3(KW, TM, D) {KW, TM, D, conv_direct3_kernel<KW, TM, D>}
+static const Direct3Cfg kDirect3Cfgs[] = {
+    // ring depth 4 only: the depth-2 instantiations come out of the compiler with MORE registers (240-256, spills)
+    OU_D3(3, 2, 4), OU_D3(3, 3, 4), OU_D3(3, 4, 4), OU_D3(5, 2, 4), OU_D3(5, 3, 4), OU_D3(5, 4, 4),
+};
+// rows per wave tile (in units of 16) for a layer with M output channels: exact tiling where 16-row granularity allows it
+static int direct3_tm(int M) {
+  if (M <= 32) return 2;
+  if (M % 64 != 0 && M % 48 == 0) return 3;  // 48, 96, 144: no padding rows
+  return 4;
+}
+// wave tiles per SIMD the throughput kernel would get for a stride-1 k3 / k5 layer of M rows (what launch_conv's choice and
+// the ConvBlock fusion plan are based on)
+double direct3_tiles_per_simd(int M, int Nq, int B, int num_cu) {
+  const int tm = direct3_tm(M);
+  return (double)((M + 16 * tm - 1) / (16 * tm)) * ((Nq + 63) / 64) * B / (4.0 * num_cu);
+}
+// Launches the throughput kernel when the layer fits it AND supplies enough wave tiles to fill the machine without
+// splitting K; hipErrorInvalidConfiguration = "use the other kernels".
+static hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
+  if (!a.wd || a.stride != 1 || a.up != 1 || (a.KW != 3 && a.KW != 5) || a.pad != (a.KW - 1) / 2 || a.fir || a.Cin % 16 ||
+      (a.in_scale != nullptr && a.act))
+    return hipErrorInvalidConfiguration;
+  if ((long)a.Cin * a.Tin * 4 >= (1L << 31) || (long)a.Cin * a.Mp * 8 * 4 >= (1L << 31)) return hipErrorInvalidConfiguration;
+  // wave tiles per SIMD below which the split-K kernels are ahead (measured, PP16 / PP24 at B = 2 .. 16: break-even at
+  // ~1 tile per SIMD, +8 .. +60 % from 2 up; OU_TILE_MIN: tuning / tests, 0 = wherever it fits)
+  double tile_min = 1.5;
+  { const char* e = getenv("OU_TILE_MIN"); if (e) tile_min = atof(e); }
+  int tm = direct3_tm(a.M);
+  if (a.force_cfg >= 200) tm = (a.force_cfg / 10) % 10;
+  if (tm < 2 || tm > 4) return hipErrorInvalidConfiguration;
+  const long gy = (a.M + 16 * tm - 1) / (16 * tm), ct = (a.Nq + 63) / 64;
+  const double per_simd = (double)gy * ct * a.B / (4.0 * num_cu);
+  if (a.force_cfg < 200 && per_simd < tile_min) return hipErrorInvalidConfiguration;
+  void (*kern)(ConvArgs) = nullptr;
+  for (const Direct3Cfg& c : kDirect3Cfgs)
+    if (c.KW == a.KW && c.TM == tm) { kern = c.kern; break; }
+  if (!kern) return hipErrorInvalidConfiguration;
+  ConvArgs aa = a;
+  aa.grid_m = (int)gy;
+  const long chunks = (ct + 3) / 4, chunks8 = (chunks + 7) / 8 * 8;
+  aa.grid_n = (int)chunks8;
+  if (cfg_out) *cfg_out = 200 + 10 * tm + a.KW;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(chunks8 * gy), 1, a.B), dim3(256), 0, stream, aa);
+  return hipGetLastError();
 }
 
 struct DirectCfg {
@@ -2901,11 +3150,17 @@ __device__ __forceinline__ void gather_wait(u32x4 (&hv)[N]) {
   else static_assert(N == 2, "gather_wait: unsupported register count");
 }
 
-// Experiment (OU_GRU_DBG bit 3), out of line so that the hot loop does not change: when a hand-off has not arrived after
-// 256 poll rounds, look at the first stale granule of this lane's columns once more with three kinds of loads and leave
-// what they return in status words 21..29 (first event only).
+// First-recovery record, out of line so that the hot loop does not change: when a hand-off has not arrived after 256 poll
+// rounds, look at the first stale granule of this lane's columns once more with three kinds of loads and leave what they
+// return -- and where this wave runs now vs. at the rendezvous -- in status words 21..29 (first event of a workspace only).
+// Reading the record: sc1 == want            -> the publish was only late (a member was not scheduled / not resident);
+//                     sc1 != want, atomic == want (or sc0 sc1 == want) -> the line sits where an L2-served agent-scope load of
+//                                               THIS CU does not see it: the writer or the reader is not on the cluster's XCD
+//                                               any more (xcc now != xcc at the rendezvous), e.g. after a context save / restore;
+//                     nothing == want         -> the writer has not stored it: look at that member's own wait record.
 __device__ __attribute__((noinline)) void gru_stale_probe(const unsigned long long* buf, int col0, int ncol, int lstride,
-                                                          unsigned want, unsigned* err, unsigned who) {
+                                                          unsigned want, unsigned* err, unsigned who, unsigned xcc_then,
+                                                          unsigned step) {
   for (int i = 0; i < ncol; i++) {
     const unsigned long long* g = buf + col0 + (i >> 2) * lstride + (i & 3);
     u32x2 a, b, c;
@@ -2916,10 +3171,13 @@ __device__ __attribute__((noinline)) void gru_stale_probe(const unsigned long lo
                                                        __HIP_MEMORY_SCOPE_AGENT);
     c = u32x2{(unsigned)v, (unsigned)(v >> 32)};
     if (atomicAdd(err + 21, 1u) == 0u) {
+      unsigned now;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(now));
       err[22] = who; err[23] = (unsigned)(col0 + (i >> 2) * lstride + (i & 3)); err[24] = want;
       err[25] = a.y; err[26] = b.y; err[27] = c.y;
       asm volatile("buffer_inv sc1\n\tglobal_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(g) : "memory");
       err[28] = a.y;
+      err[29] = (step << 16) | ((xcc_then & 0xFFu) << 8) | (now & 0xFFu);
     }
     return;
   }
@@ -3124,9 +3382,9 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
             flagged = __builtin_amdgcn_readfirstlane(mflag.y) == epoch;
           }
           if (((spins & 255u) == 255u || flagged) && !(p.dbg & 1)) {
-            if ((p.dbg & 8) && !flagged)
+            if (!flagged && !sysmode)  // first trigger of this wave: leave a record of what the stale granule looks like
               gru_stale_probe(xq + (size_t)(step & 1) * H, cg * 4, NC, 4 * LPU, want, p.err,
-                              ((unsigned)cluster << 16) | ((unsigned)g << 8) | (unsigned)(tid >> 6));
+                              ((unsigned)cluster << 16) | ((unsigned)g << 8) | (unsigned)(tid >> 6), xcc, (unsigned)step);
             if (fin) {
               const unsigned long long gran = ((unsigned long long)want << 32) | (unsigned)__float_as_int(hprev);
               unsigned long long* dst = xq + (size_t)(step & 1) * H + unit;
@@ -3153,7 +3411,10 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
           // a long wait (~2 ms): leave this workgroup's position in its rendezvous slot -- {epoch, xcc | step << 8}; the
           // tag stays the epoch, late members still pass the rendezvous -- for whoever ends up reporting a time-out
           if (spins == 4096u && tid == 0) {
-            const unsigned long long pos = ((unsigned long long)epoch << 32) | (xcc & 0xFFu) | ((unsigned)step << 8);
+            unsigned now;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(now));
+            // low byte: XCC now (4 bits) | XCC at the rendezvous (4 bits)
+            const unsigned long long pos = ((unsigned long long)epoch << 32) | ((now & 0xFu) << 4) | (xcc & 0xFu) | ((unsigned)step << 8);
             asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(xq + 2 * H + g), "v"(pos) : "memory");
           }
           if (spins > GRU_SPIN_LIMIT) {
@@ -3293,6 +3554,25 @@ static int gru_ring_resident_per_cu(int upw) {
   }
   return cache[slot];
 }
+static int gru_ring_upw(int H, int force_upw) {
+  return (force_upw == 32 && H <= 256) ? 32 : ((force_upw == 8 && H >= 128 && H <= 256) ? 8 : 16);
+}
+// utterances one ring-kernel launch may carry: whole groups of 8 clusters (one per XCD), two clusters per utterance,
+// the whole grid resident -- on HALF the machine when another GRU layer may run beside it (`shared`)
+int gru_ring_batch_cap(int H, int num_cu, int shared, int force_upw) {
+  if (H % 64) return 0;
+  const int upw = gru_ring_upw(H, force_upw), nwg = H / upw;
+  int per_cu = 1;
+  switch (H / 64) {
+    case 1: per_cu = gru_ring_resident_per_cu<1>(upw); break;
+    case 2: per_cu = gru_ring_resident_per_cu<2>(upw); break;
+    case 4: per_cu = gru_ring_resident_per_cu<4>(upw); break;
+    case 6: per_cu = gru_ring_resident_per_cu<6>(upw); break;
+    default: return 0;
+  }
+  const int wg_cap = num_cu * per_cu / (shared ? 2 : 1);
+  return (wg_cap / (8 * nwg)) * 8 / 2;
+}
 template <int HB>
 static hipError_t launch_gru_ring(const GruArgs& c, int upw, int nclusters, hipStream_t st) {
   constexpr int H = 64 * HB;
@@ -3326,24 +3606,13 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
   else if (a.H % 16 == 0 && batch_cap(16) >= a.B) upw = 16;
   else if (a.H % 32 == 0 && batch_cap(32) >= a.B) upw = 32;
   // the ring kernel runs 256-thread workgroups of 16 units (32 on request, H <= 256)
-  if (a.version == 2) upw = (a.force_upw == 32 && a.H <= 256) ? 32 : ((a.force_upw == 8 && a.H >= 128 && a.H <= 256) ? 8 : 16);
+  if (a.version == 2) upw = gru_ring_upw(a.H, a.force_upw);
   const int nwg = a.H / upw;
   int bmax = batch_cap(upw);
-  if (a.version == 2) {
-    // residency of the ring kernel: grid <= (resident workgroups per CU) x CUs / 2 -- the other half stays free for the
-    // second GRU layer that may run beside this one (conditioner / first score pass); a launch that would not fit is
-    // split into sub-launches, never enqueued oversized (a member that is not resident would be waited for in vain)
-    int per_cu = 1;
-    switch (HB) {
-      case 1: per_cu = gru_ring_resident_per_cu<1>(upw); break;
-      case 2: per_cu = gru_ring_resident_per_cu<2>(upw); break;
-      case 4: per_cu = gru_ring_resident_per_cu<4>(upw); break;
-      case 6: per_cu = gru_ring_resident_per_cu<6>(upw); break;
-      default: return hipErrorInvalidConfiguration;
-    }
-    const int wg_cap = num_cu * per_cu / 2;
-    bmax = (wg_cap / (8 * nwg)) * 8 / 2;  // whole groups of 8 clusters (one per XCD), two clusters per utterance
-  }
+  // residency of the ring kernel: every member of a cluster spins on the others, so a launch is sized to what can be on
+  // the machine at once (half of it when a second GRU layer may run beside this one: conditioner / first score pass);
+  // a batch that does not fit is split into sub-launches, never enqueued oversized
+  if (a.version == 2) bmax = gru_ring_batch_cap(a.H, num_cu, a.shared, a.force_upw);
   if (a.force_bmax > 0 && a.force_bmax < bmax) bmax = a.force_bmax;
   if (bmax < 1) return hipErrorInvalidConfiguration;
   for (int b0 = 0; b0 < a.B; b0 += bmax) {

@@ -40,7 +40,8 @@ std::string finish_conv(ConvL& L, Alloc& a) {
   L.a_off = a.take(1);
   if (L.fir_mode == 1 || L.fir_mode == 2) { L.fir_off = a.take(L.fir_len); L.fbias_off = a.take(L.Cout); }
   // layers the wide-load direct kernel can take (deep levels at small batch): taps-innermost copy of the weights
-  if (L.stride == 1 && L.up == 1 && (L.KW == 3 || L.KW == 5) && L.Cin % 64 == 0 && L.pad == (L.KW - 1) / 2) {
+  // (Cin % 64: what conv_direct2_kernel's 8-way split-K needs; Cin % 16: the no-split-K conv_direct3_kernel)
+  if (L.stride == 1 && L.up == 1 && (L.KW == 3 || L.KW == 5) && L.Cin % 16 == 0 && L.pad == (L.KW - 1) / 2) {
     L.KWP = L.KW == 3 ? 4 : 8;
     L.wd_off = a.take((size_t)L.Cin * L.Mp * L.KWP);
   }

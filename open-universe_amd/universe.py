@@ -60,7 +60,9 @@ class Universe:
         # False: free-running -- the status word is still copied to pinned host memory after every call (async,
         # no host sync) and examined at the start of the next call, in synchronize() and in _status(force=True).
         self.check_status = True
-        self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._status_host = torch.zeros(64, dtype=torch.int32).pin_memory()
+        self._gru_recoveries_seen = {}   # workspace key -> recovery counter already acted upon
+        self.gru_agent_scope = False     # True once the GRU publishes were switched to agent-scope stores for good
         self._status_event = None
         self._status_ws = None
         self.training = False
@@ -147,6 +149,18 @@ class Universe:
     def _raise_on_status(self):
         self._status_event = None
         v = int(self._status_host[0])
+        # word 20: publishes the GRU clusters' safety net had to repeat on this workspace (0 on a healthy device).  The first
+        # time it moves, the cheaper publish form has shown that it cannot be relied upon on this device / in this process
+        # mix: switch to agent-scope (write-through) publishes for good -- +0.1 ms per GRU pass, no more recoveries.
+        rec = int(self._status_host[20])
+        if rec and not self.gru_agent_scope and not v:
+            import warnings
+
+            self.gru_agent_scope = True
+            _lib.check(self._L.ou_set_gru_publish_mode(self._handle, 1), self._handle)
+            warnings.warn(f"open_universe_amd: {rec} GRU hand-off(s) had to be repeated by the kernel's safety net "
+                          f"(first event: {self._status_host[21:30].tolist()}); results are unaffected, the recurrence "
+                          "kernels publish with agent-scope stores from now on", RuntimeWarning)
         if v:
             ws = self._status_ws if self._status_ws is not None else self._ws
             diag = ws[:256].view(torch.int32).cpu().tolist()  # who waited for what (see gru_ring_kernel)
@@ -174,7 +188,7 @@ class Universe:
         st = torch.cuda.current_stream(self.device)
         self._status_ws = self._ws
         with torch.cuda.stream(st):
-            self._status_host.copy_(self._ws[:4].view(torch.int32), non_blocking=True)
+            self._status_host.copy_(self._ws[:256].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(st)
         self._status_event = ev
@@ -196,9 +210,12 @@ class Universe:
             return {"recoveries": 0, "system_scope": 0}
         d = self._ws[:128].view(torch.int32).cpu().tolist()
         out = {"recoveries": int(d[20]), "system_scope": int(d[31])}
-        if d[21]:  # OU_GRU_DBG=8: what three kinds of loads saw in the first stale granule (see gru_stale_probe)
-            out["probe"] = {"events": d[21], "who": d[22], "granule": d[23], "want": d[24], "sc1": d[25], "sc0sc1": d[26],
-                            "atomic": d[27], "sc1_after_inv": d[28]}
+        out["agent_scope_publishes"] = bool(self.gru_agent_scope)
+        if d[21]:  # first recovery on this workspace: what three kinds of loads saw in the stale granule (gru_stale_probe)
+            out["first_event"] = {"events": d[21], "cluster": (d[22] >> 16) & 0xFFFF, "member": (d[22] >> 8) & 0xFF,
+                                  "wave": d[22] & 0xFF, "granule": d[23], "want": d[24], "sc1": d[25], "sc0sc1": d[26],
+                                  "atomic": d[27], "sc1_after_inv": d[28], "step": (d[29] >> 16) & 0xFFFF,
+                                  "xcc_at_rendezvous": (d[29] >> 8) & 0xFF, "xcc_now": d[29] & 0xFF}
         return out
 
     def tensor(self, name):

@@ -66,9 +66,16 @@ def test_ring_kernel_recovers_a_lost_publish(monkeypatch):
     ref = run_enhance(model, mix, nz, n_steps=2)
     base = model.gru_exchange_stats()
     monkeypatch.setenv("OU_GRU_DBG", "4")
-    out = run_enhance(model, mix, nz, n_steps=2)
+    with pytest.warns(RuntimeWarning, match="GRU hand-off"):
+        out = run_enhance(model, mix, nz, n_steps=2)
     monkeypatch.delenv("OU_GRU_DBG")
     after = model.gru_exchange_stats()
     assert torch.equal(ref, out)
     assert after["recoveries"] > base["recoveries"] and after["system_scope"] > base["system_scope"]
-    assert torch.equal(run_enhance(model, mix, nz, n_steps=2), ref)  # and the next launch is back on the fast path
+    # the host wrapper has seen the recovery counter move and switched the publishes to agent-scope stores for good
+    assert model.gru_agent_scope and after["agent_scope_publishes"] and "first_event" in after
+    assert torch.equal(run_enhance(model, mix, nz, n_steps=2), ref)  # same result with write-through publishes
+    model._L.ou_set_gru_publish_mode(model._handle, 0)  # (the model is shared by the other tests: back to the default)
+    model.gru_agent_scope = False
+    model.reset_workspace()
+    assert torch.equal(run_enhance(model, mix, nz, n_steps=2), ref)  # and on the fast path again

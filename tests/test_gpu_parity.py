@@ -200,9 +200,25 @@ def test_c_abi_error_codes():
     x = torch.zeros(1, 1, spec.tot_ds * 4, device="cuda")
     ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # a workspace that is too small is refused where it is prepared ...
+    rc = L.ou_workspace_init(model._handle, 1, x.shape[-1], ctypes.c_void_p(ws.data_ptr()), ws.numel(), st)
+    assert rc == _lib.OU_ENOMEM
+    # ... and a buffer that ou_workspace_init has not prepared for this shape is refused by the forward calls (it would feed
+    # the recurrence kernels a garbage tag epoch)
     rc = L.ou_condition(model._handle, ctypes.c_void_p(x.data_ptr()), 1, x.shape[-1], ctypes.c_void_p(ws.data_ptr()),
                         ws.numel(), st)
-    assert rc == _lib.OU_ENOMEM
+    assert rc == _lib.OU_EINVAL and b"ou_workspace_init" in L.ou_last_error(model._handle)
+    big = torch.empty(model._workspace(1, x.shape[-1]).numel(), dtype=torch.uint8, device="cuda")
+    rc = L.ou_condition(model._handle, ctypes.c_void_p(x.data_ptr()), 1, x.shape[-1], ctypes.c_void_p(big.data_ptr()),
+                        big.numel(), st)
+    assert rc == _lib.OU_EINVAL  # large enough, but never initialised
+    assert L.ou_workspace_init(model._handle, 1, x.shape[-1], ctypes.c_void_p(big.data_ptr()), big.numel(), st) == 0
+    assert L.ou_condition(model._handle, ctypes.c_void_p(x.data_ptr()), 1, x.shape[-1], ctypes.c_void_p(big.data_ptr()),
+                          big.numel(), st) == 0
+    x2 = torch.zeros(2, 1, x.shape[-1], device="cuda")
+    rc = L.ou_condition(model._handle, ctypes.c_void_p(x2.data_ptr()), 2, x.shape[-1], ctypes.c_void_p(big.data_ptr()),
+                        big.numel(), st)
+    assert rc == _lib.OU_EINVAL  # prepared for another batch size
     rc = L.ou_condition(model._handle, ctypes.c_void_p(x.data_ptr()), 1, spec.tot_ds * 4 - 1,
                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), st)
     assert rc == _lib.OU_EINVAL
@@ -464,3 +480,29 @@ def test_fused_first_rate_change_conv_matches_fir_pass_plus_conv(name, B, T, mon
     assert sum(model.launch_stats()) < sum(n_ref) or not spec.score.use_antialiasing
     for b in range(B):
         record(f"rate_down.{name}.{b}", O.si_sdr(ref[b], out[b]), 100)
+
+
+@pytest.mark.parametrize("name,B,T", [("PP16m", 3, 3000), ("PP16", 2, 8000), ("PP24", 1, 9000), ("OR16", 2, 5000)])
+def test_throughput_conv_kernel_matches_split_k_kernels(name, B, T, monkeypatch):
+    """conv_direct3_kernel (no split-K, one 16 TM x 64 tile per wave over the whole reduction, 16x16x4 MFMA, stores
+    straight from the accumulators) takes the k3 / k5 layers of launches with many columns.  OU_TILE_MIN=0 forces it
+    onto every layer it fits (Cin % 16 == 0), OU_CONV_DIRECT=2 switches it off: same convolution, different summation
+    order -- and against the oracle like every other path."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(41, 3, B, Tp)
+    monkeypatch.setenv("OU_CONV_DIRECT", "2")
+    ref = run_enhance(model, mix, nz, n_steps=3)
+    monkeypatch.setenv("OU_CONV_DIRECT", "3")
+    monkeypatch.setenv("OU_TILE_MIN", "0")
+    monkeypatch.setenv("OU_FUSE", "0")  # the fused ConvBlock bodies of the wide levels would hide those layers from it
+    out = run_enhance(model, mix, nz, n_steps=3)
+    n_conv = model.launch_stats()[1]
+    out2 = run_enhance(model, mix, nz, n_steps=3)
+    assert torch.equal(out, out2)
+    record(f"direct3_vs_splitk.{name}.b{B}", O.si_sdr(ref, out), 90)
+    sdict = spec.to_dict()
+    e_ref = O.enhance(sd, sdict, mix, n_steps=3, noise=nz)
+    record(f"direct3_vs_oracle.{name}.b{B}", O.si_sdr(e_ref, out.cpu()), 80)
+    assert n_conv > 0

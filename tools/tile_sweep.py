@@ -1,0 +1,45 @@
+"""Tuning aid: per-layer time of the k3 / k5 convs at a throughput batch size -- the launcher's own choice ("auto"), the
+no-split-K throughput kernel forced (conv_direct3_kernel, cfg 200 + 10 TM + KW), and the kernels of round 2
+(OU_CONV_DIRECT=2: split-K direct kernels / LDS kernel)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import json
+import torch
+from helpers import get_spec
+from open_universe_amd import Universe, state_dict as S
+
+name = sys.argv[1] if len(sys.argv) > 1 else "PP24"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+spec = get_spec(name)
+model = Universe(spec, state_dict=S.synthetic_state_dict(spec, 0), device="cuda:0")
+plan = {c["name"]: c for c in json.loads(model._L.ou_plan_json(model._handle).decode())["convs"]}
+T0 = (4 * spec.fs // spec.tot_ds + 1) * spec.tot_ds
+pfx = spec.score_prefix
+rates = spec.score.rate_factors
+layers = []
+T = T0
+for i in range(len(rates) + 1):
+    for cv in ("conv1", "conv2"):
+        layers.append((f"{pfx}.encoder.ds_modules.{i}.{cv}", T))
+    if i < len(rates):
+        T //= rates[i]
+for lname, Tin in layers:
+    L = plan.get(lname)
+    if L is None:
+        print("missing", lname); continue
+    M, Cin, KW = L["M"], L["Cin"], L["KW"]
+    flop = 2.0 * M * Cin * KW * Tin * B
+    row = []
+    tm = 2 if M <= 32 else (3 if (M % 64 and M % 48 == 0) else 4)
+    for tag, cfg, env in (("auto", -1, None), ("direct3", 200 + 10 * tm + KW, None), ("r2", -1, "2")):
+        if env is not None:
+            os.environ["OU_CONV_DIRECT"] = env
+        try:
+            ms, used = model.bench_conv(lname, B, Tin, cfg=cfg, with_res=False, iters=10)
+            row.append(f"{tag}: {ms*1e3:7.1f} us {flop/ms/1e9:6.1f} TF/s (cfg {used})")
+        except Exception as e:
+            row.append(f"{tag}: n/a ({str(e)[:40]})")
+        os.environ.pop("OU_CONV_DIRECT", None)
+    print(f"{lname[-34:]:34s} M={M:4d} Cin={Cin:4d} k{KW} T={Tin:6d} B={B} | " + " | ".join(row), flush=True)
