@@ -321,19 +321,30 @@ def main():
             return 1e3 * ts[len(ts) // 2]
 
         host_enqueue = {"eager_ms": enqueue_ms(step)}
-        try:
-            run = model.graphed_enhance(args.batch, T, n_steps=args.n_steps)
-            run(mix, rng=rng)
-            host_enqueue["hipgraph_ms"] = enqueue_ms(lambda: run(mix, rng=rng))
+
+        def loop_ms(fn):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                run(mix, rng=rng)
+                fn()
             torch.cuda.synchronize()
-            host_enqueue["hipgraph_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / args.steps
-            host_enqueue["note"] = ("median host time of one enhance call returning without a sync: eager = Python + C walk "
-                                    "of the network (~430 launches on 4 streams); hipgraph = noise draws + one replay of "
-                                    "the captured ou_enhance (model.graphed_enhance)")
+            return 1e3 * (time.perf_counter() - t0) / args.steps
+
+        try:
+            # the capturable form: one chain on one stream (OU_ENH_SERIAL); and, for the record, the eager call's own
+            # fork / join structure captured as it is
+            run = model.graphed_enhance(args.batch, T, n_steps=args.n_steps, serial=True)
+            run(mix, rng=rng)
+            host_enqueue["hipgraph_ms"] = enqueue_ms(lambda: run(mix, rng=rng))
+            host_enqueue["hipgraph_ms_per_step"] = loop_ms(lambda: run(mix, rng=rng))
+            run_fj = model.graphed_enhance(args.batch, T, n_steps=args.n_steps, serial=False)
+            run_fj(mix, rng=rng)
+            host_enqueue["hipgraph_forkjoin_ms_per_step"] = loop_ms(lambda: run_fj(mix, rng=rng))
+            host_enqueue["note"] = ("eager_ms / hipgraph_ms: median host time of one enhance call returning without a sync (eager = "
+                                    "Python + C walk of the network, ~400 launches; hipgraph = noise draws + one replay).  "
+                                    "*_ms_per_step: free-running loops of args.steps calls.  hipgraph = the serial chain "
+                                    "(OU_ENH_SERIAL) captured; hipgraph_forkjoin = the eager call's three side streams captured "
+                                    "as graph edges -- slower than the chain, which is why graphed_enhance captures the chain")
         except Exception as e:  # capture support is a convenience, never the measured path
             host_enqueue["hipgraph_error"] = repr(e)[:300]
         model.check_status = True
@@ -352,7 +363,8 @@ def main():
         # records: (ms, algorithmic flops, algorithmic bytes, variant); variant < 40: conv_mfma_kernel tile configs,
         # 40-49: rate_down_kernel,
         # 66 / 76: conv_direct2_kernel, other 50-99: conv_direct_kernel / conv_direct_strided_kernel variants,
-        # >= 100: conv_chain_kernel (fused ConvBlock body).
+        # 100-199: conv_chain_kernel (fused ConvBlock body), >= 200: conv_direct3_kernel (2xx: 200 + 10 TM + KW) /
+        # conv_direct3s_kernel (260 + R).
         def summarise(rr):
             if not rr:
                 return None
@@ -372,19 +384,22 @@ def main():
             "lds": "ou::conv_mfma_kernel (LDS-tiled fp32-MFMA implicit-GEMM Conv1d, wide levels / strided convs)",
             "rate": "ou::rate_down_kernel / rate_up_kernel (outermost rate-change convs with the anti-alias FIR fused, K = 64)",
             "chain": "ou::conv_chain_kernel (fused ConvBlock body, C = 32 / 64 levels)",
+            "direct3": "ou::conv_direct3_kernel / conv_direct3s_kernel (no-split-K throughput kernels: one (16 TM) x 64 tile per "
+                       "wave over the whole reduction, 16x16x4 fp32 MFMA, register-direct operands, stores from the accumulators)",
         }
         groups = {"direct2": summarise([r for r in recs if r[3] in (66, 76)]),
                   "direct": summarise([r for r in recs if 50 <= r[3] < 100 and r[3] not in (66, 76)]),
                   "lds": summarise([r for r in recs if r[3] < 40]),
                   "rate": summarise([r for r in recs if 40 <= r[3] < 50]),
-                  "chain": summarise([r for r in recs if r[3] >= 100])}
+                  "chain": summarise([r for r in recs if 100 <= r[3] < 200]),
+                  "direct3": summarise([r for r in recs if r[3] >= 200])}
         groups = {k: v for k, v in groups.items() if v}
         dom = max(groups, key=lambda k: groups[k]["ms_per_enhance"])  # the dominant kernel = most time per enhance
         gen = groups[dom]
         allconv = summarise(list(recs))
         traffic, traffic_note = None, "not collected (PMC passes are separate rocprofv3 runs)"
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.model == "PP16" and args.batch == 1 and args.n_steps == 8:
+        if os.path.exists(tpath) and args.model == "PP16" and args.batch == 1 and args.n_steps == 8 and not args.varlen:
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = tj.get(dom + "_bytes_per_launch")

@@ -137,6 +137,8 @@ int ou_aux_to_wav(ou_handle* h, float* wav_out, int32_t B, int32_t T, void* ws, 
 #define OU_ENH_KEEP_RMS 1u       /* universe.py:352-354 */
 #define OU_ENH_USE_AUX_SIGNAL 2u /* universe.py:317-319 */
 #define OU_ENH_NO_PEAK_GUARD 4u  /* skip universe.py:356-357 (debug) */
+#define OU_ENH_SERIAL 8u         /* everything on the caller's stream, no side streams inside the call: the form to capture
+                                  * into a hipGraph (a captured fork / join replays slower than the serial chain) */
 
 /* Universe.enhance(mix, n_steps, epsilon, rng=...) -- universe.py:231-375, for a (B, T_raw) batch:
  * pad (:219-223) -> normalize (utils/norm.py:47-87) -> conditioner -> x0 = sigma_0 * noise[0] ->

@@ -13,7 +13,7 @@ OU_ABI_VERSION = 2
 OU_OK, OU_EINVAL, OU_ENOTIMPL, OU_EMISSING, OU_ESHAPE, OU_EHIP, OU_ENOMEM, OU_ESYNC = 0, -1, -2, -3, -4, -5, -6, -7
 OU_KIND_UNIVERSE, OU_KIND_UNIVERSE_GAN = 0, 1
 OU_ACT_NONE, OU_ACT_PRELU, OU_ACT_SNAKE = 0, 1, 2
-OU_ENH_KEEP_RMS, OU_ENH_USE_AUX_SIGNAL, OU_ENH_NO_PEAK_GUARD = 1, 2, 4
+OU_ENH_KEEP_RMS, OU_ENH_USE_AUX_SIGNAL, OU_ENH_NO_PEAK_GUARD, OU_ENH_SERIAL = 1, 2, 4, 8
 
 
 class NetConfig(Structure):

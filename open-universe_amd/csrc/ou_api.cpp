@@ -909,6 +909,9 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
                ou_stream_t stream) {
   if (!h || !mix || !out || !ws || B < 1 || T_raw < 1) return fail(h, OU_EINVAL, "bad argument");
   const bool use_aux = (flags & OU_ENH_USE_AUX_SIGNAL) != 0;
+  const bool saved_overlap = h->overlap;
+  struct OverlapGuard { ou_handle* h; bool v; ~OverlapGuard() { h->overlap = v; } } overlap_guard{h, saved_overlap};
+  if (flags & OU_ENH_SERIAL) h->overlap = false;
   if (!use_aux && !noise) return fail(h, OU_EINVAL, "noise must be given");
   if (n_steps < 2 || n_steps > kMaxSteps) return fail(h, OU_EINVAL, "n_steps must be in [2, 256]");
   if (warm_start >= n_steps) return fail(h, OU_EINVAL, "warm_start must be < n_steps");

@@ -1248,9 +1248,12 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   // block -> (column chunk, row group): blocks L, L + 8, L + 16, ... (one XCD) walk the row groups of one chunk
-  const int L = blockIdx.x, q8 = L >> 3, rg = q8 % p.grid_m, chunk = (q8 / p.grid_m) * 8 + (L & 7);
-  const int n0 = (chunk * 4 + wv) * 64, m0 = rg * (16 * TM), b = blockIdx.z;
-  if (n0 >= p.Nq) return;  // (whole waves: nothing in this kernel synchronises)
+  // (batch element, chunk) pairs are numbered through -- a short signal has only a chunk or two, and eight of those pairs,
+  // not eight chunks of one element, are what is spread over the XCDs
+  const int L = blockIdx.x, q8 = L >> 3, rg = q8 % p.grid_m, cidx = (q8 / p.grid_m) * 8 + (L & 7);
+  const int b = cidx / p.grid_n, chunk = cidx - b * p.grid_n;
+  const int n0 = (chunk * 4 + wv) * 64, m0 = rg * (16 * TM);
+  if (b >= p.B || n0 >= p.Nq) return;  // (whole waves: nothing in this kernel synchronises)
   if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
   const int l15 = lane & 15, kk = lane >> 4;
   const int Tin = p.Tin, Mp = p.Mp;
@@ -1411,6 +1414,198 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
   if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// conv_direct3s_kernel<R>: the same per-wave scheme for the layers WITHOUT a taps-innermost weight copy, many columns:
+//   R = 1: 1x1 convs and transposed convs as `up` phase GEMMs (row m = co * up + phase);
+//   R > 1: rate-change (down) convs, k = s = R, whole frames (Tin = Nq * R).
+// Operands from the tap-major packed weights [Cin/CK][R][CK][Mp] and the activations:
+//   A (tap k, 4 channels 4 J + kk): lane (m, kk) loads FOUR ADJACENT ROWS m0 + 4 m .. + 3 of weight row (channel, tap) with
+//     one 16-byte load -- the four 16-row accumulator tiles are row-INTERLEAVED (tile i holds rows m0 + 4 m + i), so one load
+//     feeds all four;
+//   B: lane (n, kk) loads the 4 R consecutive samples of its four adjacent output columns (R 16-byte loads); column j, tap k
+//     is window element j R + k.
+//   D tile (i, j): lane (n, q) reg r = out[m0 + 4 (4 q + r) + i][n0 + 4 n + j].  For a phase GEMM with up = 4 that is
+//   channel (m0 / 4 + 4 q + r), phase i, frame n0 + 4 n + j: the lane's 16 values of one channel are 16 CONSECUTIVE output
+//   samples (64-byte stores); up = 2 / 8 likewise in runs of 8 / 32; other rates store sample by sample.
+//   2 R load instructions per 16 R MFMAs.  The up path's anti-alias FIR stays a separate pass behind this kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <int R, int D>
+__global__ __launch_bounds__(256, 2) void conv_direct3s_kernel(ConvArgs p) {
+  constexpr int TM = 4, TN = 4, LPS = 2 * R;
+  static_assert(D * LPS <= 60, "loads in flight must fit vmcnt");
+  static_assert(D == 2 || D == 4, "ring depth");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = blockIdx.x, q8 = L >> 3, rg = q8 % p.grid_m, cidx = (q8 / p.grid_m) * 8 + (L & 7);
+  const int b = cidx / p.grid_n, chunk = cidx - b * p.grid_n;  // (batch element, chunk) pairs numbered through
+  const int n0 = (chunk * 4 + wv) * 64, m0 = rg * 64;
+  if (b >= p.B || n0 >= p.Nq) return;
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const int l15 = lane & 15, kk = lane >> 4;
+  const int Tin = p.Tin, Mp = p.Mp, CK = p.CK, lck = 31 - __clz(CK);
+  const float alpha = p.act ? p.alpha_val : 1.0f;
+  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  const u32x4 rw = direct_desc(p.w, (unsigned)p.Cin * (unsigned)R * (unsigned)Mp * 4u);
+  const int avo = (kk * Mp + m0 + 4 * l15) * 4;
+  const int c0 = n0 + TN * l15;  // this lane's first output column
+  const int bvo = c0 < p.Nq ? (kk * Tin + c0 * R) * 4 : (int)0x80000000;
+
+  const int NG = p.Cin >> 2;  // ring slots = groups of 4 channels (launcher: a multiple of D, CK % 4 == 0)
+  f32x4 a4[D][R], b4[D][R];
+#pragma unroll
+  for (int d0 = 0; d0 < D; d0++)
+#pragma unroll
+    for (int k = 0; k < R; k++) { a4[d0][k] = f32x4{0.f, 0.f, 0.f, 0.f}; b4[d0][k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  f32x4acc acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) acc[i][j] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+
+#define OU_ISSUE(g_, d)                                                                                                  \
+  {                                                                                                                      \
+    const int c4 = (g_) * 4;                                                                                             \
+    const int wrow = ((c4 >> lck) * R) * CK + (c4 & (CK - 1)); /* packed row of (channel 4 J, tap 0) */                  \
+    const int xso = c4 * Tin * 4;                                                                                        \
+    _Pragma("unroll") for (int k = 0; k < R; k++)                                                                        \
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(a4[d][k]) : "v"(avo), "s"(rw), "s"((wrow + k * CK) * Mp * 4)); \
+    _Pragma("unroll") for (int k = 0; k < R; k++)                                                                        \
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "+v"(b4[d][k]) : "v"(bvo), "s"(rx), "s"(xso), "n"(16 * k)); \
+  }
+#define OU_MMA(d, out)                                                                                                   \
+  {                                                                                                                      \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS));                                                              \
+    _Pragma("unroll") for (int k = 0; k < R; k++) { asm volatile("" : "+v"(a4[d][k])); asm volatile("" : "+v"(b4[d][k])); } \
+    float X[4 * R];                                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < R; k++) {                                                                      \
+      X[4 * k + 0] = b4[d][k].x; X[4 * k + 1] = b4[d][k].y; X[4 * k + 2] = b4[d][k].z; X[4 * k + 3] = b4[d][k].w;        \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int e = 0; e < 4 * R; e++) X[e] = X[e] >= 0.f ? X[e] : alpha * X[e];                          \
+    _Pragma("unroll") for (int k = 0; k < R; k++)                                                                        \
+      _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                   \
+        const float av = i == 0 ? a4[d][k].x : (i == 1 ? a4[d][k].y : (i == 2 ? a4[d][k].z : a4[d][k].w));              \
+        _Pragma("unroll") for (int j = 0; j < TN; j++)                                                                   \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, X[j * R + k], acc[i][j], 0, 0, 0);                        \
+      }                                                                                                                  \
+  }
+  if constexpr (D == 4) {
+    OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
+    const int NR = NG / 4;
+    for (int r = 0; r + 1 < NR; r++) {
+      const int g = r * 4;
+      OU_MMA(0, 3); OU_ISSUE(g + 4, 0);
+      OU_MMA(1, 3); OU_ISSUE(g + 5, 1);
+      OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
+      OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
+    }
+    OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
+  } else {
+    OU_ISSUE(0, 0); OU_ISSUE(1, 1);
+    const int NR = NG / 2;
+    for (int r = 0; r + 1 < NR; r++) {
+      const int g = r * 2;
+      OU_MMA(0, 1); OU_ISSUE(g + 2, 0);
+      OU_MMA(1, 1); OU_ISSUE(g + 3, 1);
+    }
+    OU_MMA(0, 1); OU_MMA(1, 0);
+  }
+#undef OU_ISSUE
+#undef OU_MMA
+
+  // ---- epilogue: value (i, j, r) = row m0 + 4 (4 kk + r) + i, column c0 + j
+  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+  const size_t ybase = (size_t)b * p.Cout * p.Tout;
+  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+  const int up = p.up;
+  int ncol = p.Nq - c0;
+  if (ncol > 4) ncol = 4;
+  if (ncol <= 0) return;
+  auto finish = [&](f32x4 v, int co, size_t idx, bool full) {  // 4 consecutive output samples of channel co at idx
+    if (p.in_scale) v *= insc;
+    v += p.bias[co];
+    if (p.add) {
+      f32x4 ad;
+      if (full) ad = *reinterpret_cast<const f32x4*>(p.add + idx);
+      else { ad = f32x4{0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; e++) if (e < ncol) ad[e] = p.add[idx + e]; }
+      v = (v + ad) * p.add_scale;
+    }
+    if (filmb) v = filmb[co] * v + filmb[p.Cout + co];
+    if (p.res) {
+      f32x4 rs;
+      if (full) rs = *reinterpret_cast<const f32x4*>(p.res + idx);
+      else { rs = f32x4{0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; e++) if (e < ncol) rs[e] = p.res[idx + e]; }
+      v = (v + rs) * p.res_scale;
+    }
+    if (full) *reinterpret_cast<f32x4*>(p.y + idx) = v;
+    else for (int e = 0; e < 4; e++) if (e < ncol) p.y[idx + e] = v[e];
+  };
+  const bool al4 = (p.Tout & 3) == 0;
+  if (up == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const int row = m0 + 4 * (4 * kk + r) + i;
+        if (row >= p.M) continue;
+        finish(f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]}, row, ybase + (size_t)row * p.Tout + c0,
+               al4 && ncol == 4);
+      }
+  } else if (up == 4 && ncol == 4) {  // channel co: phases i = 0..3 of frames c0 + j -> 16 consecutive samples
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int co = (m0 >> 2) + 4 * kk + r;
+      if (co * 4 >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+        finish(f32x4{acc[0][j][r], acc[1][j][r], acc[2][j][r], acc[3][j][r]}, co,
+               ybase + (size_t)co * p.Tout + (size_t)(c0 + j) * 4, true);
+    }
+  } else if (up == 2 && ncol == 4) {  // rows 4 (4 kk + r) + {0, 1} = channel a (phases 0, 1), + {2, 3} = channel a + 1
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; h2++) {
+        const int co = (m0 >> 1) + 2 * (4 * kk + r) + h2;
+        if (co * 2 >= p.M) continue;
+        const size_t idx = ybase + (size_t)co * p.Tout + (size_t)c0 * 2;
+        finish(f32x4{acc[2 * h2][0][r], acc[2 * h2 + 1][0][r], acc[2 * h2][1][r], acc[2 * h2 + 1][1][r]}, co, idx, true);
+        finish(f32x4{acc[2 * h2][2][r], acc[2 * h2 + 1][2][r], acc[2 * h2][3][r], acc[2 * h2 + 1][3][r]}, co, idx + 4, true);
+      }
+  } else if (up == 8 && ncol == 4) {  // rows 4 (4 kk + r) + i: channel 2 kk + (r >> 1), phase 4 (r & 1) + i
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int co = (m0 >> 3) + 2 * kk + (r >> 1);
+      if (co * 8 >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+        finish(f32x4{acc[0][j][r], acc[1][j][r], acc[2][j][r], acc[3][j][r]}, co,
+               ybase + (size_t)co * p.Tout + (size_t)(c0 + j) * 8 + 4 * (r & 1), true);
+    }
+  } else {  // any rate: sample by sample
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const int m = m0 + 4 * (4 * kk + r) + i;
+        if (m >= p.M) continue;
+        const int co = (int)__umulhi((unsigned)m, p.magic_up), ph = m - co * up;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          if (j >= ncol) continue;
+          const size_t idx = ybase + (size_t)co * p.Tout + (size_t)(c0 + j) * up + ph;
+          float v = acc[i][j][r];
+          if (p.in_scale) v *= insc;
+          v += p.bias[co];
+          if (p.add) v = (v + p.add[idx]) * p.add_scale;
+          if (filmb) v = filmb[co] * v + filmb[p.Cout + co];
+          if (p.res) v = (v + p.res[idx]) * p.res_scale;
+          p.y[idx] = v;
+        }
+      }
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
 struct Direct3Cfg {
   int KW, TM, D;
   void (*kern)(ConvArgs);
@@ -1432,9 +1627,57 @@ double direct3_tiles_per_simd(int M, int Nq, int B, int num_cu) {
   const int tm = direct3_tm(M);
   return (double)((M + 16 * tm - 1) / (16 * tm)) * ((Nq + 63) / 64) * B / (4.0 * num_cu);
 }
+struct Direct3sCfg {
+  int R;
+  void (*kern)(ConvArgs);
+};
+static const Direct3sCfg kDirect3sCfgs[] = {
+    {1, conv_direct3s_kernel<1, 4>}, {2, conv_direct3s_kernel<2, 4>}, {3, conv_direct3s_kernel<3, 2>},
+    {4, conv_direct3s_kernel<4, 2>}, {5, conv_direct3s_kernel<5, 2>},
+};
 // Launches the throughput kernel when the layer fits it AND supplies enough wave tiles to fill the machine without
 // splitting K; hipErrorInvalidConfiguration = "use the other kernels".
+static hipError_t launch_conv_direct3s(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out, double tile_min) {
+  // 1x1 / phase GEMMs (KW = 1, any up) and k = s = R rate-change convs on whole frames
+  const int R = a.stride > 1 ? a.stride : 1;
+  if (a.KW != R || a.pad != 0 || (a.stride > 1 && (a.up != 1 || a.Tin != a.Nq * R)) || a.Cin % 16 || a.CK % 4 || a.fir ||
+      (a.in_scale != nullptr && a.act))
+    return hipErrorInvalidConfiguration;
+  if ((long)a.Cin * a.Tin * 4 >= (1L << 31) || (long)a.Cin * a.KW * a.Mp * 4 >= (1L << 31)) return hipErrorInvalidConfiguration;
+  void (*kern)(ConvArgs) = nullptr;
+  for (const Direct3sCfg& c : kDirect3sCfgs)
+    if (c.R == R) { kern = c.kern; break; }
+  if (!kern) return hipErrorInvalidConfiguration;
+  const long gy = (a.M + 63) / 64, ct = (a.Nq + 63) / 64;
+  const double per_simd = (double)gy * ct * a.B / (4.0 * num_cu);
+  if (a.force_cfg < 200 && per_simd < tile_min) return hipErrorInvalidConfiguration;
+  ConvArgs aa = a;
+  aa.grid_m = (int)gy;
+  aa.magic_up = a.up == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.up) + 1u;
+  const long chunks = (ct + 3) / 4, total8 = (chunks * a.B + 7) / 8 * 8;
+  aa.grid_n = (int)chunks;
+  if (cfg_out) *cfg_out = 260 + R;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(total8 * gy)), dim3(256), 0, stream, aa);
+  return hipGetLastError();
+}
 static hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
+  double tile_min_s = 1.5;
+  { const char* e = getenv("OU_TILE_MIN"); if (e) tile_min_s = atof(e); }
+  if (a.KW == 1 || a.stride > 1) {
+    // (with the up-path FIR requested as a fused epilogue: refuse, so that the caller runs conv + FIR pass -- unless the layer
+    // is too small for this kernel anyway, then the split-K kernel with its fused FIR gets its chance)
+    if (a.fir) {
+      ConvArgs probe = a;
+      probe.fir = nullptr;
+      const int R = 1;
+      const double per_simd = (double)((a.M + 63) / 64) * ((a.Nq + 63) / 64) * a.B / (4.0 * num_cu);
+      if (a.KW == R && a.stride == 1 && a.pad == 0 && a.Cin % 16 == 0 && a.CK % 4 == 0 && per_simd >= tile_min_s &&
+          !(a.in_scale != nullptr && a.act) && a.force_cfg < 0)
+        return hipErrorNotSupported;
+      return hipErrorInvalidConfiguration;
+    }
+    return launch_conv_direct3s(a, num_cu, stream, cfg_out, tile_min_s);
+  }
   if (!a.wd || a.stride != 1 || a.up != 1 || (a.KW != 3 && a.KW != 5) || a.pad != (a.KW - 1) / 2 || a.fir || a.Cin % 16 ||
       (a.in_scale != nullptr && a.act))
     return hipErrorInvalidConfiguration;
@@ -1455,10 +1698,10 @@ static hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t
   if (!kern) return hipErrorInvalidConfiguration;
   ConvArgs aa = a;
   aa.grid_m = (int)gy;
-  const long chunks = (ct + 3) / 4, chunks8 = (chunks + 7) / 8 * 8;
-  aa.grid_n = (int)chunks8;
+  const long chunks = (ct + 3) / 4, total8 = (chunks * a.B + 7) / 8 * 8;
+  aa.grid_n = (int)chunks;
   if (cfg_out) *cfg_out = 200 + 10 * tm + a.KW;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(chunks8 * gy), 1, a.B), dim3(256), 0, stream, aa);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(total8 * gy)), dim3(256), 0, stream, aa);
   return hipGetLastError();
 }
 
@@ -1482,9 +1725,12 @@ struct StridedCfg {
 // copies of ring registers whose loads are still in flight (tools/check_isa.py) -- and a 32 x 64 tile per wave has the
 // same MFMA time per CU as two waves with 32 x 32 tiles, with half the A traffic.
 #define OU_STRIDED(R, G) {R, G, 2, conv_direct_strided_kernel<R, G, 2>}
+// (The G = 3 instantiations -- 3r taps, anti-alias FIR folded into the weights, OU_FIR_FOLD -- are not built: the compiler
+// gives each of them a 32-byte private segment (10-14 scratch instructions around the ring), and the folded form lost to the
+// separate FIR pass on every level anyway; with OU_FIR_FOLD those layers run on conv_mfma_kernel.  Every kernel that IS
+// dispatched has private_segment_fixed_size 0 -- `make check` verifies it.)
 static const StridedCfg kStridedCfgs[] = {
-    OU_STRIDED(2, 1), OU_STRIDED(2, 3), OU_STRIDED(3, 1), OU_STRIDED(3, 3), OU_STRIDED(4, 1), OU_STRIDED(4, 3),
-    OU_STRIDED(5, 1), OU_STRIDED(5, 3), OU_STRIDED(8, 1),
+    OU_STRIDED(2, 1), OU_STRIDED(3, 1), OU_STRIDED(4, 1), OU_STRIDED(5, 1), OU_STRIDED(8, 1),
 };
 
 // Launches a direct kernel when the layer fits one; hipErrorInvalidConfiguration = "use conv_mfma_kernel".

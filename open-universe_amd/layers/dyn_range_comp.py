@@ -84,7 +84,7 @@ class CompressedMagSTFT:
         if self._inv:
             inv = not inv
         if not inv:
-            if x.shape[1] != 1:
+            if x.shape[1] != 1:  # (checked before the rank, like the reference, dyn_range_comp.py:75-78)
                 raise ValueError("Expects single channel input")
             if x.ndim != 3:
                 raise ValueError("Expects a 3D input tensor (batch, channels, time)")
@@ -97,9 +97,7 @@ class CompressedMagSTFT:
         return self(x, inv=True, length=length)
 
     def _stft(self, sig):
-        B, T = sig.shape
-        if T <= self.n_fft // 2:
-            raise RuntimeError("the signal is shorter than the STFT's reflection-free centre padding allows")
+        B, T = sig.shape  # (any length >= 1: the centre padding is zeros -- pad_mode="constant" --, not a reflection)
         F = self.n_fft // 2 + 1
         n_frames = self._L.ou_transform_frames(T, self.n_fft, self.hop_length)
         out = torch.empty(B, 2 * F, n_frames, dtype=torch.float32, device=sig.device)

@@ -483,7 +483,7 @@ class Universe:
         return res
 
     # ---- hipGraph replay of the hot path ------------------------------------------------------------------------
-    def graphed_enhance(self, batch, length, n_steps=None, epsilon=None, keep_rms=False):
+    def graphed_enhance(self, batch, length, n_steps=None, epsilon=None, keep_rms=False, serial=True):
         """-> callable `run(mix, rng=None)` equivalent to `enhance(mix, n_steps, epsilon, rng=rng, keep_rms=keep_rms)`
         for inputs of shape (batch, length): ONE `ou_enhance` (pad .. peak guard, ~430 launches over the caller's stream
         and three side streams) is captured into a hipGraph once and replayed per call -- the host then enqueues one
@@ -501,7 +501,10 @@ class Universe:
         s_out = torch.empty(B, 1, mix_len, dtype=torch.float32, device=dev)
         sigma = self.get_std_dev(torch.linspace(0, 1, n_steps).to(torch.float32).flip(dims=[0])).to(torch.float32).contiguous()
         ws = self._workspace(B, T)
-        flags = _lib.OU_ENH_KEEP_RMS if keep_rms else 0
+        # serial=True: capture the call as ONE chain on the capture stream.  The eager path forks three side streams inside
+        # the call (mel branch, st convs, first score-encoder pass); captured, every fork / join becomes a cross-stream edge
+        # of the graph, and such a graph replays SLOWER than the chain (measured, profiles/).
+        flags = (_lib.OU_ENH_KEEP_RMS if keep_rms else 0) | (_lib.OU_ENH_SERIAL if serial else 0)
 
         def launch():
             _lib.check(self._L.ou_enhance(
@@ -524,8 +527,9 @@ class Universe:
         def run(mix, rng=None):
             self._poll_deferred_status()
             x = self._prep(mix).reshape(B, 1, mix_len)
-            if self._ws_key != (B, T) or self._ws is not ws:
-                raise RuntimeError("the model's workspace changed shape since graphed_enhance() was set up")
+            if self._workspace(B, T) is not ws:  # (eager calls on other shapes in between are fine: workspaces are cached)
+                raise RuntimeError("the workspace this graph was captured on has been released (reset_workspace / cache "
+                                   "eviction): set graphed_enhance() up again")
             s_mix.copy_(x)
             for n in range(n_steps):  # draw order of the reference: x0, z_0 .. z_{N-2}
                 s_noise[n].copy_(torch.randn((B, 1, T), dtype=torch.float32, device=dev, generator=rng))

@@ -25,15 +25,28 @@ for i in range(len(rates) + 1):
         layers.append((f"{pfx}.encoder.ds_modules.{i}.{cv}", T))
     if i < len(rates):
         T //= rates[i]
+# rate-change convs (down: k = s = r; up: transposed conv as r phase GEMMs, KW = 1) and the GRU input projection
+T = T0
+for i, r in enumerate(rates):
+    layers.append((f"{pfx}.encoder.ds_modules.{i}.rate_change_conv", T))
+    T //= r
+layers.append((f"{pfx}.encoder.gru#l0", T))
+nb = len(rates) + 1
+for j in range(1, nb):
+    layers.append((f"{pfx}.decoder.up_modules.{j}.rate_change_conv", T))
+    T *= rates[len(rates) - j]
 for lname, Tin in layers:
     L = plan.get(lname)
     if L is None:
         print("missing", lname); continue
     M, Cin, KW = L["M"], L["Cin"], L["KW"]
-    flop = 2.0 * M * Cin * KW * Tin * B
+    stride = L.get("stride", 1)
+    Nq = Tin // stride
+    flop = 2.0 * M * Cin * KW * Nq * B
     row = []
     tm = 2 if M <= 32 else (3 if (M % 64 and M % 48 == 0) else 4)
-    for tag, cfg, env in (("auto", -1, None), ("direct3", 200 + 10 * tm + KW, None), ("r2", -1, "2")):
+    forced = 200 + 10 * tm + KW if (KW in (3, 5) and stride == 1) else 260 + stride
+    for tag, cfg, env in (("auto", -1, None), ("direct3", forced, None), ("r2", -1, "2")):
         if env is not None:
             os.environ["OU_CONV_DIRECT"] = env
         try:
@@ -42,4 +55,4 @@ for lname, Tin in layers:
         except Exception as e:
             row.append(f"{tag}: n/a ({str(e)[:40]})")
         os.environ.pop("OU_CONV_DIRECT", None)
-    print(f"{lname[-34:]:34s} M={M:4d} Cin={Cin:4d} k{KW} T={Tin:6d} B={B} | " + " | ".join(row), flush=True)
+    print(f"{lname[-34:]:34s} M={M:4d} Cin={Cin:4d} k{KW} s{stride} up{L.get('up', 1)} T={Tin:6d} B={B} | " + " | ".join(row), flush=True)
