@@ -399,13 +399,16 @@ def main():
         allconv = summarise(list(recs))
         traffic, traffic_note = None, "not collected (PMC passes are separate rocprofv3 runs)"
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.model == "PP16" and args.batch == 1 and args.n_steps == 8 and not args.varlen:
+        cfg_tag = f"{args.model}_b{args.batch}" + ("_varlen" if args.varlen else "") + (f"_n{args.n_steps}" if args.n_steps != 8 else "")
+        if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic = tj.get(dom + "_bytes_per_launch")
-            traffic_note = ("STATIC: copied from profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / "
-                            "WRITE_SIZE passes of this command on an earlier box), not measured in this run. "
-                            + tj.get("note", ""))
+            ent = tj.get("configs", {}).get(cfg_tag)
+            if ent is not None:
+                traffic = ent.get(dom + "_bytes_per_launch")
+                traffic_note = (f"STATIC: copied from profiles/pmc_traffic.json [{cfg_tag}] (separate rocprofv3 --pmc FETCH_SIZE / "
+                                "WRITE_SIZE passes of this command on an earlier box), not measured in this run. "
+                                + tj.get("note", ""))
 
         # whole score-network forward (the unit of work of SURVEY 8(d)): HIP events on the launch stream around
         # K calls of the operator seam score_model(x, sigma | cond)

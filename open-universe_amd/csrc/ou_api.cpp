@@ -253,7 +253,7 @@ struct Runner {
     // even); below that the fused launch wins (B = 1: 24 us for all three convs).
     if (h->fuse_mode < 0 && Bk.C % 16 == 0 && Bk.c1.KWP && Bk.c2.KWP && Bk.c3.KWP) {
       const char* d = std::getenv("OU_CONV_DIRECT");
-      if ((!d || std::atoi(d) >= 3) && direct3_tiles_per_simd(Bk.C, T, B, h->num_cu) >= 1.9) return 0;
+      if ((!d || std::atoi(d) >= 3) && direct3_tiles_per_simd(Bk.C, T, B, h->num_cu) >= 1.9 && T >= 1024) return 0;
     }
     auto shape = [&](int depth) {
       ChainArgs ca;

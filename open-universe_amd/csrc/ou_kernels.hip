@@ -1661,9 +1661,10 @@ static hipError_t launch_conv_direct3s(const ConvArgs& a, int num_cu, hipStream_
   return hipGetLastError();
 }
 static hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
-  double tile_min_s = 1.5;
+  double tile_min_s = 1.2;
   { const char* e = getenv("OU_TILE_MIN"); if (e) tile_min_s = atof(e); }
   if (a.KW == 1 || a.stride > 1) {
+    if (tile_min_s > 0 && a.Nq < 1024 && a.force_cfg < 200) return hipErrorInvalidConfiguration;
     // (with the up-path FIR requested as a fused epilogue: refuse, so that the caller runs conv + FIR pass -- unless the layer
     // is too small for this kernel anyway, then the split-K kernel with its fused FIR gets its chance)
     if (a.fir) {
@@ -1682,10 +1683,13 @@ static hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t
       (a.in_scale != nullptr && a.act))
     return hipErrorInvalidConfiguration;
   if ((long)a.Cin * a.Tin * 4 >= (1L << 31) || (long)a.Cin * a.Mp * 8 * 4 >= (1L << 31)) return hipErrorInvalidConfiguration;
-  // wave tiles per SIMD below which the split-K kernels are ahead (measured, PP16 / PP24 at B = 2 .. 16: break-even at
-  // ~1 tile per SIMD, +8 .. +60 % from 2 up; OU_TILE_MIN: tuning / tests, 0 = wherever it fits)
-  double tile_min = 1.5;
+  // wave tiles per SIMD below which the split-K kernels are ahead (measured, PP16 / PP24 at B = 1 .. 16: break-even at
+  // ~1 tile per SIMD, +8 .. +60 % from 1.5 up, 2-3x slower at 0.25; OU_TILE_MIN: tuning / tests, 0 = wherever it fits)
+  double tile_min = 1.2;
   { const char* e = getenv("OU_TILE_MIN"); if (e) tile_min = atof(e); }
+  // short signals (the T / 160 level: 401 frames = 6.3 column tiles per element) waste the last tile and supply few
+  // chunks; the split-K kernels keep them whatever the batch (B = 8: 54 vs 107 us on the latent k3 convs)
+  if (tile_min > 0 && a.Nq < 1024 && a.force_cfg < 200) return hipErrorInvalidConfiguration;
   int tm = direct3_tm(a.M);
   if (a.force_cfg >= 200) tm = (a.force_cfg / 10) % 10;
   if (tm < 2 || tm > 4) return hipErrorInvalidConfiguration;

@@ -4,7 +4,7 @@ import csv, json, os, shutil, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "final")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
 shutil.copy(os.path.join(src, "prof", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats_PP16_B1.csv"))
 for n in sorted(os.listdir(src)):
     if n.startswith("bench_") and n.endswith(".json"):
@@ -15,10 +15,12 @@ for n in sorted(os.listdir(src)):
         json.loads(lines[-1])
         open(os.path.join(dst, f"{tag}_{n}"), "w").write(lines[-1] + "\n")
 for n in sorted(os.listdir(src)):
-    if n.startswith(("kstats_", "pmc_sq_", "gru_ts", "layers", "direct_ts", "direct_sweep", "ubench_")):
+    if n.startswith(("kstats_", "pmc_sq_", "gru_ts", "layers", "direct_ts", "direct_sweep", "ubench_", "tile_sweep", "stress_",
+                     "xcc_migrate", "timings")):
         shutil.copy(os.path.join(src, n), os.path.join(dst, f"{tag}_{n}"))
 
 FAMS = {"direct2": ("conv_direct2_kernel",), "direct": ("conv_direct_kernel", "conv_direct_strided_kernel"),
+        "direct3": ("conv_direct3_kernel", "conv_direct3s_kernel"),
         "lds": ("conv_mfma_kernel",), "rate": ("rate_down_kernel", "rate_up_kernel"), "chain": ("conv_chain_kernel",), "gru_ring": ("gru_ring_kernel",),
         "gru_cluster": ("gru_cluster_kernel",)}
 
@@ -32,20 +34,26 @@ def fam_avg(path):
     return {k: {"dispatches": len(v), "avg": sum(v) / len(v)} for k, v in agg.items()}
 
 
-fetch = fam_avg(os.path.join(src, "pmc_FETCH_SIZE", "p_counter_collection.csv"))
-write = fam_avg(os.path.join(src, "pmc_WRITE_SIZE", "p_counter_collection.csv"))
 KB = 1024.0
-out = {
-    "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate runs of `python bench.py --steps 2 --warmup 1 "
-            "--no-cpu-baseline --profile-steps 1`, PP16, batch 1), averaged per dispatch over the instantiations of each "
-            "kernel family; bytes = 2 x FETCH_SIZE KB (gfx950 correction of MI355X_MICROARCH.md, HBM section: the counter "
-            "tallies 128-B requests at 64 B) + WRITE_SIZE KB (uncalibrated, taken as is). Memory-side L2 traffic: "
-            "Infinity-Cache hits are included.",
-    "raw_KB_per_dispatch": {"FETCH_SIZE": fetch, "WRITE_SIZE": write},
-}
-for fam in FAMS:
-    if fam in fetch and fam in write:
-        out[fam + "_bytes_per_launch"] = (2 * fetch[fam]["avg"] + write[fam]["avg"]) * KB
-        out[fam + "_bytes_per_launch_uncorrected"] = (fetch[fam]["avg"] + write[fam]["avg"]) * KB
+NOTE = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate runs of the bench command of that configuration with "
+        "--steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1), averaged per dispatch over the instantiations of each kernel "
+        "family; bytes = 2 x FETCH_SIZE KB (gfx950 correction of MI355X_MICROARCH.md, HBM section: the counter tallies 128-B "
+        "requests at 64 B) + WRITE_SIZE KB (uncalibrated, taken as is). Memory-side L2 traffic: Infinity-Cache hits are included.")
+out = {"note": NOTE, "configs": {}}
+# configuration tag -> sub-directory prefix written by tools/round_profile.sh (pmc_<tag>_FETCH_SIZE / _WRITE_SIZE)
+for cfg_tag in ("PP16_b1", "PP16_b8", "PP24_b8_varlen", "PP16_b4_n64", "OR16_b16_n32"):
+    fp = os.path.join(src, f"pmc_{cfg_tag}_FETCH_SIZE", "p_counter_collection.csv")
+    wp = os.path.join(src, f"pmc_{cfg_tag}_WRITE_SIZE", "p_counter_collection.csv")
+    if not (os.path.exists(fp) and os.path.exists(wp)):
+        continue
+    fetch, write = fam_avg(fp), fam_avg(wp)
+    ent = {"raw_KB_per_dispatch": {"FETCH_SIZE": fetch, "WRITE_SIZE": write}}
+    for fam in FAMS:
+        if fam in fetch and fam in write:
+            ent[fam + "_bytes_per_launch"] = (2 * fetch[fam]["avg"] + write[fam]["avg"]) * KB
+            ent[fam + "_bytes_per_launch_uncorrected"] = (fetch[fam]["avg"] + write[fam]["avg"]) * KB
+    out["configs"][cfg_tag] = ent
+    if cfg_tag == "PP16_b1":  # (the keys bench.py of round 2 read, kept at the top level)
+        out.update({k: v for k, v in ent.items()})
 json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if k.endswith("per_launch")}, indent=1))
+print(json.dumps({c: {k: round(v) for k, v in e.items() if k.endswith("per_launch")} for c, e in out["configs"].items()}, indent=1))

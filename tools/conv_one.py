@@ -1,4 +1,5 @@
-"""Run ONE packed conv layer of PP16 repeatedly (ou_bench_conv) -- target for rocprofv3 --pmc."""
+"""Run ONE packed conv layer repeatedly (ou_bench_conv) -- target for rocprofv3 --pmc.
+usage: conv_one.py <layer> <Tin> <iters> [model=PP16] [B=1] [cfg=-1]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -8,11 +9,14 @@ from ctypes import byref, c_float, c_int32, c_size_t, c_void_p
 from helpers import get_spec
 from open_universe_amd import Universe, state_dict as S, _lib
 layer, Tin, iters = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-spec = get_spec("PP16")
+name = sys.argv[4] if len(sys.argv) > 4 else "PP16"
+B = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+cfg = int(sys.argv[6]) if len(sys.argv) > 6 else -1
+spec = get_spec(name)
 model = Universe(spec, state_dict=S.synthetic_state_dict(spec, 0), device="cuda:0")
-ws = torch.zeros(1 << 29, dtype=torch.uint8, device="cuda")
+ws = torch.zeros(1 << 31, dtype=torch.uint8, device="cuda")
 ms, used = c_float(), c_int32()
-_lib.check(model._L.ou_bench_conv(model._handle, layer.encode(), 1, Tin, -1, -1, 1, iters, c_void_p(ws.data_ptr()),
+_lib.check(model._L.ou_bench_conv(model._handle, layer.encode(), B, Tin, cfg, -1, 1, iters, c_void_p(ws.data_ptr()),
                                   c_size_t(ws.numel()), model._stream(), byref(ms), byref(used)), model._handle)
 torch.cuda.synchronize()
-print(f"{layer} cfg{used.value} {ms.value*1e3:.1f} us/launch")
+print(f"{name} {layer} B={B} cfg{used.value} {ms.value*1e3:.1f} us/launch")

@@ -1,8 +1,10 @@
 #!/bin/bash
-# Round-end evidence run (on the GPU box, from the repo root): bench lines (headline + the other BASELINE configs),
-# rocprofv3 kernel stats of the headline command, the two PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) for the conv
-# kernels' memory-side traffic, SQ counters of one deep-level conv layer in isolation, GRU per-step cycle stamps.
-# Everything lands under gpurun_out/final/; tools/collect_profiles.py copies what should be judged into profiles/.
+# Round-end evidence run (on the GPU box, from the repo root): bench lines (headline + the other BASELINE configs), rocprofv3
+# kernel stats of the headline command, PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) for the conv kernels' memory-side
+# traffic of the headline AND the throughput configurations, SQ counters of one deep-level layer (split-K kernel) and one
+# throughput layer (no-split-K kernel) in isolation, GRU per-step cycle stamps, the micro-benchmarks behind the design
+# decisions, the two-ranks-on-one-GPU stress loop.  Everything lands under gpurun_out/final/; tools/collect_profiles.py copies
+# what should be judged into profiles/.
 set -u
 export TMPDIR=/tmp
 O=gpurun_out/final
@@ -10,38 +12,69 @@ mkdir -p $O
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -c 400 $O/bench_default.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- \
-  python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_under_rocprof.json 2> $O/rocprof.err
 python tools/kstats.py $O/prof/bench_kernel_trace.csv | head -16 | tee $O/kstats_PP16_B1.txt
 # the other BASELINE configurations (per-GPU shapes): C3 PP16 64 steps B=4, C4 OR16 32 steps B=16, C5 PP24 varlen B=8
-timeout 900 python bench.py --batch 4 --n_steps 64 --steps 5 --warmup 1 > $O/bench_C3_PP16_n64_b4.json 2>> $O/bench_default.err
-timeout 900 python bench.py --model OR16 --batch 16 --n_steps 32 --steps 5 --warmup 1 > $O/bench_C4_OR16_n32_b16.json 2>> $O/bench_default.err
+timeout 900 python bench.py --batch 4 --n_steps 64 --steps 5 --warmup 1 --batch-sweep "" > $O/bench_C3_PP16_n64_b4.json 2>> $O/bench_default.err
+timeout 900 python bench.py --model OR16 --batch 16 --n_steps 32 --steps 5 --warmup 1 --batch-sweep "" > $O/bench_C4_OR16_n32_b16.json 2>> $O/bench_default.err
 timeout 900 python bench.py --model PP24 --batch 8 --varlen --steps 5 --warmup 1 > $O/bench_C5_PP24_varlen_b8.json 2>> $O/bench_default.err
-timeout 900 python bench.py --batch 8 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_PP16_b8.json 2>> $O/bench_default.err
-timeout 900 python bench.py --batch 4 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_PP16_b4.json 2>> $O/bench_default.err
+timeout 900 python bench.py --batch 8 --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_PP16_b8.json 2>> $O/bench_default.err
+timeout 900 python bench.py --batch 4 --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_PP16_b4.json 2>> $O/bench_default.err
 for f in C3_PP16_n64_b4 C4_OR16_n32_b16 C5_PP24_varlen_b8 PP16_b8 PP16_b4; do tail -c 200 $O/bench_$f.json | head -c 200; echo; done
 for cfgname in "PP16_B8 --batch 8 --steps 2 --warmup 1" "C3 --batch 4 --n_steps 64 --steps 2 --warmup 1" "C4 --model OR16 --batch 16 --n_steps 32 --steps 2 --warmup 1" "C5 --model PP24 --batch 8 --varlen --steps 2 --warmup 1"; do
   set -- $cfgname; name=$1; shift
-  timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/prof_$name -o k -- python bench.py "$@" --no-cpu-baseline --profile-steps 1 > /dev/null 2>> $O/rocprof.err
-  python tools/kstats.py $O/prof_$name/k_kernel_trace.csv | head -10 > $O/kstats_$name.txt
+  timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/prof_$name -o k -- python bench.py "$@" --no-cpu-baseline --profile-steps 1 --batch-sweep "" > /dev/null 2>> $O/rocprof.err
+  python tools/kstats.py $O/prof_$name/k_kernel_trace.csv | head -12 > $O/kstats_$name.txt
+  rm -rf $O/prof_$name
 done
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- \
-    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 > /dev/null 2> $O/pmc_$c.err
+# memory-side traffic per kernel family: headline, batch 8, C5
+for cfgname in "PP16_b1 " "PP16_b8 --batch 8" "PP24_b8_varlen --model PP24 --batch 8 --varlen"; do
+  set -- $cfgname; tag=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${tag}_$c -o p -- \
+      python bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 --batch-sweep "" > /dev/null 2> $O/pmc_${tag}_$c.err
+  done
 done
-# SQ counters (4 per pass) of the 512-channel k3 latent-level conv in isolation (direct kernel)
-L=_edm_model.encoder.ds_modules.4.conv2
-rm -f $O/pmc_sq_latent_conv.txt
+# SQ counters (4 per pass): the 512-channel k3 latent-level conv at batch 1 (split-K kernel) and the 192-channel k3 conv of
+# UNIVERSE++ 24 kHz at batch 8 (no-split-K throughput kernel), each in isolation
+rm -f $O/pmc_sq_latent_conv.txt $O/pmc_sq_direct3_PP24_b8.txt
 for set in "SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/sq -o s -- python tools/conv_one.py $L 401 20 > /dev/null 2>> $O/rocprof.err
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/sq -o s -- python tools/conv_one.py _edm_model.encoder.ds_modules.4.conv2 401 20 > /dev/null 2>> $O/rocprof.err
   python tools/pmc_summary.py $O/sq/s_counter_collection.csv conv_direct >> $O/pmc_sq_latent_conv.txt
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/sq3 -o s -- python tools/conv_one.py _edm_model.encoder.ds_modules.2.conv2 16040 10 PP24 8 > $O/sq3_run.txt 2>> $O/rocprof.err
+  python tools/pmc_summary.py $O/sq3/s_counter_collection.csv conv_direct3 >> $O/pmc_sq_direct3_PP24_b8.txt
 done
-cat $O/pmc_sq_latent_conv.txt
+cat $O/sq3_run.txt >> $O/pmc_sq_direct3_PP24_b8.txt
+cat $O/pmc_sq_latent_conv.txt $O/pmc_sq_direct3_PP24_b8.txt
+rm -rf $O/sq $O/sq3
 timeout 300 python tools/gru_ts.py 2>&1 | grep -v amdgpu.ids > $O/gru_ts.txt; tail -5 $O/gru_ts.txt
+OU_GRU_AGENT_STORES=1 timeout 300 python tools/gru_ts.py 2>&1 | grep -v amdgpu.ids | sed "s/^/agent-scope publishes: /" >> $O/gru_ts.txt
 timeout 300 python tools/direct_ts.py 2>&1 | grep -v amdgpu.ids > $O/direct_ts.txt; tail -8 $O/direct_ts.txt
-timeout 300 python tools/direct_sweep.py PP16 1 2>&1 | grep -v amdgpu.ids > $O/direct_sweep_PP16_B1.txt
-# microbenchmarks behind the design decisions (exchange hand-off latency, dispatch cost, VMEM issue rate)
+for args in "PP24 8" "PP16 8" "PP16 4" "OR16 16"; do set -- $args; timeout 300 python tools/tile_sweep.py $1 $2 2>&1 | grep -v amdgpu.ids > $O/tile_sweep_$1_B$2.txt; done
+# microbenchmarks behind the design decisions
 for u in xchg_latency launch_overhead vmem_issue; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o /tmp/$u 2>> $O/rocprof.err && timeout 150 /tmp/$u > $O/ubench_$u.txt 2>&1
 done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench/xcc_migrate.hip -o /tmp/xcc_migrate 2>> $O/rocprof.err
+echo "--- one process" > $O/xcc_migrate.txt; timeout 60 /tmp/xcc_migrate 200 2 >> $O/xcc_migrate.txt
+echo "--- three processes at once" >> $O/xcc_migrate.txt
+for i in 1 2 3; do timeout 120 /tmp/xcc_migrate 300 6 >> $O/xcc_migrate.txt 2>&1 & done; wait
+# two ranks on ONE GPU, repeated (the arrangement that produced the GRU time-outs of round 2)
+ok=0; bad=0
+for i in $(seq 1 30); do
+  if timeout 120 python bench.py --gpus 2 --share-devices --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 1 --batch-sweep "" > $O/st.out 2> $O/st.err; then ok=$((ok+1)); else bad=$((bad+1)); grep -h RuntimeError $O/st.err | head -2 | cut -c1-700 >> $O/stress_two_ranks.txt; fi
+done
+echo "two ranks on one GPU, bench.py --gpus 2 --share-devices --steps 3: ok=$ok failed=$bad of 30" | tee -a $O/stress_two_ranks.txt
+python - >> $O/stress_two_ranks.txt <<PY
+import json
+d=json.loads([l for l in open("$O/st.out") if l.startswith("{")][-1]); print("last run:", d["ms_per_step"], d["gru_exchange"])
+PY
 OU_TRACE=1 OU_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr -o t -- python tools/gpu_debug.py timing PP16 iters=2 > /dev/null 2> $O/trace.log
 python tools/trace_summary.py $O/tr/t_kernel_trace.csv $O/trace.log > $O/layers_PP16_B1.txt 2>&1
+for cfg in "PP24_B8 PP24 B=8 T=96000 iters=1" "PP16_B8 PP16 B=8 iters=1"; do
+  set -- $cfg; name=$1; shift
+  OU_TRACE=1 OU_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr_$name -o t -- python tools/gpu_debug.py timing "$@" > /dev/null 2> $O/trace_$name.log
+  python tools/trace_summary.py $O/tr_$name/t_kernel_trace.csv $O/trace_$name.log > $O/layers_$name.txt 2>&1
+  rm -rf $O/tr_$name $O/trace_$name.log
+done
+rm -rf $O/tr $O/trace.log
