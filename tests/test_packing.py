@@ -68,17 +68,17 @@ def test_pack_all_convs(built_lib, name):
 
 
 def test_taps_innermost_weight_copy_equals_the_tap_major_one(built_lib):
-    """Stride-1 k3 / k5 layers with Cin % 64 == 0 carry a second copy [Cin][Mp][4 | 8] for conv_direct2_kernel: same
-    numbers as the [Cin/CK][KW][CK][Mp] layout, zero in the padding taps and rows."""
+    """Stride-1 k3 / k5 layers with Cin % 16 == 0 carry a second copy [Cin][Mp][4 | 8] for conv_direct2_kernel (Cin % 64)
+    and conv_direct3_kernel (Cin % 16): same numbers as the [Cin/CK][KW][CK][Mp] layout, zero in the padding taps and rows."""
     spec = get_spec("PP16m")
     sd = S.synthetic_state_dict(spec, seed=5)
     blob, plan = _lib.pack_weights(spec, sd)
     n = 0
     for nm, L in plan_convs(plan).items():
         if not L["KWP"]:
-            assert not (L["stride"] == 1 and L["up"] == 1 and L["KW"] in (3, 5) and L["Cin"] % 64 == 0), nm
+            assert not (L["stride"] == 1 and L["up"] == 1 and L["KW"] in (3, 5) and L["Cin"] % 16 == 0), nm
             continue
-        assert L["KW"] in (3, 5) and L["KWP"] == (4 if L["KW"] == 3 else 8) and L["Cin"] % 64 == 0
+        assert L["KW"] in (3, 5) and L["KWP"] == (4 if L["KW"] == 3 else 8) and L["Cin"] % 16 == 0
         Cin, KW, KWP, Mp, M = L["Cin"], L["KW"], L["KWP"], L["Mp"], L["M"]
         W, _, _ = unpack_conv(blob, L)                                     # [M][Cin][KW]
         wd = blob[L["wd_off"]: L["wd_off"] + Cin * Mp * KWP].view(Cin, Mp, KWP)
