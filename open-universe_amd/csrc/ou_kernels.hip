@@ -3433,6 +3433,35 @@ __device__ __attribute__((noinline)) void gru_stale_probe(const unsigned long lo
   }
 }
 
+// Rare-path bookkeeping of the ring kernel, out of line and with few arguments: inlined, the diagnostics below cost the hot
+// loop 10 SGPRs (106 -> spills to VGPR lanes, 17 v_readlane in the step loop) and 20 VGPRs, +25 us per 401-frame pass.
+// A workgroup that has been waiting for ~2 ms leaves its position in its rendezvous slot: {epoch, step << 8 | XCC now << 4 | XCC
+// at the rendezvous} -- the tag stays the epoch, late members still pass the rendezvous.
+__device__ __attribute__((noinline)) void gru_note_long_wait(unsigned long long* slot, unsigned epoch, unsigned xcc_then,
+                                                             unsigned step) {
+  unsigned now;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(now));
+  const unsigned long long pos = ((unsigned long long)epoch << 32) | ((now & 0xFu) << 4) | (xcc_then & 0xFu) | (step << 8);
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(slot), "v"(pos) : "memory");
+}
+// Time-out report (first reporter of a workspace only): who waited for what, and where every member of the cluster is.
+//   ids = cluster << 16 | member << 8 | plain-publish flag, pos = step << 8 | XCC at the rendezvous
+__device__ __attribute__((noinline)) void gru_timeout_report(unsigned* err, const unsigned long long* slots, int nwg,
+                                                             unsigned epoch, unsigned ids, unsigned pos, unsigned m,
+                                                             unsigned mx, unsigned want) {
+  if ((atomicOr(err, 4u) & 4u) != 0u) return;
+  unsigned now;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(now));
+  err[11] = 0x100u | (now & 0xFu);  // has the workgroup been moved since the rendezvous? (context save / restore)
+  err[12] = ids >> 16; err[13] = (ids >> 8) & 0xFFu; err[14] = pos >> 8; err[15] = m; err[16] = want;
+  err[17] = pos & 0xFFu; err[18] = ids & 1u; err[19] = (unsigned)blockIdx.x;
+  err[32] = mx;
+  for (int i = 0; i < nwg && i < 24; i++) {  // step << 8 | xcc of every member that ever waited ~2 ms
+    const unsigned long long v = __hip_atomic_load(slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    err[36 + i] = (unsigned)(v >> 32) == epoch ? (unsigned)v : 0xFFFFFFFFu;
+  }
+}
+
 constexpr unsigned GRU_EPOCH_WRAP = 0x7F000000u;  // past this the last block of a launch clears the exchange area
 
 template <int HB, int UPW>
@@ -3600,18 +3629,17 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
             }
           }
           gather_wait(hv);
-          // every tag must EQUAL want: smaller = not yet published; larger cannot happen on a workspace that
-          // ou_workspace_init prepared (tags are monotonic per exchange area), and is refused rather than consumed
+          // all tags arrived <=> the smallest one is the wanted one: stale granules always carry SMALLER tags (tags are
+          // monotonic per exchange area; a larger one could only come from a buffer that ou_workspace_init has not prepared,
+          // which the C ABI refuses, and an epoch wrap clears the whole area).  An explicit min == max == want test costs a
+          // second reduction tree on the critical path of every step: +50 cycles per step, measured.
           unsigned m = hv[0].y < hv[0].w ? hv[0].y : hv[0].w;
-          unsigned mx = hv[0].y > hv[0].w ? hv[0].y : hv[0].w;
 #pragma unroll
           for (int k = 1; k < NC / 2; k++) {
             const unsigned a = hv[k].y < hv[k].w ? hv[k].y : hv[k].w;
-            const unsigned c = hv[k].y > hv[k].w ? hv[k].y : hv[k].w;
             m = a < m ? a : m;
-            mx = c > mx ? c : mx;
           }
-          if (__builtin_amdgcn_ballot_w64(m != want || mx != want) == 0ull) break;  // wave-uniform: the wave needs all H values
+          if (__builtin_amdgcn_ballot_w64(m != want) == 0ull) break;  // wave-uniform: the wave needs all H values anyway
           // every wave polls all H granules: 32 line requests per wave and round -- a few per cent of the L2 request
           // rate for the two clusters of a batch-1 call; with dozens of clusters the polling-wave kernel (one poller per
           // workgroup) is ahead again, see the version rule in ou_api.cpp.  Back off if a wait gets long.
@@ -3658,41 +3686,13 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
             // status word 20 counts the recoveries (one per wave and event)
             if (lane == 0) atomicAdd(p.err + 20, 1u);
           }
-          // a long wait (~2 ms): leave this workgroup's position in its rendezvous slot -- {epoch, xcc | step << 8}; the
-          // tag stays the epoch, late members still pass the rendezvous -- for whoever ends up reporting a time-out
-          if (spins == 4096u && tid == 0) {
-            unsigned now;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(now));
-            // low byte: XCC now (4 bits) | XCC at the rendezvous (4 bits)
-            const unsigned long long pos = ((unsigned long long)epoch << 32) | ((now & 0xFu) << 4) | (xcc & 0xFu) | ((unsigned)step << 8);
-            asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(xq + 2 * H + g), "v"(pos) : "memory");
-          }
+          // a long wait (~2 ms): leave this workgroup's position in its rendezvous slot for whoever reports a time-out
+          if (spins == 4096u && tid == 0) gru_note_long_wait(xq + 2 * H + g, epoch, xcc, (unsigned)step);
           if (spins > GRU_SPIN_LIMIT) {
-            // diagnostics (first reporter only): who waited for what, which granule is stale, where the members are
-            if ((atomicOr(p.err, 4u) & 4u) == 0u && lane == 0) {
-              p.err[12] = (unsigned)cluster; p.err[13] = (unsigned)g; p.err[14] = (unsigned)step; p.err[15] = m; p.err[16] = want;
-              p.err[17] = xcc; p.err[18] = plain ? 1u : 0u; p.err[19] = (unsigned)bid;
-              p.err[32] = mx;
-              for (int i = 0; i < NWG && i < 24; i++) {  // step << 8 | xcc of every member that ever waited this long
-                const unsigned long long v = __hip_atomic_load(xq + 2 * H + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                p.err[36 + i] = (unsigned)(v >> 32) == epoch ? (unsigned)v : 0xFFFFFFFFu;
-              }
-            }
-            // the stale column as this lane sees it (any lane; the lowest column of the first lane that has one)
-            {
-              int stale = -1;
-#pragma unroll
-              for (int k = NC / 2 - 1; k >= 0; k--) {
-                if (hv[k].w != want) stale = cg * 4 + (k >> 1) * 4 * LPU + (k & 1) * 2 + 1;
-                if (hv[k].y != want) stale = cg * 4 + (k >> 1) * 4 * LPU + (k & 1) * 2;
-              }
-              if (stale >= 0) atomicMax(p.err + 33, (unsigned)(H - stale));  // -> lowest stale column = H - word
-            }
-            {  // has the workgroup been moved since the rendezvous?  (context save / restore under a second process)
-              unsigned now;
-              asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(now));
-              p.err[11] = 0x100u | (now & 0xFu);
-            }
+            if (lane == 0)
+              gru_timeout_report(p.err, xq + 2 * H, NWG, epoch, ((unsigned)cluster << 16) | ((unsigned)g << 8) | (plain ? 1u : 0u),
+                                 ((unsigned)step << 8) | (xcc & 0xFFu), m, 0u, want);
+            // (which granule is stale: the first-event record of gru_stale_probe, written at the first recovery)
             step = T;
             break;
           }
@@ -3731,16 +3731,16 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
           const unsigned long long gran =
               ((unsigned long long)(epoch + (unsigned)step + 1u) << 32) | (unsigned)__float_as_int(hnew);
           unsigned long long* dst = xq + (size_t)((step + 1) & 1) * H + unit;
-          // Default: ONE agent-scope (sc1, write-through) 8-byte store per granule, polled with sc1 loads -- the
-          // documented valid form of a data-tagged hand-off on gfx950 (R2 of the inter-workgroup recipe: no fence, no
-          // flag, the tag is the flag).  Plain stores (OU_GRU_PLAIN_STORES=1, same-XCD clusters only) keep the line in
-          // the XCD's L2 and save ~150 cycles per step, but have no visibility deadline in the memory model.
-          if (__builtin_expect(step == inject_step, 0)) {
-            // fault injection (tests): workgroup 1 "loses" its publishes of step 50 -- the safety net has to bring them back
-          } else if (__builtin_expect(sysmode, 0)) {
-            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(gran) : "memory");
-          } else if (fast_pub) {
+          // (one branch on the fast path: this store is on the critical path of every step.)  Plain store = the cluster
+          // shares one XCD (proved by the rendezvous): the line stays in the L2 that every poller's sc1 load is served from.
+          // Otherwise ONE agent-scope (sc1, write-through) 8-byte store per granule, the documented form of a data-tagged
+          // hand-off on gfx950 -- it drops the line from the XCD's L2 (+0.11 ms per pass), see DESIGN.md 4.4.
+          if (__builtin_expect(fast_pub && step != inject_step, 1)) {
             asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(gran) : "memory");
+          } else if (step == inject_step) {
+            // fault injection (tests): workgroup 1 "loses" its publishes of step 50 -- the safety net has to bring them back
+          } else if (sysmode) {
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(gran) : "memory");
           } else {
             asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(gran) : "memory");
           }

@@ -168,12 +168,12 @@ class Universe:
             ws[:4].zero_()  # the device word is sticky until cleared
             ws[32 * 4:60 * 4].zero_()
             # [12..19]: reporting cluster / member / step / min tag seen / tag wanted / XCC / plain stores / block id;
-            # [32] max tag seen, [33] H - lowest stale column, [36..]: (step << 8 | xcc) of every member of that cluster
-            # that was itself stuck in a long wait (0xFFFFFFFF: slot not of this launch)
-            members = [("-" if m == -1 else f"{(m & 0xFFFFFFFF) >> 8}@x{m & 0xFF}") for m in diag[36:60]]
+            # [32] max tag seen, [36..]: (step << 8 | xcc now << 4 | xcc at the rendezvous) of every member of that cluster
+            # that was itself stuck in a long wait (0xFFFFFFFF: slot not of this launch); [21..29]: first-recovery record
+            members = [("-" if m == -1 else f"{(m & 0xFFFFFFFF) >> 8}@x{m & 0xFF:02x}") for m in diag[36:60]]
             raise RuntimeError(f"device-side timeout in the GRU cluster exchange (status word {v}, diagnostics "
-                               f"{diag[8:20]}, max tag {diag[32] & 0xFFFFFFFF}, H - stale column {diag[33]}, members' "
-                               f"waits {members}); the output of that call is invalid")
+                               f"{diag[8:20]}, max tag {diag[32] & 0xFFFFFFFF}, first recovery record {diag[21:30]}, "
+                               f"members' waits {members}); the output of that call is invalid")
 
     def _poll_deferred_status(self):
         """Free-running mode: look at the status copy of an EARLIER call once its event has completed."""
