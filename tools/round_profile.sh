@@ -51,6 +51,7 @@ timeout 300 python tools/gru_ts.py 2>&1 | grep -v amdgpu.ids > $O/gru_ts.txt; ta
 OU_GRU_AGENT_STORES=1 timeout 300 python tools/gru_ts.py 2>&1 | grep -v amdgpu.ids | sed "s/^/agent-scope publishes: /" >> $O/gru_ts.txt
 timeout 300 python tools/direct_ts.py 2>&1 | grep -v amdgpu.ids > $O/direct_ts.txt; tail -8 $O/direct_ts.txt
 for args in "PP24 8" "PP16 8" "PP16 4" "OR16 16"; do set -- $args; timeout 300 python tools/tile_sweep.py $1 $2 2>&1 | grep -v amdgpu.ids > $O/tile_sweep_$1_B$2.txt; done
+timeout 300 python tools/sharded_rate.py PP16 32 2>&1 | grep -v amdgpu.ids > $O/sharded_rate.txt; cat $O/sharded_rate.txt
 # microbenchmarks behind the design decisions
 for u in xchg_latency launch_overhead vmem_issue; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o /tmp/$u 2>> $O/rocprof.err && timeout 150 /tmp/$u > $O/ubench_$u.txt 2>&1
