@@ -485,7 +485,9 @@ static size_t conv_smem_bytes(const ConvCfg& c, const ConvArgs& a) {
 }
 
 static hipError_t init_chain_kernels();
+static hipError_t init_direct3_kernels();
 hipError_t init_conv_kernels() {
+  hipError_t e_d3 = hipSuccess;
   for (int i = 0; i < kNumConvCfgs; i++) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kConvCfgs[i].kern4),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -497,6 +499,8 @@ hipError_t init_conv_kernels() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
+  e_d3 = init_direct3_kernels();
+  if (e_d3 != hipSuccess) return e_d3;
   return init_chain_kernels();
 }
 
@@ -1238,7 +1242,7 @@ __global__ __launch_bounds__(512) void conv_direct_strided_kernel(ConvArgs p) {
 //   but different from the split-K kernels (results agree to fp32 rounding).
 // ---------------------------------------------------------------------------------------------------------
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
-template <int KW, int TM, int D>
+template <int KW, int TM, int D, bool PRE>
 __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
   constexpr int TN = 4, W = KW + TN - 1, KWP = KW == 3 ? 4 : 8, PAD = (KW - 1) / 2;
   constexpr int A2 = KW == 5 ? 1 : 0;       // second A load per row tile (tap 4)
@@ -1302,9 +1306,10 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
     else                                                                                                              \
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "+v"(b4b[d]) : "v"(bvo), "s"(rx), "s"(xso)); \
   }
-#define OU_MMA(d, out)                                                                                                \
+#define OU_MMA(d, out) OU_MMAX(d, out, 0)
+#define OU_MMAX(d, out, extra)                                                                                        \
   {                                                                                                                   \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS));                                                           \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS + (extra)));                                                 \
     _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                  \
       asm volatile("" : "+v"(a4[d][i]));                                                                              \
       if constexpr (A2 == 1) asm volatile("" : "+v"(a1[d][i]));                                                       \
@@ -1332,8 +1337,30 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, X[j + k], acc[i][j], 0, 0, 0);                         \
       }                                                                                                               \
   }
-  static_assert(D == 2 || D == 4, "ring depth");
-  if constexpr (D == 4) {
+  static_assert(D == 4, "ring depth");
+  // The epilogue's tensor operand (the residual, or the cond add when there is no residual) is as large as the output: read
+  // after the main loop its 16 KB per tile are pure exposed latency / bandwidth (the `.v` layers ran 5-20 us behind their
+  // residual-free twins).  It is PREFETCHED into a wave-private LDS slab with LDS-DMA -- no registers, LDS is otherwise unused
+  // here -- right before the last four ring slots, i.e. under 4 KW TM 4 = 192-320 MFMAs; every lane fetches exactly the
+  // 4 TM quads it will consume (instruction (i, r): row m0 + 16 i + 4 kk + r, columns c0 .. c0 + 3 -> LDS slab (4 i + r) KB +
+  // 16 lane), so the read-back is conflict-free and needs no barrier.  The DMA loads count in vmcnt like any load: the
+  // counted waits of the drain carry them (NDMA younger loads still in flight).
+  extern __shared__ __attribute__((aligned(16))) float smem3[];
+  constexpr int NDMA = 4 * TM;
+  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+  const size_t ybase = (size_t)b * p.Cout * p.Tout;
+  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+  const int c0 = n0 + TN * l15;
+  int ncol = p.Nq - c0;
+  if (ncol > 4) ncol = 4;
+  const bool vec4 = (p.Tout & 3) == 0 && ncol == 4;
+  // PRE (chosen by the launcher: an operand exists, rows are 16-byte multiples -- then every lane has a whole quad or none --
+  // and the LDS was provided).  A template parameter, not a branch: a branch here would split the control flow while ring
+  // loads are in flight, and the copies the compiler places at the join read registers whose data has not landed.
+  const float* pre = p.res ? p.res : p.add;  // the operand that is prefetched
+  constexpr bool pre_on = PRE;
+  float* const slab = smem3 + wv * (NDMA * 256);
+  {
     OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
     const int NR = NG / 4;
     for (int r = 0; r + 1 < NR; r++) {
@@ -1343,28 +1370,27 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
       OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
       OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
     }
-    OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
-  } else {
-    OU_ISSUE(0, 0); OU_ISSUE(1, 1);
-    const int NR = NG / 2;
-    for (int r = 0; r + 1 < NR; r++) {
-      const int g = r * 2;
-      OU_MMA(0, 1); OU_ISSUE(g + 2, 0);
-      OU_MMA(1, 1); OU_ISSUE(g + 3, 1);
+    if constexpr (PRE) {
+      const __amdgpu_buffer_rsrc_t rp = make_rsrc(pre + ybase, (unsigned)p.Cout * (unsigned)p.Tout * 4u);
+      const int pvo = ncol > 0 ? ((m0 + 4 * kk) * p.Tout + c0) * 4 : (int)0x80000000;
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          dma_b128(rp, slab + (4 * i + r) * 256, pvo, (16 * i + r) * p.Tout * 4);
+      asm volatile("" ::: "memory");
+      OU_MMAX(0, 3, NDMA); OU_MMAX(1, 2, NDMA); OU_MMAX(2, 1, NDMA); OU_MMAX(3, 0, NDMA);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
     }
-    OU_MMA(0, 1); OU_MMA(1, 0);
   }
 #undef OU_ISSUE
 #undef OU_MMA
+#undef OU_MMAX
 
   // ---- epilogue: bias, cond add, FiLM, residual -- straight from the accumulators, 16 bytes per lane and row
-  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
-  const size_t ybase = (size_t)b * p.Cout * p.Tout;
-  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
-  const int c0 = n0 + TN * l15;
-  int ncol = p.Nq - c0;
-  if (ncol > 4) ncol = 4;
-  const bool vec4 = (p.Tout & 3) == 0 && ncol == 4;
   if (ncol > 0) {
 #pragma unroll
     for (int i = 0; i < TM; i++) {
@@ -1380,8 +1406,9 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
         ga[r] = 1.f; be[r] = 0.f;
         if (on && filmb) { ga[r] = filmb[row]; be[r] = filmb[p.Cout + row]; }
         if (on && vec4) {
-          if (p.add) ad[r] = *reinterpret_cast<const f32x4*>(p.add + idx);
-          if (p.res) rs[r] = *reinterpret_cast<const f32x4*>(p.res + idx);
+          const f32x4 pq = pre_on ? *reinterpret_cast<const f32x4*>(slab + (4 * i + r) * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.add) ad[r] = (pre_on && !p.res) ? pq : *reinterpret_cast<const f32x4*>(p.add + idx);
+          if (p.res) rs[r] = pre_on ? pq : *reinterpret_cast<const f32x4*>(p.res + idx);
         } else if (on) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {
@@ -1608,13 +1635,21 @@ __global__ __launch_bounds__(256, 2) void conv_direct3s_kernel(ConvArgs p) {
 
 struct Direct3Cfg {
   int KW, TM, D;
-  void (*kern)(ConvArgs);
+  void (*kern)(ConvArgs);      // no tensor operand in the epilogue (or rows that are not 16-byte multiples)
+  void (*kern_pre)(ConvArgs);  // residual / cond add prefetched into LDS under the last ring slots
 };
-#define OU_D3(KW, TM, D) {KW, TM, D, conv_direct3_kernel<KW, TM, D>}
+#define OU_D3(KW, TM, D) {KW, TM, D, conv_direct3_kernel<KW, TM, D, false>, conv_direct3_kernel<KW, TM, D, true>}
 static const Direct3Cfg kDirect3Cfgs[] = {
     // ring depth 4 only: the depth-2 instantiations come out of the compiler with MORE registers (240-256, spills)
     OU_D3(3, 2, 4), OU_D3(3, 3, 4), OU_D3(3, 4, 4), OU_D3(5, 2, 4), OU_D3(5, 3, 4), OU_D3(5, 4, 4),
 };
+static hipError_t init_direct3_kernels() {
+  for (const Direct3Cfg& c : kDirect3Cfgs) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern_pre), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
 // rows per wave tile (in units of 16) for a layer with M output channels: exact tiling where 16-row granularity allows it
 static int direct3_tm(int M) {
   if (M <= 32) return 2;
@@ -1696,16 +1731,20 @@ static hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t
   const long gy = (a.M + 16 * tm - 1) / (16 * tm), ct = (a.Nq + 63) / 64;
   const double per_simd = (double)gy * ct * a.B / (4.0 * num_cu);
   if (a.force_cfg < 200 && per_simd < tile_min) return hipErrorInvalidConfiguration;
+  // 4 waves x 4 TM KB of LDS for the prefetched epilogue operand (OU_TILE_PREFETCH=0 switches it off)
+  const char* pf = getenv("OU_TILE_PREFETCH");
+  const bool prefetch = (a.res || a.add) && (a.Tout & 3) == 0 && !(pf && atoi(pf) == 0);
   void (*kern)(ConvArgs) = nullptr;
   for (const Direct3Cfg& c : kDirect3Cfgs)
-    if (c.KW == a.KW && c.TM == tm) { kern = c.kern; break; }
+    if (c.KW == a.KW && c.TM == tm) { kern = prefetch ? c.kern_pre : c.kern; break; }
   if (!kern) return hipErrorInvalidConfiguration;
   ConvArgs aa = a;
   aa.grid_m = (int)gy;
   const long chunks = (ct + 3) / 4, total8 = (chunks * a.B + 7) / 8 * 8;
   aa.grid_n = (int)chunks;
   if (cfg_out) *cfg_out = 200 + 10 * tm + a.KW;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(total8 * gy)), dim3(256), 0, stream, aa);
+  const size_t smem = prefetch ? (size_t)4 * 4 * tm * 1024 : 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(total8 * gy)), dim3(256), smem, stream, aa);
   return hipGetLastError();
 }
 
@@ -3788,9 +3827,10 @@ static void (*gru_ring_entry(int upw))(GruArgs, int) {
   return gru_ring_kernel<HB, 16>;
 }
 // Workgroups of the ring kernel that can be resident per CU (every member of a cluster spins on the others: the whole
-// grid has to be on the machine at once).  The occupancy query can be one block high for kernels near an SGPR
-// allocation step (guide: admitted = min(API, 8, 800 / (ceil(sgpr / 16) * 16 + 16))), so one block of margin is taken
-// off and at most two per CU are relied upon.
+// grid has to be on the machine at once).  The occupancy query can be one block high where SGPRs are the limit (guide:
+// admitted = min(API, 8, 800 / (ceil(sgpr / 16) * 16 + 16)): API 8 -> 7 at 81-96 SGPRs, 7 -> 6 at 97-112), which only
+// concerns answers >= 7: one block of margin is taken off those.  These kernels are VGPR-limited (134-180 VGPRs: API 3 / 2),
+// and at most TWO per CU are relied upon (two workgroups = two waves per SIMD, each waiting on its gather most of the time).
 template <int HB>
 static int gru_ring_resident_per_cu(int upw) {
   static int cache[3] = {0, 0, 0};
@@ -3800,7 +3840,8 @@ static int gru_ring_resident_per_cu(int upw) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(gru_ring_entry<HB>(upw)), 256, 0) !=
         hipSuccess)
       nb = 1;
-    cache[slot] = nb >= 3 ? 2 : 1;
+    if (nb >= 7) nb -= 1;
+    cache[slot] = nb >= 2 ? 2 : 1;
   }
   return cache[slot];
 }
