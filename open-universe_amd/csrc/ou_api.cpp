@@ -95,8 +95,31 @@ struct Tensor {
 // Bump allocator over the caller's workspace.  In `dry` mode nothing is launched and `base` may be null:
 // the same walk then only measures the footprint (ou_workspace_bytes) -> layout is a pure function of
 // (config, B, T).
+// Tuning / debug switches, read ONCE per C-ABI call: a forward walks ~400 launches and used to call getenv
+// eight times for each of them (a linear scan of the environment: a third of the host time of an enhance call).
+struct EnvCfg {
+  int dbg = 0, xcd_map = -1, conv_direct = 3, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1;
+  int gru_v = 2, gru_bmax = 0, gru_ts = 0, gru_upw = 0, gru_backoff = 0, gru_agent = -1, gru_dbg = 0;
+  double tile_min = -1.0;  // < 0: the launcher's default
+  int tile_prefetch = 1;
+  std::string chain_ts;
+  static int geti(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
+  EnvCfg() {
+    dbg = geti("OU_DBG", 0); xcd_map = geti("OU_XCD_MAP", -1); conv_direct = geti("OU_CONV_DIRECT", 3);
+    fuse = geti("OU_FUSE", -1); fuse_nc = geti("OU_FUSE_NC", 0); rate_small = geti("OU_RATE_SMALL", 1);
+    fuse_upfir = geti("OU_FUSE_UPFIR", 1);
+    gru_v = geti("OU_GRU_V", 2); gru_bmax = geti("OU_GRU_BMAX", 0); gru_ts = std::getenv("OU_GRU_TS") ? 1 : 0;
+    gru_upw = geti("OU_GRU_UPW", 0); gru_backoff = geti("OU_GRU_BACKOFF", 0); gru_agent = geti("OU_GRU_AGENT_STORES", -1);
+    gru_dbg = geti("OU_GRU_DBG", 0);
+    { const char* e = std::getenv("OU_TILE_MIN"); if (e) tile_min = std::atof(e); }
+    tile_prefetch = geti("OU_TILE_PREFETCH", 1);
+    { const char* e = std::getenv("OU_CHAIN_TS"); if (e) chain_ts = e; }
+  }
+};
+
 struct Runner {
   ou_handle* h;
+  EnvCfg env;
   char* base;
   size_t cap;
   size_t off = 0;
@@ -199,9 +222,8 @@ struct Runner {
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
     a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
-    { const char* d = std::getenv("OU_DBG"); a.dbg = d ? std::atoi(d) : 0; }
-    { const char* d = std::getenv("OU_XCD_MAP"); a.force_xcd_map = d ? std::atoi(d) : -1; }
-    { const char* d = std::getenv("OU_CONV_DIRECT"); a.direct = d ? std::atoi(d) : 3; }
+    a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct;
+    a.tile_min = env.tile_min; a.tile_prefetch = env.tile_prefetch;
     a.tstamps = h->tstamps;
     int cfg = -1;
     if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {
@@ -245,15 +267,13 @@ struct Runner {
   // fused (conv2, conv3).  Pure function of (layer shapes, B, T, device, OU_FUSE*) -- estimated cycles, see
   // chain_cost(); the generic launches are priced at their measured ~45 TFLOP/s with a 12 us floor.
   int plan_chain(const BlockL& Bk, int T) {
-    { const char* f = std::getenv("OU_FUSE"); h->fuse_mode = f ? std::atoi(f) : -1; }
-    { const char* f = std::getenv("OU_FUSE_NC"); h->fuse_nc = f ? std::atoi(f) : 0; }
+    h->fuse_mode = env.fuse; h->fuse_nc = env.fuse_nc;
     if (h->fuse_mode == 0) return 0;
     // Throughput regime: with >= ~2 wave tiles per SIMD the three convs run unfused on conv_direct3_kernel at 70-100 TFLOP/s
     // each, ahead of the fused body's ~75 (measured end to end: PP16 B = 4 19.2 -> 18.4 ms, OR16 B = 16 57.7 -> 55.5 ms, B = 8
     // even); below that the fused launch wins (B = 1: 24 us for all three convs).
     if (h->fuse_mode < 0 && Bk.C % 16 == 0 && Bk.c1.KWP && Bk.c2.KWP && Bk.c3.KWP) {
-      const char* d = std::getenv("OU_CONV_DIRECT");
-      if ((!d || std::atoi(d) >= 3) && direct3_tiles_per_simd(Bk.C, T, B, h->num_cu) >= 1.9 && T >= 1024) return 0;
+      if (env.conv_direct >= 3 && direct3_tiles_per_simd(Bk.C, T, B, h->num_cu) >= 1.9 && T >= 1024) return 0;
     }
     auto shape = [&](int depth) {
       ChainArgs ca;
@@ -293,12 +313,11 @@ struct Runner {
     Tensor hu = hin;
     bool small_up = false;
     if (Bk.dir == 2 && (Bk.rc.fir_mode == 0 || Bk.rc.fir_mode == 2)) {  // pure function of the layer shape
-      const char* senv = std::getenv("OU_RATE_SMALL");
       ConvArgs probe;
       probe.up = Bk.rc.up; probe.stride = Bk.rc.stride; probe.KW = Bk.rc.KW; probe.pad = Bk.rc.pad; probe.Tin = hin.T;
       probe.Nq = hin.T; probe.Tout = hin.T * Bk.rc.up; probe.M = Bk.rc.M; probe.Cout = Bk.rc.Cout; probe.Cin = Bk.rc.Cin;
       probe.fir = Bk.rc.fir_mode == 2 ? h->W : nullptr; probe.fir_len = Bk.rc.fir_len;
-      small_up = (!senv || std::atoi(senv) != 0) && rate_up_supported(probe);
+      small_up = env.rate_small != 0 && rate_up_supported(probe);
     }
     if (small_up) {
       Epi e;
@@ -313,8 +332,7 @@ struct Runner {
         Tensor u = alloc(nm + ".upc", Bk.rc.Cout, hin.T * Bk.rc.up);
         hu = alloc(nm + ".up", u.C, u.T);
         if (!dry && ok()) {
-          const char* fenv = std::getenv("OU_FUSE_UPFIR");
-          const bool fuse = fenv ? std::atoi(fenv) != 0 : true;
+          const bool fuse = env.fuse_upfir != 0;
           bool done = false;
           if (fuse) {
             Epi e;
@@ -365,7 +383,7 @@ struct Runner {
           ca.cv[0] = chain_conv(Bk.c2); ca.cv[1] = chain_conv(Bk.c3);
         }
         ca.force_nc = h->fuse_nc;
-        { const char* f = std::getenv("OU_CHAIN_TS"); if (f && nm == f) ca.tstamps = (long long*)(base + cap - (16u << 20)); }
+        if (!env.chain_ts.empty() && nm == env.chain_ts) ca.tstamps = (long long*)(base + cap - (16u << 20));
         int variant = -1;
         if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {
           ou_handle::ProfRec rec;
@@ -402,12 +420,11 @@ struct Runner {
     if (Bk.dir == 1) {  // blocks.py:401-410
       bool small = false;
       if (Bk.rc.fir_mode <= 1) {  // wide levels: FIR + strided conv in one launch (pure function of the layer shape)
-        const char* senv = std::getenv("OU_RATE_SMALL");
-        ConvArgs probe;
+          ConvArgs probe;
         probe.up = Bk.rc.up; probe.stride = Bk.rc.stride; probe.KW = Bk.rc.KW; probe.pad = Bk.rc.pad; probe.Tin = v.T;
         probe.Nq = v.T / Bk.rc.stride; probe.M = Bk.rc.M; probe.Cin = Bk.rc.Cin;
         probe.fir = Bk.rc.fir_mode == 1 ? h->W : nullptr; probe.fir_len = Bk.rc.fir_len;
-        small = (!senv || std::atoi(senv) != 0) && rate_down_supported(probe);
+        small = env.rate_small != 0 && rate_down_supported(probe);
       }
       if (small) {
         Epi e;
@@ -443,23 +460,17 @@ struct Runner {
     // kernel generation: the ring kernel (every wave gathers h straight from L2, no polling wave, no workgroup barrier)
     // for every batch size -- its publishes are agent-scope (sc1) stores by default, the documented form of the hand-off;
     // OU_GRU_V=1 selects the polling-wave kernel of round 1.
-    {
-      const char* f = std::getenv("OU_GRU_V");
-      a.version = f ? std::atoi(f) : 2;
-    }
+    a.version = env.gru_v;
     a.shared = gru_shared ? 1 : 0;
-    { const char* f = std::getenv("OU_GRU_BMAX"); a.force_bmax = f ? std::atoi(f) : 0; }
-    if (std::getenv("OU_GRU_TS")) a.tstamps = (long long*)(base + cap - (1u << 20));
-    { const char* f = std::getenv("OU_GRU_UPW"); a.force_upw = f ? std::atoi(f) : 0; }
-    { const char* f = std::getenv("OU_GRU_BACKOFF"); a.poll_backoff = f ? std::atoi(f) : 0; }
+    a.force_bmax = env.gru_bmax;
+    if (env.gru_ts) a.tstamps = (long long*)(base + cap - (1u << 20));
+    a.force_upw = env.gru_upw;
+    a.poll_backoff = env.gru_backoff;
     // publishes: plain stores inside a cluster that shares one XCD (the L2 is that XCD's point of coherence; the
     // rendezvous proves the placement), agent-scope (sc1) stores otherwise or on request -- ou_set_gru_publish_mode(), which
     // the host wrapper calls for good the first time the safety net of the kernel had to repeat a publish
-    {
-      const char* f = std::getenv("OU_GRU_AGENT_STORES");
-      a.agent_stores = f ? (std::atoi(f) != 0) : h->gru_agent_stores;
-    }
-    { const char* f = std::getenv("OU_GRU_DBG"); a.dbg = f ? std::atoi(f) : 0; }
+    a.agent_stores = env.gru_agent >= 0 ? (env.gru_agent != 0) : h->gru_agent_stores;
+    a.dbg = env.gru_dbg;
     chk(launch_gru(a, h->num_cu, st), G.name.c_str());
     return out;
   }

@@ -34,6 +34,8 @@ struct ConvArgs {
   int xcd_map = 0;                     // filled by launch_conv: block -> tile mapping (see the kernel)
   int force_cfg = -1, force_sc = 0;    // tuning overrides (ou_bench_conv)
   int force_xcd_map = -1;              // tuning: 0 / 1 / 2
+  double tile_min = -1.0;              // OU_TILE_MIN (< 0: the launcher's default of 1.2 wave tiles per SIMD)
+  int tile_prefetch = 1;               // OU_TILE_PREFETCH: LDS prefetch of the epilogue operand in conv_direct3_kernel
   int direct = 3;                      // OU_CONV_DIRECT: 0 = never use the register-direct kernels, 1 = only the first
                                        // generation (dword loads), 2 = + wide-load split-K variant where a layer has `wd`,
                                        // 3 = + the no-split-K throughput kernel (conv_direct3_kernel) for many-column launches

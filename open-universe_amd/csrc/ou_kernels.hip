@@ -1696,8 +1696,7 @@ static hipError_t launch_conv_direct3s(const ConvArgs& a, int num_cu, hipStream_
   return hipGetLastError();
 }
 static hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
-  double tile_min_s = 1.2;
-  { const char* e = getenv("OU_TILE_MIN"); if (e) tile_min_s = atof(e); }
+  const double tile_min_s = a.tile_min >= 0 ? a.tile_min : 1.2;
   if (a.KW == 1 || a.stride > 1) {
     if (tile_min_s > 0 && a.Nq < 1024 && a.force_cfg < 200) return hipErrorInvalidConfiguration;
     // (with the up-path FIR requested as a fused epilogue: refuse, so that the caller runs conv + FIR pass -- unless the layer
@@ -1720,8 +1719,7 @@ static hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t
   if ((long)a.Cin * a.Tin * 4 >= (1L << 31) || (long)a.Cin * a.Mp * 8 * 4 >= (1L << 31)) return hipErrorInvalidConfiguration;
   // wave tiles per SIMD below which the split-K kernels are ahead (measured, PP16 / PP24 at B = 1 .. 16: break-even at
   // ~1 tile per SIMD, +8 .. +60 % from 1.5 up, 2-3x slower at 0.25; OU_TILE_MIN: tuning / tests, 0 = wherever it fits)
-  double tile_min = 1.2;
-  { const char* e = getenv("OU_TILE_MIN"); if (e) tile_min = atof(e); }
+  const double tile_min = a.tile_min >= 0 ? a.tile_min : 1.2;
   // short signals (the T / 160 level: 401 frames = 6.3 column tiles per element) waste the last tile and supply few
   // chunks; the split-K kernels keep them whatever the batch (B = 8: 54 vs 107 us on the latent k3 convs)
   if (tile_min > 0 && a.Nq < 1024 && a.force_cfg < 200) return hipErrorInvalidConfiguration;
@@ -1732,8 +1730,7 @@ static hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t
   const double per_simd = (double)gy * ct * a.B / (4.0 * num_cu);
   if (a.force_cfg < 200 && per_simd < tile_min) return hipErrorInvalidConfiguration;
   // 4 waves x 4 TM KB of LDS for the prefetched epilogue operand (OU_TILE_PREFETCH=0 switches it off)
-  const char* pf = getenv("OU_TILE_PREFETCH");
-  const bool prefetch = (a.res || a.add) && (a.Tout & 3) == 0 && !(pf && atoi(pf) == 0);
+  const bool prefetch = (a.res || a.add) && (a.Tout & 3) == 0 && a.tile_prefetch != 0;
   void (*kern)(ConvArgs) = nullptr;
   for (const Direct3Cfg& c : kDirect3Cfgs)
     if (c.KW == a.KW && c.TM == tm) { kern = prefetch ? c.kern_pre : c.kern; break; }
