@@ -464,7 +464,8 @@ def main():
                                  "algorithmic_gflop_per_enhance": allconv["algorithmic_gflop_per_enhance"]},
             "score_forward": score_forward,
             "method": f"device-side per-launch timing (first block start .. last block end on the 100 MHz s_memrealtime clock) of every conv launch, profiled pass of {args.profile_steps} "
-                      "enhance calls right after the timed region; algorithmic FLOPs/bytes = reference (un-folded) "
+                      "enhance calls right after the timed region, run as ONE serial chain (no side streams inside the call: a "
+                      "launch's own duration cannot be measured beside kernels of another stream); algorithmic FLOPs/bytes = reference (un-folded) "
                       "layer-granular accounting, SURVEY.md 8(d)",
         }
 

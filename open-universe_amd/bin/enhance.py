@@ -180,20 +180,23 @@ def main(argv=None, model=None):
             done.append(output_path)
         return done
 
-    # --batch-size: files are decoded once up front (their rate / length decide the grouping), enhanced group by group
+    # --batch-size: files are read in processing order and held only until their group is complete (consecutive files of
+    # equal rate and length, any length with --pad-batch, at most batch_size of them)
     if any(enhance_kwargs.get(key) is not None for key in ("ensemble", "target")):
         raise ValueError("--batch-size cannot be combined with --ensemble (one call per file needed)")
-    loaded = {k: load(path) for k, path in todo}
-    infos = {k: (fs, int(a.shape[-1])) for k, (a, fs) in loaded.items()}
     kw = {key: v for key, v in enhance_kwargs.items() if key not in ("rng", "ensemble", "ensemble_stat", "target",
                                                                     "fake_score_snr")}
-    for group in group_files(todo, infos, args.batch_size, args.pad_batch):
-        fs = infos[group[0][0]][0]
+
+    def flush(group):
+        """group: list of (k, path, audio, fs) with one fs"""
+        if not group:
+            return
+        fs = group[0][3]
         with torch.no_grad():
-            sigs = [resample(loaded[k][0].to(device), fs, model.fs) for k, _ in group]
+            sigs = [resample(a.to(device), fs, model.fs) for _, _, a, _ in group]
             if per_file_seed:
                 rngs = []
-                for k, _ in group:
+                for k, _, _, _ in group:
                     g = torch.Generator(device=device)
                     g.manual_seed(args.seed + k)
                     rngs.append(g)
@@ -201,11 +204,21 @@ def main(argv=None, model=None):
                 rngs = rng  # one shared generator, drawn from file by file in processing order
             enhs = model.enhance_many(sigs, rngs, pad_batch=args.pad_batch, **kw)
             enhs = [resample(e, model.fs, fs) for e in enhs]
-        for (k, path), enh in zip(group, enhs):
+        for (k, path, _, _), enh in zip(group, enhs):
             output_path = out_path(path)
             save(output_path, enh.cpu(), fs)
             done.append(output_path)
-            loaded.pop(k, None)
+
+    group = []
+    for k, path in todo:
+        audio, fs = load(path)
+        if group:
+            same = fs == group[0][3] and (args.pad_batch or audio.shape[-1] == group[0][2].shape[-1])
+            if not same or len(group) >= args.batch_size:
+                flush(group)
+                group = []
+        group.append((k, path, audio, fs))
+    flush(group)
     return done
 
 

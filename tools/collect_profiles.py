@@ -16,7 +16,7 @@ for n in sorted(os.listdir(src)):
         open(os.path.join(dst, f"{tag}_{n}"), "w").write(lines[-1] + "\n")
 for n in sorted(os.listdir(src)):
     if n.startswith(("kstats_", "pmc_sq_", "gru_ts", "layers", "direct_ts", "direct_sweep", "ubench_", "tile_sweep", "stress_",
-                     "xcc_migrate", "timings", "sharded_rate")):
+                     "xcc_migrate", "timings", "sharded_rate", "box_health")):
         shutil.copy(os.path.join(src, n), os.path.join(dst, f"{tag}_{n}"))
 
 FAMS = {"direct2": ("conv_direct2_kernel",), "direct": ("conv_direct_kernel", "conv_direct_strided_kernel"),

@@ -9,6 +9,7 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out/final
 mkdir -p $O
+timeout 120 python tools/box_health.py 2>&1 | grep "box health" | tee $O/box_health.txt
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -c 400 $O/bench_default.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- \
