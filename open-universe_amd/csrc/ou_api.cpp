@@ -102,8 +102,6 @@ struct EnvCfg {
   int gru_v = 2, gru_bmax = 0, gru_ts = 0, gru_upw = 0, gru_backoff = 0, gru_agent = -1, gru_dbg = 0;
   double tile_min = -1.0;  // < 0: the launcher's default
   int tile_prefetch = 1;
-  int chain3 = 1;            // OU_CHAIN3: 0 never, 1 where it pays (default), 2 wherever the shape allows
-  double chain3_min = 0.9;   // OU_CHAIN3_MIN: 60-column wave tiles per SIMD from which conv_chain3_kernel takes a ConvBlock body
   std::string chain_ts;
   static int geti(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
   EnvCfg() {
@@ -115,8 +113,6 @@ struct EnvCfg {
     gru_dbg = geti("OU_GRU_DBG", 0);
     { const char* e = std::getenv("OU_TILE_MIN"); if (e) tile_min = std::atof(e); }
     tile_prefetch = geti("OU_TILE_PREFETCH", 1);
-    chain3 = geti("OU_CHAIN3", 1);
-    { const char* e = std::getenv("OU_CHAIN3_MIN"); if (e) chain3_min = std::atof(e); }
     { const char* e = std::getenv("OU_CHAIN_TS"); if (e) chain_ts = e; }
   }
 };
@@ -368,47 +364,12 @@ struct Runner {
     auto chain_conv = [&](const ConvL& L) {
       ChainConv c;
       c.w = W(L.w_off); c.bias = W(L.b_off); c.alpha = h->alphas[L.a_off]; c.KW = L.KW; c.CK = L.CK;
-      c.wd = L.KWP ? W(L.wd_off) : nullptr;
       return c;
     };
-    // wide, shallow levels: the body runs as one fused launch (per-wave conv_chain3_kernel where there are enough 60-column
-    // tiles, else the LDS-tiled conv_chain_kernel), or conv1 + a fused (conv2, conv3), or three launches
-    bool use3 = false;
-    ChainArgs c3;
-    if (!dry && ok() && env.chain3 != 0 && (env.fuse < 0 || env.chain3 >= 2) && Bk.c1.act && Bk.c2.act && Bk.c3.act &&
-        Bk.c1.pad == 2 && Bk.c2.pad == 1 && Bk.c3.pad == 1 && Bk.c1.stride == 1 && Bk.c1.up == 1) {
-      c3.depth = 3; c3.B = B; c3.C = Bk.C; c3.T = hu.T; c3.Mp = Bk.c1.Mp;
-      c3.x = hu.p; c3.y = v.p; c3.res = hu.p; c3.res_scale = kInvSqrt2;
-      c3.add = e1.add; c3.add_scale = e1.add_scale; c3.film = e1.film; c3.film_bstride = e1.film_bstride;
-      c3.c1_out = need_c1 ? c1.p : nullptr;
-      c3.cv[0] = chain_conv(Bk.c1); c3.cv[1] = chain_conv(Bk.c2); c3.cv[2] = chain_conv(Bk.c3);
-      use3 = Bk.c1.Cin == Bk.C && Bk.c1.Cout == Bk.C && Bk.c2.Mp == Bk.c1.Mp && Bk.c3.Mp == Bk.c1.Mp && chain3_supported(c3) &&
-             (env.chain3 >= 2 || chain3_tiles_per_simd(c3, h->num_cu) >= env.chain3_min);
-    }
-    const int depth = (dry || use3) ? 0 : plan_chain(Bk, hu.T);
+    // wide, shallow levels: the body runs as one fused launch (conv_chain_kernel), or conv1 + a fused (conv2, conv3)
+    const int depth = dry ? 0 : plan_chain(Bk, hu.T);
 
-    if (use3) {
-      int variant = -1;
-      if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {
-        ou_handle::ProfRec rec;
-        rec.flops = 0;
-        double wbytes = 0;
-        for (int s2 = 0; s2 < 3; s2++) {
-          rec.flops += 2.0 * Bk.C * (double)hu.T * Bk.C * c3.cv[s2].KW * B;
-          wbytes += 4.0 * Bk.C * Bk.C * c3.cv[s2].KW;
-        }
-        rec.bytes = 4.0 * B * (double)Bk.C * hu.T * (2 + (c3.add ? 1 : 0)) + wbytes;
-        rec.cfg = -1;
-        c3.prof = h->prof_dev + 32 * h->prof_used;
-        h->prof.push_back(rec);
-        h->prof_used++;
-      }
-      chk(launch_chain3(c3, h->num_cu, st, &variant), nm.c_str());
-      if (c3.prof) h->prof.back().cfg = variant;
-      if (h->trace)
-        std::fprintf(stderr, "OU_TRACE chain %-63s variant=%d depth=3 C=%d T=%d B=%d\n", nm.c_str(), variant, Bk.C, hu.T, B);
-      h->n_conv++;
-    } else if (depth == 3 || depth == 2) {
+    if (depth == 3 || depth == 2) {
       if (depth == 2) conv(Bk.c1, hu, nm + ".c1", e1, &c1);
       if (ok()) {
         ChainArgs ca;

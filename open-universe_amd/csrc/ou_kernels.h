@@ -136,7 +136,6 @@ hipError_t launch_sum(const float* a, const float* b, const float* c, const floa
 // 'same' convs chained through LDS-resident activation tiles, see conv_chain_kernel.
 struct ChainConv {
   const float* w = nullptr;     // packed generic-conv weights [C/CK][KW][CK][Mp]
-  const float* wd = nullptr;    // taps-innermost copy [C][Mp][4 | 8] (conv_chain3_kernel) or null
   const float* bias = nullptr;  // [C]
   float alpha = 0.f;            // PReLU slope applied to this conv's INPUT
   int KW = 3, CK = 32;
@@ -161,10 +160,6 @@ struct ChainArgs {
 // Shape check + cost estimate (in cycles) of the best variant; <0 when the shape is not supported.
 double chain_cost(const ChainArgs& a, int num_cu, int* nc_out);
 hipError_t launch_chain(const ChainArgs& a, int num_cu, hipStream_t st, int* variant);
-// Per-wave fused ConvBlock body (conv_chain3_kernel): k5 + k3 + k3 at C = 32 / 48 / 64, no barriers, 60 output columns per wave
-bool chain3_supported(const ChainArgs& a);
-double chain3_tiles_per_simd(const ChainArgs& a, int num_cu);
-hipError_t launch_chain3(const ChainArgs& a, int num_cu, hipStream_t st, int* variant);
 
 struct GruArgs {
   const float* gx = nullptr;

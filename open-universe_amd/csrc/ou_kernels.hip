@@ -486,7 +486,6 @@ static size_t conv_smem_bytes(const ConvCfg& c, const ConvArgs& a) {
 
 static hipError_t init_chain_kernels();
 static hipError_t init_direct3_kernels();
-static hipError_t init_chain3_kernels();
 hipError_t init_conv_kernels() {
   hipError_t e_d3 = hipSuccess;
   for (int i = 0; i < kNumConvCfgs; i++) {
@@ -501,8 +500,6 @@ hipError_t init_conv_kernels() {
     if (e != hipSuccess) return e;
   }
   e_d3 = init_direct3_kernels();
-  if (e_d3 != hipSuccess) return e_d3;
-  e_d3 = init_chain3_kernels();
   if (e_d3 != hipSuccess) return e_d3;
   return init_chain_kernels();
 }
@@ -1665,270 +1662,6 @@ double direct3_tiles_per_simd(int M, int Nq, int B, int num_cu) {
   const int tm = direct3_tm(M);
   return (double)((M + 16 * tm - 1) / (16 * tm)) * ((Nq + 63) / 64) * B / (4.0 * num_cu);
 }
-// ---------------------------------------------------------------------------------------------------------
-// conv_chain3_kernel<TM>: the ConvBlock body (blocks.py:377-399) of the wide levels, C = 16 TM = 32 / 48 / 64 channels,
-//     conv1 (k5) -> (+cond)/sqrt2 -> FiLM -> conv2 (k3) -> conv3 (k3) -> (+x)/sqrt2
-// fused PER WAVE in the scheme of conv_direct3_kernel: one wave owns ALL C output channels of a 64-column tile through the
-// three convs -- no workgroup barrier, no cross-wave traffic.  Between two convs the tile changes from the MFMA's D layout
-// (lane = column, registers = channels) to the B layout (lane = (column, channel)) through a wave-private LDS slab
-// S[C][68] (next conv's PReLU applied on the way in, out-of-signal columns zeroed: 'same' padding sees zeros there, not a
-// conv evaluated on zero-extended input); the next conv reads its 6-sample windows from there with aligned 16 + 8-byte LDS
-// loads, its weights stream from L2 through the register ring.  Each conv shrinks the valid range by its halo: local columns
-// [0, 64) of conv1 -> [1, 63) of conv2 -> [2, 62) of conv3, so a tile delivers 60 output columns (6.7 % recompute) and tiles
-// advance by 60.  HBM traffic of the whole body: input once (+ the cond add), output once -- the three separate launches
-// moved the (B, C, T) tensor five more times, which at C = 32 made each of them HBM-bound.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int CH3_LD = 68;  // slab row length in floats (64 columns + one either side, padded to 16 bytes)
-template <int TM>
-__global__ __launch_bounds__(256, 2) void conv_chain3_kernel(ChainArgs p) {
-  constexpr int TN = 4, D = 4, C = 16 * TM;
-  constexpr int LPS1 = 2 * TM + 2;  // conv1 (k5): TM x (dwordx4 + dword) weights + 2 x dwordx4 window
-  constexpr int LPS2 = TM;          // conv2 / conv3 (k3): TM x dwordx4 weights (windows come from LDS)
-  static_assert(D * LPS1 <= 60, "loads in flight must fit vmcnt");
-  extern __shared__ __attribute__((aligned(16))) float smem_c3[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = blockIdx.x, cidx = (L >> 3) * 8 + (L & 7);
-  const int chunks = (p.T + 239) / 240;  // 4 tiles of 60 columns per block
-  const int b = cidx / chunks, chunk = cidx - b * chunks;
-  const int tile = chunk * 4 + wv;
-  if (b >= p.B || tile * 60 >= p.T) return;  // (whole waves: nothing in this kernel synchronises across waves)
-  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
-  const int l15 = lane & 15, kk = lane >> 4;
-  const int T = p.T, Mp = p.Mp;
-  const int g0 = tile * 60 - 2;  // signal column of local column 0
-  float* const S = smem_c3 + wv * (C * CH3_LD);
-  const size_t xbase = (size_t)b * C * T;
-
-  f32x4acc acc[TM][TN];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-      for (int j = 0; j < TN; j++) acc[i][j] = f32x4acc{0.f, 0.f, 0.f, 0.f};
-  };
-
-  // ================= conv1 (k5, pad 2): operands straight from global memory, as conv_direct3_kernel<5, TM> ================
-  {
-    // descriptor shifted 4 floats to the left (the 16 bytes in front of a workspace tensor are workspace too): the first tile's
-    // windows start up to 4 samples before the row, and a NEGATIVE buffer offset would read as all-zero, valid samples included
-    const u32x4 rx = direct_desc(p.x + xbase - 4, (unsigned)C * (unsigned)T * 4u + 16u);
-    const u32x4 rw = direct_desc(p.cv[0].wd, (unsigned)C * (unsigned)Mp * 8u * 4u);
-    const float alpha = p.cv[0].alpha;
-    const int avo = (kk * Mp + l15) * 8 * 4;
-    const int t0 = g0 + TN * l15 - 2;            // first sample of this lane's 8-sample window (>= -4)
-    const int bvo = (kk * T + t0 + 4) * 4;
-    const bool edge = __builtin_amdgcn_readfirstlane((g0 < 2 || g0 + 66 > T) ? 1 : 0) != 0;
-    unsigned vmask = 0;
-#pragma unroll
-    for (int e = 0; e < 8; e++) vmask |= (t0 + e >= 0 && t0 + e < T) ? (1u << e) : 0u;
-    f32x4 a4[D][TM], b4[D], b4b[D];
-    float a1[D][TM];
-#pragma unroll
-    for (int d0 = 0; d0 < D; d0++) {
-#pragma unroll
-      for (int i = 0; i < TM; i++) { a4[d0][i] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[d0][i] = 0.f; }
-      b4[d0] = f32x4{0.f, 0.f, 0.f, 0.f}; b4b[d0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    zero_acc();
-#define OU_ISSUE(g_, d)                                                                                               \
-  {                                                                                                                   \
-    const int aso = (g_) * 4 * Mp * 8 * 4, xso = (g_) * 4 * T * 4;                                                    \
-    _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                  \
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"                                               \
-                   : "+v"(a4[d][i]) : "v"(avo), "s"(rw), "s"(aso), "n"(i * 16 * 8 * 4));                              \
-      asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4"                                                 \
-                   : "+v"(a1[d][i]) : "v"(avo), "s"(rw), "s"(aso), "n"(i * 16 * 8 * 4 + 16));                         \
-    }                                                                                                                 \
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(b4[d]) : "v"(bvo), "s"(rx), "s"(xso));             \
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "+v"(b4b[d]) : "v"(bvo), "s"(rx), "s"(xso));  \
-  }
-#define OU_MMA(d, out)                                                                                                \
-  {                                                                                                                   \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS1));                                                          \
-    _Pragma("unroll") for (int i = 0; i < TM; i++) { asm volatile("" : "+v"(a4[d][i])); asm volatile("" : "+v"(a1[d][i])); } \
-    asm volatile("" : "+v"(b4[d]));                                                                                   \
-    asm volatile("" : "+v"(b4b[d]));                                                                                  \
-    float X[8] = {b4[d].x, b4[d].y, b4[d].z, b4[d].w, b4b[d].x, b4b[d].y, b4b[d].z, b4b[d].w};                        \
-    if (edge) {                                                                                                       \
-      _Pragma("unroll") for (int e = 0; e < 8; e++) X[e] = ((vmask >> e) & 1u) ? X[e] : 0.f;                          \
-    }                                                                                                                 \
-    _Pragma("unroll") for (int e = 0; e < 8; e++) X[e] = X[e] >= 0.f ? X[e] : alpha * X[e];                           \
-    _Pragma("unroll") for (int k = 0; k < 5; k++)                                                                     \
-      _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                \
-        const float av = k == 0 ? a4[d][i].x : (k == 1 ? a4[d][i].y : (k == 2 ? a4[d][i].z : (k == 3 ? a4[d][i].w : a1[d][i]))); \
-        _Pragma("unroll") for (int j = 0; j < TN; j++)                                                                \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, X[j + k], acc[i][j], 0, 0, 0);                         \
-      }                                                                                                               \
-  }
-    OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
-    const int NR = (C / 4) / 4;
-    for (int r = 0; r + 1 < NR; r++) {
-      const int g = r * 4;
-      OU_MMA(0, 3); OU_ISSUE(g + 4, 0);
-      OU_MMA(1, 3); OU_ISSUE(g + 5, 1);
-      OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
-      OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
-    }
-    OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
-#undef OU_ISSUE
-#undef OU_MMA
-  }
-
-  // D layout -> slab: value (i, j, r) = channel 16 i + 4 kk + r, local column 4 l15 + j, stored at S[ch][1 + col]
-  const int gc0 = g0 + TN * l15;  // signal column of this lane's first local column
-  {  // epilogue of conv1: bias, (+cond) * scale, FiLM; keep the raw result if a caller wants it; next conv's PReLU
-    const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
-    const float a2 = p.cv[1].alpha;
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int ch = 16 * i + 4 * kk + r;
-        const float bi = p.cv[0].bias[ch];
-        const float ga = filmb ? filmb[ch] : 1.f, be = filmb ? filmb[C + ch] : 0.f;
-        const size_t row = xbase + (size_t)ch * T;
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-          const int gc = gc0 + j;
-          const bool in = gc >= 0 && gc < T;
-          float v = acc[i][j][r] + bi;
-          if (p.add) v = (v + (in ? p.add[row + gc] : 0.f)) * p.add_scale;
-          if (filmb) v = ga * v + be;
-          const int lc = TN * l15 + j;
-          if (p.c1_out && in && lc >= 2 && lc < 62) p.c1_out[row + gc] = v;
-          v = in ? v : 0.f;
-          S[ch * CH3_LD + 1 + lc] = v >= 0.f ? v : a2 * v;
-        }
-        if (l15 == 0) S[ch * CH3_LD] = 0.f;
-        if (l15 == 15) { S[ch * CH3_LD + 65] = 0.f; S[ch * CH3_LD + 66] = 0.f; S[ch * CH3_LD + 67] = 0.f; }
-        asm volatile("" ::: "memory");  // one row at a time: hoisting all 16 TM rows' loads spills the accumulators
-      }
-  }
-
-  // ================= conv2, conv3 (k3, pad 1): weights through the register ring, windows from the slab ================
-#pragma unroll  // (both stages as straight-line code: as a rolled loop the register ring of the stage is allocated beside
-                // conv1's instead of over it: 256 VGPRs and up to 94 spills)
-  for (int stage = 1; stage <= 2; stage++) {
-    const u32x4 rw = direct_desc(p.cv[stage].wd, (unsigned)C * (unsigned)Mp * 4u * 4u);
-    const int avo = (kk * Mp + l15) * 4 * 4;
-    f32x4 a4[D][TM];
-#pragma unroll
-    for (int d0 = 0; d0 < D; d0++)
-#pragma unroll
-      for (int i = 0; i < TM; i++) a4[d0][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    zero_acc();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is written (same wave: program order is enough)
-    const float* Sw = S + kk * CH3_LD + TN * l15;        // this lane's window: S[4 J + kk][4 l15 .. 4 l15 + 5]
-#define OU_ISSUE(g_, d)                                                                                               \
-  {                                                                                                                   \
-    const int aso = (g_) * 4 * Mp * 4 * 4;                                                                            \
-    _Pragma("unroll") for (int i = 0; i < TM; i++)                                                                    \
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"                                               \
-                   : "+v"(a4[d][i]) : "v"(avo), "s"(rw), "s"(aso), "n"(i * 16 * 4 * 4));                              \
-  }
-#define OU_MMA(g_, d, out)                                                                                            \
-  {                                                                                                                   \
-    const f32x4 w4 = *reinterpret_cast<const f32x4*>(Sw + (g_) * 4 * CH3_LD);                                         \
-    const f32x2 w2 = *reinterpret_cast<const f32x2*>(Sw + (g_) * 4 * CH3_LD + 4);                                     \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS2));                                                          \
-    _Pragma("unroll") for (int i = 0; i < TM; i++) asm volatile("" : "+v"(a4[d][i]));                                 \
-    const float X[6] = {w4.x, w4.y, w4.z, w4.w, w2.x, w2.y};                                                          \
-    _Pragma("unroll") for (int k = 0; k < 3; k++)                                                                     \
-      _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                \
-        const float av = k == 0 ? a4[d][i].x : (k == 1 ? a4[d][i].y : a4[d][i].z);                                    \
-        _Pragma("unroll") for (int j = 0; j < TN; j++)                                                                \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, X[j + k], acc[i][j], 0, 0, 0);                         \
-      }                                                                                                               \
-  }
-    OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
-    const int NR = (C / 4) / 4;
-    for (int r = 0; r + 1 < NR; r++) {
-      const int g = r * 4;
-      OU_MMA(g, 0, 3); OU_ISSUE(g + 4, 0);
-      OU_MMA(g + 1, 1, 3); OU_ISSUE(g + 5, 1);
-      OU_MMA(g + 2, 2, 3); OU_ISSUE(g + 6, 2);
-      OU_MMA(g + 3, 3, 3); OU_ISSUE(g + 7, 3);
-    }
-    {
-      const int g = (NR - 1) * 4;
-      OU_MMA(g, 0, 3); OU_MMA(g + 1, 1, 2); OU_MMA(g + 2, 2, 1); OU_MMA(g + 3, 3, 0);
-    }
-#undef OU_ISSUE
-#undef OU_MMA
-    if (stage == 1) {  // -> slab again (all window reads of this stage are done): bias, zero outside the signal, conv3's PReLU
-      const float a3 = p.cv[2].alpha;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int ch = 16 * i + 4 * kk + r;
-          const float bi = p.cv[1].bias[ch];
-#pragma unroll
-          for (int j = 0; j < TN; j++) {
-            const int gc = gc0 + j;
-            float v = (gc >= 0 && gc < T) ? acc[i][j][r] + bi : 0.f;
-            S[ch * CH3_LD + 1 + TN * l15 + j] = v >= 0.f ? v : a3 * v;
-          }
-          asm volatile("" ::: "memory");
-        }
-    } else {  // block output: bias, (+x) * scale, columns [2, 62) of the tile
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int ch = 16 * i + 4 * kk + r;
-          const float bi = p.cv[2].bias[ch];
-          const size_t row = xbase + (size_t)ch * T;
-#pragma unroll
-          for (int j = 0; j < TN; j++) {
-            const int lc = TN * l15 + j, gc = gc0 + j;
-            if (lc < 2 || lc >= 62 || gc >= T) continue;
-            float v = acc[i][j][r] + bi;
-            if (p.res) v = (v + p.res[row + gc]) * p.res_scale;
-            p.y[row + gc] = v;
-          }
-          asm volatile("" ::: "memory");
-        }
-    }
-  }
-  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
-}
-
-struct Chain3Cfg {
-  int TM;
-  void (*kern)(ChainArgs);
-};
-static const Chain3Cfg kChain3Cfgs[] = {{2, conv_chain3_kernel<2>}, {3, conv_chain3_kernel<3>}, {4, conv_chain3_kernel<4>}};
-static hipError_t init_chain3_kernels() {
-  for (const Chain3Cfg& c : kChain3Cfgs) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e != hipSuccess) return e;
-  }
-  return hipSuccess;
-}
-// per-wave fused ConvBlock body: C = 32 / 48 / 64, k5 + k3 + k3, every conv with a taps-innermost weight copy
-bool chain3_supported(const ChainArgs& a) {
-  if (a.depth != 3 || (a.C != 32 && a.C != 48 && a.C != 64) || a.Mp < a.C) return false;
-  if (a.cv[0].KW != 5 || a.cv[1].KW != 3 || a.cv[2].KW != 3) return false;
-  if (!a.cv[0].wd || !a.cv[1].wd || !a.cv[2].wd) return false;
-  return (long)a.C * a.T * 4 < (1L << 31) - 64;
-}
-double chain3_tiles_per_simd(const ChainArgs& a, int num_cu) { return (double)((a.T + 59) / 60) * a.B / (4.0 * num_cu); }
-hipError_t launch_chain3(const ChainArgs& a, int num_cu, hipStream_t st, int* variant) {
-  (void)num_cu;
-  if (!chain3_supported(a)) return hipErrorInvalidConfiguration;
-  void (*kern)(ChainArgs) = nullptr;
-  for (const Chain3Cfg& c : kChain3Cfgs)
-    if (16 * c.TM == a.C) kern = c.kern;
-  if (!kern) return hipErrorInvalidConfiguration;
-  const long chunks = (a.T + 239) / 240, total8 = (chunks * a.B + 7) / 8 * 8;
-  if (variant) *variant = 190 + a.C / 16;
-  hipLaunchKernelGGL(kern, dim3((unsigned)total8), dim3(256), (size_t)4 * a.C * CH3_LD * 4, st, a);
-  return hipGetLastError();
-}
-
 struct Direct3sCfg {
   int R;
   void (*kern)(ConvArgs);

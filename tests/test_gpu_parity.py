@@ -506,33 +506,3 @@ def test_throughput_conv_kernel_matches_split_k_kernels(name, B, T, monkeypatch)
     e_ref = O.enhance(sd, sdict, mix, n_steps=3, noise=nz)
     record(f"direct3_vs_oracle.{name}.b{B}", O.si_sdr(e_ref, out.cpu()), 80)
     assert n_conv > 0
-
-
-@pytest.mark.parametrize("name,B,T", [("PP16", 2, 7000), ("PP24", 1, 9000), ("OR16", 3, 5000), ("PP16", 1, 200)])
-def test_per_wave_fused_convblock_matches_unfused_and_oracle(name, B, T, monkeypatch):
-    """conv_chain3_kernel: conv1 (k5) -> cond add -> FiLM -> conv2 -> conv3 -> residual of the C = 32 / 48 / 64 levels fused
-    per wave (D layout -> wave-private LDS slab -> next conv's windows, 60 output columns per 64-column tile).  OU_CHAIN3=2
-    forces it wherever the shape allows, OU_CHAIN3=0 / OU_FUSE=0 runs the three convs as separate launches; T = 200 is a
-    single, mostly empty tile (both signal edges inside one window)."""
-    model, spec, sd = get_model(name)
-    mix = synth_mix(spec, B, T)
-    Tp = T + (spec.tot_ds - T % spec.tot_ds)
-    nz = noise_list(43, 3, B, Tp)
-    monkeypatch.setenv("OU_CHAIN3", "0")
-    monkeypatch.setenv("OU_FUSE", "0")
-    ref = run_enhance(model, mix, nz, n_steps=3)
-    monkeypatch.delenv("OU_FUSE")
-    monkeypatch.setenv("OU_CHAIN3", "2")
-    out = run_enhance(model, mix, nz, n_steps=3)
-    assert torch.equal(out, run_enhance(model, mix, nz, n_steps=3))
-    record(f"chain3_vs_unfused.{name}.b{B}.T{T}", O.si_sdr(ref, out), 90)
-    e_ref = O.enhance(sd, spec.to_dict(), mix, n_steps=3, noise=nz)
-    record(f"chain3_vs_oracle.{name}.b{B}.T{T}", O.si_sdr(e_ref, out), 80)
-    # the conditioner's decoder hands conv1's raw output on as a condition (c1_out): compare a conditioner tap too
-    xin = O.normalize(mix[:, None, :], spec.level_db)
-    pad = Tp - T
-    xin = torch.nn.functional.pad(xin, (pad // 2, pad - pad // 2))
-    taps = {}
-    c_ref, _, _ = O.conditioner_network(sd, "condition_model", spec.to_dict(), xin, taps=taps)
-    cond = model.condition_model(xin.cuda(), train=False)
-    record(f"chain3_cond_last.{name}.b{B}.T{T}", O.si_sdr(c_ref[-1], cond[-1].cpu()), 80)
