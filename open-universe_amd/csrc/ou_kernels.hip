@@ -1659,8 +1659,10 @@ static int direct3_tm(int M) {
 // wave tiles per SIMD the throughput kernel would get for a stride-1 k3 / k5 layer of M rows (what launch_conv's choice and
 // the ConvBlock fusion plan are based on)
 double direct3_tiles_per_simd(int M, int Nq, int B, int num_cu) {
-  const int tm = direct3_tm(M);
-  return (double)((M + 16 * tm - 1) / (16 * tm)) * ((Nq + 63) / 64) * B / (4.0 * num_cu);
+  int tm = direct3_tm(M);
+  double t = (double)((M + 16 * tm - 1) / (16 * tm)) * ((Nq + 63) / 64) * B / (4.0 * num_cu);
+  if (tm > 2 && M % 32 == 0 && t < 3.0) t = (double)((M + 31) / 32) * ((Nq + 63) / 64) * B / (4.0 * num_cu);
+  return t;
 }
 struct Direct3sCfg {
   int R;
@@ -1724,9 +1726,15 @@ static hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t
   // chunks; the split-K kernels keep them whatever the batch (B = 8: 54 vs 107 us on the latent k3 convs)
   if (tile_min > 0 && a.Nq < 1024 && a.force_cfg < 200) return hipErrorInvalidConfiguration;
   int tm = direct3_tm(a.M);
+  const long ct = (a.Nq + 63) / 64;
+  // 32-row tiles where the preferred ones leave fewer than ~3 wave tiles per SIMD (and M tiles by 32): twice the waves, half the
+  // registers (4 waves per SIMD instead of 2), for 4 instead of 6 loads per 24 instead of 48 MFMAs.  Measured (tile_sweep):
+  // PP24 C = 384 at B = 8 (2.4 -> 4.8 tiles per SIMD) 355 / 222 -> 305 / 190 us, PP16 C = 64 at B = 8 (3.9 -> 7.8) 109 / 68 -> 104 / 64;
+  // even at 5.9 tiles per SIMD (PP24 C = 192) the two are equal.
+  if (tm > 2 && a.M % 32 == 0 && (double)((a.M + 16 * tm - 1) / (16 * tm)) * ct * a.B / (4.0 * num_cu) < 3.0) tm = 2;
   if (a.force_cfg >= 200) tm = (a.force_cfg / 10) % 10;
   if (tm < 2 || tm > 4) return hipErrorInvalidConfiguration;
-  const long gy = (a.M + 16 * tm - 1) / (16 * tm), ct = (a.Nq + 63) / 64;
+  const long gy = (a.M + 16 * tm - 1) / (16 * tm);
   const double per_simd = (double)gy * ct * a.B / (4.0 * num_cu);
   if (a.force_cfg < 200 && per_simd < tile_min) return hipErrorInvalidConfiguration;
   // 4 waves x 4 TM KB of LDS for the prefetched epilogue operand (OU_TILE_PREFETCH=0 switches it off)

@@ -46,7 +46,10 @@ for lname, Tin in layers:
     row = []
     tm = 2 if M <= 32 else (3 if (M % 64 and M % 48 == 0) else 4)
     forced = 200 + 10 * tm + KW if (KW in (3, 5) and stride == 1) else 260 + stride
-    for tag, cfg, env in (("auto", -1, None), ("direct3", forced, None), ("r2", -1, "2")):
+    variants = [("auto", -1, None), ("direct3", forced, None), ("r2", -1, "2")]
+    if KW in (3, 5) and stride == 1 and tm == 4:
+        variants += [("tm2", 200 + 20 + KW, None), ("tm3", 200 + 30 + KW, None)]
+    for tag, cfg, env in variants:
         if env is not None:
             os.environ["OU_CONV_DIRECT"] = env
         try:
