@@ -464,8 +464,9 @@ def main():
                                  "algorithmic_gflop_per_enhance": allconv["algorithmic_gflop_per_enhance"]},
             "score_forward": score_forward,
             "method": f"device-side per-launch timing (first block start .. last block end on the 100 MHz s_memrealtime clock) of every conv launch, profiled pass of {args.profile_steps} "
-                      "enhance calls right after the timed region, run as ONE serial chain (no side streams inside the call: a "
-                      "launch's own duration cannot be measured beside kernels of another stream); algorithmic FLOPs/bytes = reference (un-folded) "
+                      "enhance calls right after the timed region, in the SAME mode as the timed calls (side streams inside the call: the "
+                      "launches of the first score-encoder pass run beside the conditioner's and are timed as they run there; "
+                      "profiles/*kstats*_serial.txt has the rocprofv3 averages of the same command as one serial chain); algorithmic FLOPs/bytes = reference (un-folded) "
                       "layer-granular accounting, SURVEY.md 8(d)",
         }
 

@@ -923,8 +923,7 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
   const bool use_aux = (flags & OU_ENH_USE_AUX_SIGNAL) != 0;
   const bool saved_overlap = h->overlap;
   struct OverlapGuard { ou_handle* h; bool v; ~OverlapGuard() { h->overlap = v; } } overlap_guard{h, saved_overlap};
-  // (also while per-launch profiling is on: a kernel's own duration is not measurable beside kernels of another stream)
-  if ((flags & OU_ENH_SERIAL) || h->profile) h->overlap = false;
+  if (flags & OU_ENH_SERIAL) h->overlap = false;
   if (!use_aux && !noise) return fail(h, OU_EINVAL, "noise must be given");
   if (n_steps < 2 || n_steps > kMaxSteps) return fail(h, OU_EINVAL, "n_steps must be in [2, 256]");
   if (warm_start >= n_steps) return fail(h, OU_EINVAL, "warm_start must be < n_steps");

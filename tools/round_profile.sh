@@ -15,6 +15,12 @@ tail -c 400 $O/bench_default.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- \
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_under_rocprof.json 2> $O/rocprof.err
 python tools/kstats.py $O/prof/bench_kernel_trace.csv | head -16 | tee $O/kstats_PP16_B1.txt
+# the same command as ONE serial chain (OU_NO_OVERLAP=1: no side streams inside the call) -- every kernel alone on the device;
+# the default run above times the first score-encoder pass beside the conditioner, like bench.py's own per-launch pass does
+OU_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -o bench -- \
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_under_rocprof_serial.json 2>> $O/rocprof.err
+python tools/kstats.py $O/prof_serial/bench_kernel_trace.csv | head -16 | tee $O/kstats_PP16_B1_serial.txt
+rm -rf $O/prof_serial
 # the other BASELINE configurations (per-GPU shapes): C3 PP16 64 steps B=4, C4 OR16 32 steps B=16, C5 PP24 varlen B=8
 timeout 900 python bench.py --batch 4 --n_steps 64 --steps 5 --warmup 1 --batch-sweep "" > $O/bench_C3_PP16_n64_b4.json 2>> $O/bench_default.err
 timeout 900 python bench.py --model OR16 --batch 16 --n_steps 32 --steps 5 --warmup 1 --batch-sweep "" > $O/bench_C4_OR16_n32_b16.json 2>> $O/bench_default.err
