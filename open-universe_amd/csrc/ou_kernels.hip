@@ -3429,7 +3429,9 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
 // inline asm, invisible to the compiler's own wait-count insertion)
 template <int N>
 __device__ __forceinline__ void gather_wait(u32x4 (&hv)[N]) {
-  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]));
+  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]));
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]));
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]));
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]));
   else if constexpr (N == 8)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]),
@@ -3454,9 +3456,10 @@ __device__ __forceinline__ void gather_wait(u32x4 (&hv)[N]) {
 //                     nothing == want         -> the writer has not stored it: look at that member's own wait record.
 __device__ __attribute__((noinline)) void gru_stale_probe(const unsigned long long* buf, int col0, int ncol, int lstride,
                                                           unsigned want, unsigned* err, unsigned who, unsigned xcc_then,
-                                                          unsigned step) {
+                                                          unsigned step, int grp) {
   for (int i = 0; i < ncol; i++) {
-    const unsigned long long* g = buf + col0 + (i >> 2) * lstride + (i & 3);
+    const int goff = col0 + (i / grp) * lstride + (i % grp);
+    const unsigned long long* g = buf + goff;
     u32x2 a, b, c;
     asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(g) : "memory");
     if (a.y == want) continue;
@@ -3467,7 +3470,7 @@ __device__ __attribute__((noinline)) void gru_stale_probe(const unsigned long lo
     if (atomicAdd(err + 21, 1u) == 0u) {
       unsigned now;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(now));
-      err[22] = who; err[23] = (unsigned)(col0 + (i >> 2) * lstride + (i & 3)); err[24] = want;
+      err[22] = who; err[23] = (unsigned)goff; err[24] = want;
       err[25] = a.y; err[26] = b.y; err[27] = c.y;
       asm volatile("buffer_inv sc1\n\tglobal_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(g) : "memory");
       err[28] = a.y;
@@ -3508,12 +3511,21 @@ __device__ __attribute__((noinline)) void gru_timeout_report(unsigned* err, cons
 
 constexpr unsigned GRU_EPOCH_WRAP = 0x7F000000u;  // past this the last block of a launch clears the exchange area
 
-template <int HB, int UPW>
+// WIDE: the gather layout with no redundant loads.  In the default layout a unit's 16 lanes hold all H columns, so the four
+// units of a wave each fetch the same 2 KB (H = 256) per poll round: 8 dwordx4 loads per lane, 32 wave-loads of 16 TA cycles
+// per workgroup and round -- the round is bound by the CU's address path (~500 cycles), not by the L2 latency (~200).  WIDE:
+// lane l holds columns 2l, 2l + 1 (+ 128 i) for ALL four units of its wave: HB / 2 loads per lane and round; the 12 (unit,
+// gate) partial sums are folded 64 -> 16 lanes by two swap levels (v_permlane32_swap / v_permlane16_swap halve the value
+// count as they halve the lane count: 6 + 3 swaps), after which row r of the wave holds unit r's sums exactly as in the
+// default layout.
+template <int HB, int UPW, bool WIDE = false>
 __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters) {
-  constexpr int H = 64 * HB, NT = 256, LPU = NT / UPW, NC = H / LPU, NI = NC / 4, NWG = H / UPW;
+  constexpr int H = 64 * HB, NT = 256, LPU = WIDE ? 16 : NT / UPW, NC = WIDE ? HB : H / LPU, NI = WIDE ? HB / 2 : NC / 4,
+                NWG = H / UPW;
+  static_assert(!WIDE || (UPW == 16 && HB % 2 == 0), "wide gather: four units per wave, whole 16-byte granule pairs");
   constexpr int CSTRIDE = 2 * H + 64;  // granules per cluster: two parity buffers + rendezvous slots
   static_assert(LPU == 8 || LPU == 16 || LPU == 32, "8, 16 or 32 lanes per hidden unit");
-  static_assert(NC % 4 == 0 && NWG > 1 && NWG < 64, "column blocks / rendezvous slots (slot 63 = the mode flag)");
+  static_assert((WIDE || NC % 4 == 0) && NWG > 1 && NWG < 64, "column blocks / rendezvous slots (slot 63 = the mode flag)");
   const int tid = threadIdx.x, lane = tid & 63;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
@@ -3532,9 +3544,24 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
     const int unit = g * UPW + ul;
 
     // this lane's weights: (W_r, W_z) row pairs and W_n for columns 4cg + 4 LPU i + {0..3}
-    f32x2 wrz[NC];
-    float wn[NC];
-    {
+    // (WIDE: for the wave's four units u and columns 2 lane + 128 i + {0, 1}: index u * HB + 2 i + {0, 1})
+    constexpr int NW = WIDE ? 4 * HB : NC;
+    f32x2 wrz[NW];
+    float wn[NW];
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float* wd = p.whh + (size_t)dir * 3 * H * H + (size_t)(g * UPW + (tid >> 6) * 4 + u) * H + 2 * lane;
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+          const float2 vr = *reinterpret_cast<const float2*>(wd + 128 * i);
+          const float2 vz = *reinterpret_cast<const float2*>(wd + (size_t)H * H + 128 * i);
+          const float2 vn = *reinterpret_cast<const float2*>(wd + (size_t)2 * H * H + 128 * i);
+          wrz[u * HB + 2 * i] = f32x2{vr.x, vz.x}; wrz[u * HB + 2 * i + 1] = f32x2{vr.y, vz.y};
+          wn[u * HB + 2 * i] = vn.x; wn[u * HB + 2 * i + 1] = vn.y;
+        }
+      }
+    } else {
       const float* wd = p.whh + (size_t)dir * 3 * H * H + (size_t)unit * H + cg * 4;
 #pragma unroll
       for (int i = 0; i < NI; i++) {
@@ -3640,13 +3667,17 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
         for (int k = 0; k < NC / 2; k++) hv[k] = u32x4{0u, 0u, 0u, 0u};
       } else {
         const unsigned want = epoch + (unsigned)step;
-        const unsigned long long* src = xq + (size_t)(step & 1) * H + cg * 4;
+        const unsigned long long* src = xq + (size_t)(step & 1) * H + (WIDE ? 2 * lane : cg * 4);
         unsigned spins = 0;
         while (true) {
           // 16-byte loads = two granules each; asm: the compiler must neither cache the values nor pick the scope.
           // sc1 = agent scope.  (sc0 -- workgroup scope -- polls were tried for clusters that share an XCD: they never
           // observe the other CUs' publishes; kept behind OU_GRU_BACKOFF=3 for the record.)
-          if (plain && p.poll_backoff == 3) {
+          if constexpr (WIDE) {
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+              asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(hv[i]) : "v"(src), "n"(1024 * i) : "memory");
+          } else if (plain && p.poll_backoff == 3) {
 #pragma unroll
             for (int i = 0; i < NI; i++) {
               asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0"
@@ -3705,8 +3736,9 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
           }
           if (((spins & 255u) == 255u || flagged) && !(p.dbg & 1)) {
             if (!flagged && !sysmode)  // first trigger of this wave: leave a record of what the stale granule looks like
-              gru_stale_probe(xq + (size_t)(step & 1) * H, cg * 4, NC, 4 * LPU, want, p.err,
-                              ((unsigned)cluster << 16) | ((unsigned)g << 8) | (unsigned)(tid >> 6), xcc, (unsigned)step);
+              gru_stale_probe(xq + (size_t)(step & 1) * H, WIDE ? 2 * lane : cg * 4, NC, WIDE ? 128 : 4 * LPU, want, p.err,
+                              ((unsigned)cluster << 16) | ((unsigned)g << 8) | (unsigned)(tid >> 6), xcc, (unsigned)step,
+                              WIDE ? 2 : 4);
             if (fin) {
               const unsigned long long gran = ((unsigned long long)want << 32) | (unsigned)__float_as_int(hprev);
               unsigned long long* dst = xq + (size_t)(step & 1) * H + unit;
@@ -3745,17 +3777,57 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
       }
       if (ts_on) q1 = __builtin_readcyclecounter();
       // ---- matvec: (r, z) as packed row pairs against the granule's value half, n as scalar FMAs
-      f32x2 arz0 = {0.f, 0.f}, arz1 = {0.f, 0.f};
-      float an0 = 0.f, an1 = 0.f;
+      float hs[3];
+      if constexpr (WIDE) {
+        // 12 partial sums (unit u of the wave x gate) over this lane's HB columns
+        f32x2 arz[4];
+        float an[4];
 #pragma unroll
-      for (int k = 0; k < NC / 2; k++) {
-        const float h0 = __uint_as_float(hv[k].x), h1 = __uint_as_float(hv[k].z);
-        arz0 = __builtin_elementwise_fma(wrz[2 * k], f32x2{h0, h0}, arz0);
-        arz1 = __builtin_elementwise_fma(wrz[2 * k + 1], f32x2{h1, h1}, arz1);
-        an0 = fmaf(wn[2 * k], h0, an0);
-        an1 = fmaf(wn[2 * k + 1], h1, an1);
+        for (int u = 0; u < 4; u++) { arz[u] = f32x2{0.f, 0.f}; an[u] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < NC / 2; k++) {
+          const float h0 = __uint_as_float(hv[k].x), h1 = __uint_as_float(hv[k].z);
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            arz[u] = __builtin_elementwise_fma(wrz[u * HB + 2 * k], f32x2{h0, h0}, arz[u]);
+            an[u] = fmaf(wn[u * HB + 2 * k], h0, an[u]);
+            arz[u] = __builtin_elementwise_fma(wrz[u * HB + 2 * k + 1], f32x2{h1, h1}, arz[u]);
+            an[u] = fmaf(wn[u * HB + 2 * k + 1], h1, an[u]);
+          }
+        }
+        // fold 64 -> 32 lanes: units (0, 2) and (1, 3) trade halves; lanes < 32 keep units 0 / 1, lanes >= 32 units 2 / 3
+        f32x2 rz01[2];
+        float n01[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const auto sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(arz[u].x), __float_as_uint(arz[u + 2].x), false, false);
+          const auto sz = __builtin_amdgcn_permlane32_swap(__float_as_uint(arz[u].y), __float_as_uint(arz[u + 2].y), false, false);
+          const auto sn = __builtin_amdgcn_permlane32_swap(__float_as_uint(an[u]), __float_as_uint(an[u + 2]), false, false);
+          rz01[u] = f32x2{__uint_as_float(sr[0]), __uint_as_float(sz[0])} + f32x2{__uint_as_float(sr[1]), __uint_as_float(sz[1])};
+          n01[u] = __uint_as_float(sn[0]) + __uint_as_float(sn[1]);
+        }
+        // fold 32 -> 16 lanes: the two remaining units trade rows; row r of the wave ends up with unit r
+        {
+          const auto sr = __builtin_amdgcn_permlane16_swap(__float_as_uint(rz01[0].x), __float_as_uint(rz01[1].x), false, false);
+          const auto sz = __builtin_amdgcn_permlane16_swap(__float_as_uint(rz01[0].y), __float_as_uint(rz01[1].y), false, false);
+          const auto sn = __builtin_amdgcn_permlane16_swap(__float_as_uint(n01[0]), __float_as_uint(n01[1]), false, false);
+          const f32x2 rz = f32x2{__uint_as_float(sr[0]), __uint_as_float(sz[0])} + f32x2{__uint_as_float(sr[1]), __uint_as_float(sz[1])};
+          hs[0] = rz.x; hs[1] = rz.y;
+          hs[2] = __uint_as_float(sn[0]) + __uint_as_float(sn[1]);
+        }
+      } else {
+        f32x2 arz0 = {0.f, 0.f}, arz1 = {0.f, 0.f};
+        float an0 = 0.f, an1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC / 2; k++) {
+          const float h0 = __uint_as_float(hv[k].x), h1 = __uint_as_float(hv[k].z);
+          arz0 = __builtin_elementwise_fma(wrz[2 * k], f32x2{h0, h0}, arz0);
+          arz1 = __builtin_elementwise_fma(wrz[2 * k + 1], f32x2{h1, h1}, arz1);
+          an0 = fmaf(wn[2 * k], h0, an0);
+          an1 = fmaf(wn[2 * k + 1], h1, an1);
+        }
+        hs[0] = arz0.x + arz1.x; hs[1] = arz0.y + arz1.y; hs[2] = an0 + an1;
       }
-      float hs[3] = {arz0.x + arz1.x, arz0.y + arz1.y, an0 + an1};
 #pragma unroll
       for (int gt = 0; gt < 3; gt++) {
         hs[gt] = LPU == 8 ? row8_sum(hs[gt]) : row16_sum(hs[gt]);
@@ -3822,33 +3894,40 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
 }
 
 template <int HB>
-static void (*gru_ring_entry(int upw))(GruArgs, int) {
+static void (*gru_ring_entry(int upw, bool wide))(GruArgs, int) {
   if constexpr (HB <= 4) {
     if (upw == 32) return gru_ring_kernel<HB, 32>;
   }
   if constexpr (HB >= 2 && HB <= 4) {  // 8 units per workgroup: half the columns (and polls) per lane, twice the workgroups
     if (upw == 8) return gru_ring_kernel<HB, 8>;
   }
+  if constexpr (HB % 2 == 0) {
+    if (wide) return gru_ring_kernel<HB, 16, true>;
+  }
   return gru_ring_kernel<HB, 16>;
 }
 // Workgroups of the ring kernel that can be resident per CU (every member of a cluster spins on the others: the whole
 // grid has to be on the machine at once).  The occupancy query can be one block high where SGPRs are the limit (guide:
 // admitted = min(API, 8, 800 / (ceil(sgpr / 16) * 16 + 16)): API 8 -> 7 at 81-96 SGPRs, 7 -> 6 at 97-112), which only
-// concerns answers >= 7: one block of margin is taken off those.  These kernels are VGPR-limited (134-180 VGPRs: API 3 / 2),
-// and at most TWO per CU are relied upon (two workgroups = two waves per SIMD, each waiting on its gather most of the time).
+// concerns answers >= 7: one block of margin is taken off those.  At most TWO per CU are relied upon (two workgroups = two
+// waves per SIMD, each waiting on its gather most of the time).
 template <int HB>
-static int gru_ring_resident_per_cu(int upw) {
-  static int cache[3] = {0, 0, 0};
-  const int slot = upw == 32 ? 2 : (upw == 8 ? 0 : 1);
+static int gru_ring_resident_per_cu(int upw, bool wide) {
+  static int cache[4] = {0, 0, 0, 0};
+  const int slot = upw == 32 ? 2 : (upw == 8 ? 0 : (wide ? 3 : 1));
   if (cache[slot] == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(gru_ring_entry<HB>(upw)), 256, 0) !=
-        hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(gru_ring_entry<HB>(upw, wide)), 256,
+                                                     0) != hipSuccess)
       nb = 1;
     if (nb >= 7) nb -= 1;
     cache[slot] = nb >= 2 ? 2 : 1;
   }
   return cache[slot];
+}
+// the gather layout without redundant loads (16 units per workgroup, even H / 64); OU_GRU_UPW=17 asks for the default layout
+static bool gru_ring_wide(int H, int force_upw) {
+  return (H / 64) % 2 == 0 && force_upw != 17 && force_upw != 32 && !(force_upw == 8 && H >= 128 && H <= 256);
 }
 static int gru_ring_upw(int H, int force_upw) {
   return (force_upw == 32 && H <= 256) ? 32 : ((force_upw == 8 && H >= 128 && H <= 256) ? 8 : 16);
@@ -3858,12 +3937,13 @@ static int gru_ring_upw(int H, int force_upw) {
 int gru_ring_batch_cap(int H, int num_cu, int shared, int force_upw) {
   if (H % 64) return 0;
   const int upw = gru_ring_upw(H, force_upw), nwg = H / upw;
+  const bool wide = gru_ring_wide(H, force_upw);
   int per_cu = 1;
   switch (H / 64) {
-    case 1: per_cu = gru_ring_resident_per_cu<1>(upw); break;
-    case 2: per_cu = gru_ring_resident_per_cu<2>(upw); break;
-    case 4: per_cu = gru_ring_resident_per_cu<4>(upw); break;
-    case 6: per_cu = gru_ring_resident_per_cu<6>(upw); break;
+    case 1: per_cu = gru_ring_resident_per_cu<1>(upw, wide); break;
+    case 2: per_cu = gru_ring_resident_per_cu<2>(upw, wide); break;
+    case 4: per_cu = gru_ring_resident_per_cu<4>(upw, wide); break;
+    case 6: per_cu = gru_ring_resident_per_cu<6>(upw, wide); break;
     default: return 0;
   }
   const int wg_cap = num_cu * per_cu / (shared ? 2 : 1);
@@ -3874,7 +3954,7 @@ static hipError_t launch_gru_ring(const GruArgs& c, int upw, int nclusters, hipS
   constexpr int H = 64 * HB;
   const int nwg = H / upw;
   dim3 grid(8 * nwg * ((nclusters + 7) / 8));
-  hipLaunchKernelGGL(gru_ring_entry<HB>(upw), grid, dim3(256), 0, st, c, nclusters);
+  hipLaunchKernelGGL(gru_ring_entry<HB>(upw, gru_ring_wide(H, c.force_upw)), grid, dim3(256), 0, st, c, nclusters);
   return hipGetLastError();
 }
 
