@@ -983,7 +983,7 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
     r.chk(launch_film(P.g, r.W(m.film.w_off), r.W(m.film.b_off), P.film, n_steps, m.film.rows, m.film.D, st), "film");
     // (only when two GRU layers fit on the machine side by side: their clusters spin on each other's publishes and must
     // all be resident)
-    const bool gru_fit = gru_ring_batch_cap(m.s_gru.H, h->num_cu, 1, 0) >= 1 && gru_ring_batch_cap(m.c_gru0.H, h->num_cu, 1, 0) >= 1;
+    const bool gru_fit = gru_ring_batch_cap(m.s_gru.H, h->num_cu, 1, 0, B) >= 1 && gru_ring_batch_cap(m.c_gru0.H, h->num_cu, 1, 0, B) >= 1;
     if (warm_start < 0 && h->overlap && gru_fit) {
       r.gru_shared = true;
       r.chk(launch_init_x(noise, nullptr, sigma[n_start], P.x.p, nBT, st), "init x");  // universe.py:325-327

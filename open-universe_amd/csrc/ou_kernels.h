@@ -186,7 +186,7 @@ struct GruArgs {
 };
 hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st);
 // utterances one ring-kernel launch can carry with its whole grid resident (0: hidden size not supported)
-int gru_ring_batch_cap(int H, int num_cu, int shared, int force_upw);
+int gru_ring_batch_cap(int H, int num_cu, int shared, int force_upw, int B);
 // 8-byte exchange granules needed for a batch of B sequences with hidden size H (both kernel generations)
 inline size_t gru_granules(int B, int H) { return (size_t)2 * B * (2 * H + 64); }
 

@@ -3518,11 +3518,18 @@ constexpr unsigned GRU_EPOCH_WRAP = 0x7F000000u;  // past this the last block of
 // gate) partial sums are folded 64 -> 16 lanes by two swap levels (v_permlane32_swap / v_permlane16_swap halve the value
 // count as they halve the lane count: 6 + 3 swaps), after which row r of the wave holds unit r's sums exactly as in the
 // default layout.
+// (Tried on top of WIDE and dropped: the four waves of a workgroup sharing the gather -- wave w polls granules [w H / 4,
+// (w + 1) H / 4), 32 instead of 128 requests per line and step, and passes them on through a tag-checked LDS copy of the
+// exchange buffer.  Gather 1 225 instead of 738 cycles per step: the L2 request rate is not what a poll round waits for.
+// Measured for the record (OU_GRU_BACKOFF=10..14, tools/gru_ts.py): the first poll round succeeds on 92-95 % of the steps; a
+// wave's two stores are acknowledged after ~230 cycles; one isolated 8-byte load, sc1 or plain, quiet or just-written line,
+// takes ~320 cycles; every cycle a wave spends between its publish and its poll comes back one-to-one in everybody's step
+// time -- the clusters run in lock step, the step is compute + one store latency + one load latency + the skew of 64-128 waves.)
 template <int HB, int UPW, bool WIDE = false>
 __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters) {
-  constexpr int H = 64 * HB, NT = 256, LPU = WIDE ? 16 : NT / UPW, NC = WIDE ? HB : H / LPU, NI = WIDE ? HB / 2 : NC / 4,
-                NWG = H / UPW;
-  static_assert(!WIDE || (UPW == 16 && HB % 2 == 0), "wide gather: four units per wave, whole 16-byte granule pairs");
+  constexpr int H = 64 * HB, NT = 256, LPU = NT / UPW, NC = WIDE ? HB : H / LPU, NI = WIDE ? HB / 2 : NC / 4, NWG = H / UPW;
+  constexpr int WU = UPW / 4;  // units per wave
+  static_assert(!WIDE || ((UPW == 16 || UPW == 8) && HB % 2 == 0), "wide gather: 4 / 2 units per wave, whole granule pairs");
   constexpr int CSTRIDE = 2 * H + 64;  // granules per cluster: two parity buffers + rendezvous slots
   static_assert(LPU == 8 || LPU == 16 || LPU == 32, "8, 16 or 32 lanes per hidden unit");
   static_assert((WIDE || NC % 4 == 0) && NWG > 1 && NWG < 64, "column blocks / rendezvous slots (slot 63 = the mode flag)");
@@ -3537,6 +3544,8 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
   const int T = p.T;
   const bool ts_on = p.tstamps != nullptr;
   long long c_poll = 0, c_comp = 0, r_start = 0, r_loop = 0;
+  unsigned c_rounds = 0;
+  long long c_ack = 0;
   if (ts_on) r_start = (long long)__builtin_amdgcn_s_memrealtime();
   if (cluster < nclusters) {
     const int dir = cluster & 1, b = cluster >> 1;
@@ -3545,13 +3554,13 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
 
     // this lane's weights: (W_r, W_z) row pairs and W_n for columns 4cg + 4 LPU i + {0..3}
     // (WIDE: for the wave's four units u and columns 2 lane + 128 i + {0, 1}: index u * HB + 2 i + {0, 1})
-    constexpr int NW = WIDE ? 4 * HB : NC;
+    constexpr int NW = WIDE ? WU * HB : NC;
     f32x2 wrz[NW];
     float wn[NW];
     if constexpr (WIDE) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const float* wd = p.whh + (size_t)dir * 3 * H * H + (size_t)(g * UPW + (tid >> 6) * 4 + u) * H + 2 * lane;
+      for (int u = 0; u < WU; u++) {
+        const float* wd = p.whh + (size_t)dir * 3 * H * H + (size_t)(g * UPW + (tid >> 6) * WU + u) * H + 2 * lane;
 #pragma unroll
         for (int i = 0; i < NI; i++) {
           const float2 vr = *reinterpret_cast<const float2*>(wd + 128 * i);
@@ -3669,6 +3678,14 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
         const unsigned want = epoch + (unsigned)step;
         const unsigned long long* src = xq + (size_t)(step & 1) * H + (WIDE ? 2 * lane : cg * 4);
         unsigned spins = 0;
+        // experiment (OU_GRU_BACKOFF = 6..9): nothing can have arrived right after this wave's own publish -- the first poll
+        // rounds only load the L2 channels that the other members' stores have to get through
+        if (p.poll_backoff >= 6) {
+          if (p.poll_backoff == 6) __builtin_amdgcn_s_sleep(1);
+          else if (p.poll_backoff == 7) __builtin_amdgcn_s_sleep(2);
+          else if (p.poll_backoff == 8) __builtin_amdgcn_s_sleep(3);
+          else __builtin_amdgcn_s_sleep(5);
+        }
         while (true) {
           // 16-byte loads = two granules each; asm: the compiler must neither cache the values nor pick the scope.
           // sc1 = agent scope.  (sc0 -- workgroup scope -- polls were tried for clusters that share an XCD: they never
@@ -3774,46 +3791,50 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
           }
         }
         if (step >= T) break;
+        if (ts_on) c_rounds += spins + 1u;
       }
       if (ts_on) q1 = __builtin_readcyclecounter();
       // ---- matvec: (r, z) as packed row pairs against the granule's value half, n as scalar FMAs
       float hs[3];
       if constexpr (WIDE) {
-        // 12 partial sums (unit u of the wave x gate) over this lane's HB columns
-        f32x2 arz[4];
-        float an[4];
+        // 3 WU partial sums (unit u of the wave x gate) over this lane's HB columns
+        f32x2 arz[WU];
+        float an[WU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { arz[u] = f32x2{0.f, 0.f}; an[u] = 0.f; }
+        for (int u = 0; u < WU; u++) { arz[u] = f32x2{0.f, 0.f}; an[u] = 0.f; }
 #pragma unroll
         for (int k = 0; k < NC / 2; k++) {
           const float h0 = __uint_as_float(hv[k].x), h1 = __uint_as_float(hv[k].z);
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < WU; u++) {
             arz[u] = __builtin_elementwise_fma(wrz[u * HB + 2 * k], f32x2{h0, h0}, arz[u]);
             an[u] = fmaf(wn[u * HB + 2 * k], h0, an[u]);
             arz[u] = __builtin_elementwise_fma(wrz[u * HB + 2 * k + 1], f32x2{h1, h1}, arz[u]);
             an[u] = fmaf(wn[u * HB + 2 * k + 1], h1, an[u]);
           }
         }
-        // fold 64 -> 32 lanes: units (0, 2) and (1, 3) trade halves; lanes < 32 keep units 0 / 1, lanes >= 32 units 2 / 3
-        f32x2 rz01[2];
-        float n01[2];
+        // fold 64 -> 32 lanes: units u and u + WU / 2 trade halves; lanes < 32 keep the lower units, lanes >= 32 the upper ones
+        constexpr int HU = WU / 2;
+        f32x2 rz01[HU];
+        float n01[HU];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const auto sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(arz[u].x), __float_as_uint(arz[u + 2].x), false, false);
-          const auto sz = __builtin_amdgcn_permlane32_swap(__float_as_uint(arz[u].y), __float_as_uint(arz[u + 2].y), false, false);
-          const auto sn = __builtin_amdgcn_permlane32_swap(__float_as_uint(an[u]), __float_as_uint(an[u + 2]), false, false);
+        for (int u = 0; u < HU; u++) {
+          const auto sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(arz[u].x), __float_as_uint(arz[u + HU].x), false, false);
+          const auto sz = __builtin_amdgcn_permlane32_swap(__float_as_uint(arz[u].y), __float_as_uint(arz[u + HU].y), false, false);
+          const auto sn = __builtin_amdgcn_permlane32_swap(__float_as_uint(an[u]), __float_as_uint(an[u + HU]), false, false);
           rz01[u] = f32x2{__uint_as_float(sr[0]), __uint_as_float(sz[0])} + f32x2{__uint_as_float(sr[1]), __uint_as_float(sz[1])};
           n01[u] = __uint_as_float(sn[0]) + __uint_as_float(sn[1]);
         }
-        // fold 32 -> 16 lanes: the two remaining units trade rows; row r of the wave ends up with unit r
-        {
+        if constexpr (WU == 4) {
+          // fold 32 -> 16 lanes: the two remaining units trade rows; row r of the wave ends up with unit r
           const auto sr = __builtin_amdgcn_permlane16_swap(__float_as_uint(rz01[0].x), __float_as_uint(rz01[1].x), false, false);
           const auto sz = __builtin_amdgcn_permlane16_swap(__float_as_uint(rz01[0].y), __float_as_uint(rz01[1].y), false, false);
           const auto sn = __builtin_amdgcn_permlane16_swap(__float_as_uint(n01[0]), __float_as_uint(n01[1]), false, false);
           const f32x2 rz = f32x2{__uint_as_float(sr[0]), __uint_as_float(sz[0])} + f32x2{__uint_as_float(sr[1]), __uint_as_float(sz[1])};
           hs[0] = rz.x; hs[1] = rz.y;
           hs[2] = __uint_as_float(sn[0]) + __uint_as_float(sn[1]);
+        } else {  // two units per wave: each half of the wave goes on as one 32-lane group (row sums + row_bcast:15 below)
+          hs[0] = rz01[0].x; hs[1] = rz01[0].y; hs[2] = n01[0];
         }
       } else {
         f32x2 arz0 = {0.f, 0.f}, arz1 = {0.f, 0.f};
@@ -3863,13 +3884,32 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
         }
         p.out[orow + t] = has_res ? (hnew + rs) * p.res_scale : hnew;
       }
-      if (ts_on) { c_poll += q1 - q0; c_comp += __builtin_readcyclecounter() - q1; }
+      if (ts_on) {
+        const long long q2 = __builtin_readcyclecounter();
+        c_poll += q1 - q0; c_comp += q2 - q1;
+        if (p.poll_backoff == 10) {  // experiment: how long until this wave's two stores (publish, output) are acknowledged?
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          c_ack += __builtin_readcyclecounter() - q2;
+        } else if (p.poll_backoff >= 11 && p.poll_backoff <= 14) {
+          // experiment: latency of ONE 8-byte load per lane once this wave's stores are acknowledged --
+          // 11: sc1, quiet lines (the rendezvous slots), 12: sc1, the buffer that was gathered in this step (nobody writes
+          // it now), 13: the same without sc1, 14: sc1, the buffer everybody is publishing into right now
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          const unsigned long long* a = p.poll_backoff == 11 ? xq + 2 * H + (lane & 31)
+                                        : xq + (size_t)((step + (p.poll_backoff == 14 ? 1 : 0)) & 1) * H + (tid >> 6) * (H / 4) + lane % (H / 4);
+          u32x2 d;
+          const long long q3 = __builtin_readcyclecounter();
+          if (p.poll_backoff == 13) asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(d) : "v"(a) : "memory");
+          else asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(d) : "v"(a) : "memory");
+          c_ack += __builtin_readcyclecounter() - q3;
+        }
+      }
     }
     if (ts_on && lane == 0) {
       long long* o = p.tstamps + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 8;
       // 10 ns ticks: kernel entry -> first step (weights, rendezvous, first chunks), the T steps
-      o[0] = c_comp; o[1] = c_poll; o[2] = 0; o[3] = T; o[4] = r_loop - r_start;
-      o[5] = (long long)__builtin_amdgcn_s_memrealtime() - r_loop; o[6] = r_start;
+      o[0] = c_comp; o[1] = c_poll; o[2] = c_rounds; o[3] = T; o[4] = r_loop - r_start;
+      o[5] = (long long)__builtin_amdgcn_s_memrealtime() - r_loop; o[6] = r_start; o[7] = c_ack;
     }
   }
   // ---- epoch hand-over: the last block to finish advances the epoch for the next launch on this exchange area
@@ -3894,11 +3934,14 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
 }
 
 template <int HB>
-static void (*gru_ring_entry(int upw, bool wide))(GruArgs, int) {
+static void (*gru_ring_entry(int upw, int wide))(GruArgs, int) {
   if constexpr (HB <= 4) {
     if (upw == 32) return gru_ring_kernel<HB, 32>;
   }
-  if constexpr (HB >= 2 && HB <= 4) {  // 8 units per workgroup: half the columns (and polls) per lane, twice the workgroups
+  if constexpr (HB % 2 == 0) {  // 8 units per workgroup: half the matvec per wave, twice the workgroups
+    if (upw == 8 && wide) return gru_ring_kernel<HB, 8, true>;
+  }
+  if constexpr (HB >= 2 && HB <= 4) {
     if (upw == 8) return gru_ring_kernel<HB, 8>;
   }
   if constexpr (HB % 2 == 0) {
@@ -3912,9 +3955,9 @@ static void (*gru_ring_entry(int upw, bool wide))(GruArgs, int) {
 // concerns answers >= 7: one block of margin is taken off those.  At most TWO per CU are relied upon (two workgroups = two
 // waves per SIMD, each waiting on its gather most of the time).
 template <int HB>
-static int gru_ring_resident_per_cu(int upw, bool wide) {
-  static int cache[4] = {0, 0, 0, 0};
-  const int slot = upw == 32 ? 2 : (upw == 8 ? 0 : (wide ? 3 : 1));
+static int gru_ring_resident_per_cu(int upw, int wide) {
+  static int cache[5] = {0, 0, 0, 0, 0};
+  const int slot = upw == 32 ? 2 : (upw == 8 ? (wide ? 4 : 0) : (wide ? 3 : 1));
   if (cache[slot] == 0) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(gru_ring_entry<HB>(upw, wide)), 256,
@@ -3925,19 +3968,28 @@ static int gru_ring_resident_per_cu(int upw, bool wide) {
   }
   return cache[slot];
 }
-// the gather layout without redundant loads (16 units per workgroup, even H / 64); OU_GRU_UPW=17 asks for the default layout
-static bool gru_ring_wide(int H, int force_upw) {
-  return (H / 64) % 2 == 0 && force_upw != 17 && force_upw != 32 && !(force_upw == 8 && H >= 128 && H <= 256);
+// OU_GRU_UPW (force_upw): 0 auto | 16 / 8 units per workgroup, wide layout | 17 / 9 the same in the default (round-2)
+// layout | 32 units, default layout
+static int gru_ring_wide(int H, int force_upw) {
+  return ((H / 64) % 2 == 0 && force_upw != 17 && force_upw != 32 && force_upw != 9) ? 1 : 0;
 }
-static int gru_ring_upw(int H, int force_upw) {
-  return (force_upw == 32 && H <= 256) ? 32 : ((force_upw == 8 && H >= 128 && H <= 256) ? 8 : 16);
+// hidden units per workgroup.  16 by default; 8 (wide layout: two units per wave -- half the matvec and one fold level less
+// on the critical path of every step, 252 -> 240 us per 401-frame pass) while every workgroup of the launch still gets a CU
+// of its own: measured 7.59 -> 7.43 ms per enhance at B = 1, 16.80 -> 16.71 at B = 4, but 29.0 -> 29.5 at B = 8 (two
+// workgroups per CU).  B = 0: the choice for the smallest batch.
+static int gru_ring_upw(int H, int force_upw, int B, int num_cu) {
+  if (force_upw == 32 && H <= 256) return 32;
+  if (force_upw == 9 && H >= 128 && H <= 256) return 8;
+  if (force_upw == 8 && (H / 64) % 2 == 0 && H <= 384) return 8;
+  if (force_upw == 0 && (H / 64) % 2 == 0 && H <= 256 && 2 * (B > 0 ? B : 1) * (H / 8) <= num_cu) return 8;
+  return 16;
 }
 // utterances one ring-kernel launch may carry: whole groups of 8 clusters (one per XCD), two clusters per utterance,
 // the whole grid resident -- on HALF the machine when another GRU layer may run beside it (`shared`)
-int gru_ring_batch_cap(int H, int num_cu, int shared, int force_upw) {
+int gru_ring_batch_cap(int H, int num_cu, int shared, int force_upw, int B) {
   if (H % 64) return 0;
-  const int upw = gru_ring_upw(H, force_upw), nwg = H / upw;
-  const bool wide = gru_ring_wide(H, force_upw);
+  const int upw = gru_ring_upw(H, force_upw, B, num_cu), nwg = H / upw;
+  const int wide = gru_ring_wide(H, force_upw);
   int per_cu = 1;
   switch (H / 64) {
     case 1: per_cu = gru_ring_resident_per_cu<1>(upw, wide); break;
@@ -3982,13 +4034,13 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
   else if (a.H % 16 == 0 && batch_cap(16) >= a.B) upw = 16;
   else if (a.H % 32 == 0 && batch_cap(32) >= a.B) upw = 32;
   // the ring kernel runs 256-thread workgroups of 16 units (32 on request, H <= 256)
-  if (a.version == 2) upw = gru_ring_upw(a.H, a.force_upw);
+  if (a.version == 2) upw = gru_ring_upw(a.H, a.force_upw, a.B, num_cu);
   const int nwg = a.H / upw;
   int bmax = batch_cap(upw);
   // residency of the ring kernel: every member of a cluster spins on the others, so a launch is sized to what can be on
   // the machine at once (half of it when a second GRU layer may run beside this one: conditioner / first score pass);
   // a batch that does not fit is split into sub-launches, never enqueued oversized
-  if (a.version == 2) bmax = gru_ring_batch_cap(a.H, num_cu, a.shared, a.force_upw);
+  if (a.version == 2) bmax = gru_ring_batch_cap(a.H, num_cu, a.shared, a.force_upw, a.B);
   if (a.force_bmax > 0 && a.force_bmax < bmax) bmax = a.force_bmax;
   if (bmax < 1) return hipErrorInvalidConfiguration;
   for (int b0 = 0; b0 < a.B; b0 += bmax) {

@@ -23,7 +23,9 @@ for blk in (0, 1, 8, 9):
         print("v2 block", blk, "per-step cycles per wave [compute (matvec..publish), gather (poll until all tags)]:",
               [[round(float(x) / 401) for x in ts[blk, w, [0, 1]]] for w in (0, 1, 2, 3)],
               "| us: entry -> first step", [round(float(ts[blk, w, 4]) / 100, 1) for w in (0, 1, 2, 3)],
-              "steps", [round(float(ts[blk, w, 5]) / 100, 1) for w in (0, 1, 2, 3)])
+              "steps", [round(float(ts[blk, w, 5]) / 100, 1) for w in (0, 1, 2, 3)],
+              "| poll rounds per step", [round(float(ts[blk, w, 2]) / 400, 2) for w in (0, 1, 2, 3)],
+              "| store ack (OU_GRU_BACKOFF=10)", [round(float(ts[blk, w, 7]) / 401) for w in (0, 1, 2, 3)])
 if v != "1":
     st = ts[:, :, 6]
     on = st > 0
