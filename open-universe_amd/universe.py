@@ -117,6 +117,11 @@ class Universe:
     def _workspace(self, B, T):
         key = (B, T)
         if self._ws_key != key:
+            # free-running mode: the status copy of the previous call belongs to the workspace that is left now -- the next
+            # call's copy would replace it unexamined
+            if self._status_event is not None and not self.check_status:
+                self._status_event.synchronize()
+                self._raise_on_status()
             cache = self._ws_cache
             if key in cache:
                 cache[key] = cache.pop(key)  # move to the back
