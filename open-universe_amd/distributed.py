@@ -198,7 +198,8 @@ def enhance_sharded(model, signals, seed=1028282, gather=True, batch_size=1, pad
     finally:
         if sync_mode is not None:
             model.check_status = sync_mode
-            model.synchronize()  # raises on a device-side time-out of any call of the shard
+    if sync_mode is not None:
+        model.synchronize()  # raises on a device-side time-out of any call of the shard
     if not gather:
         return outs
     return gather_outputs([outs[i] for i in mine], mine, len(signals))
