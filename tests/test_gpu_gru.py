@@ -32,6 +32,29 @@ def test_ring_kernel_matches_polling_wave_kernel(name, B, monkeypatch):
     model.reset_workspace()
 
 
+@pytest.mark.parametrize("name,B", [("PP16", 1), ("PP16", 3), ("PP24", 1)])
+def test_ring_kernel_gather_layouts_agree(name, B, monkeypatch):
+    """The ring kernel's gather layouts and cluster splits against each other (OU_GRU_UPW: 17 = round-2 layout, every unit's
+    16 lanes hold all H columns; 16 / 8 = wide layout -- a lane holds its granule pairs for all units of the wave, partial
+    sums folded with v_permlane32/16_swap -- with 16 / 8 units per workgroup; 0 = the launcher's choice).  Same recurrence;
+    the summation order inside a row differs."""
+    model, spec, sd = get_model(name)
+    T = spec.tot_ds * 41 + 5
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(37, 3, B, Tp)
+    monkeypatch.setenv("OU_GRU_UPW", "17")
+    model.reset_workspace()
+    ref = run_enhance(model, mix, nz, n_steps=3)
+    # (8 units per workgroup at H = 384 are 48-workgroup clusters: more than an XCD's 32 CUs, not offered by the launcher)
+    for code in ("16", "8", "0") if name != "PP24" else ("16", "0"):
+        monkeypatch.setenv("OU_GRU_UPW", code)
+        out = run_enhance(model, mix, nz, n_steps=3)
+        assert torch.equal(out, run_enhance(model, mix, nz, n_steps=3))
+        record(f"gru.layout_vs_round2.{name}.b{B}.upw{code}", O.si_sdr(ref, out), 90)
+    model.reset_workspace()
+
+
 def test_ring_kernel_epoch_wrap(monkeypatch):
     """Tags are epoch + step with a device-side epoch that only grows; near 2^31 the last block of a launch clears the
     exchange area and restarts.  Poke the stored epochs close to the limit and run across it."""
