@@ -2738,7 +2738,56 @@ __global__ __launch_bounds__(1024) void pad_normalize_kernel(const float* __rest
   const float* xb = mix + (size_t)b * T_raw;
   // (one CU per utterance and three dependent passes: the loops are unrolled by hand so that 8 loads are in flight per
   // thread -- same elements per thread, same order of the double sums as the plain loop)
-  constexpr int U = 8;
+  constexpr int U = 8, NREG = 64;
+  float* yb = y + (size_t)b * T_pad;
+  if (T_raw <= NREG * 1024) {
+    // utterances of up to 65 536 samples (4 s at 16 kHz): every thread keeps its <= 64 samples in registers -- ONE trip to
+    // memory with all loads in flight instead of three dependent passes (26 -> ~6 us at batch 1, where this kernel is the
+    // first link of the chain).  Same elements per thread and the same order of the double sums as the loops below.
+    // (buffer instructions: one VGPR offset for all 64 accesses, the k-th sample 4096 k bytes further in the SGPR offset;
+    // samples past the end of the row read as 0 and stores past the end of the padded row are dropped by the bounds check)
+    float v[NREG];
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)T_raw * 4u);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(yb, (unsigned)T_pad * 4u);
+    const int nk = (T_raw - tid + 1023) >> 10;  // this thread's samples: tid + 1024 k, k < nk
+#pragma unroll
+    for (int k = 0; k < NREG; k++) v[k] = buf_load(rx, tid * 4, k * 4096);
+    double s = 0, sq = 0;
+#pragma unroll
+    for (int k = 0; k < NREG; k++) {  // (+ 0.0 past the end: exact)
+      // (the empty asm ties sample k to the running sums: without it the scheduler converts all 64 samples to double
+      // first -- 128 more live registers, spills)
+      asm volatile("" : "+v"(v[k]), "+v"(s), "+v"(sq));
+      const double d = v[k]; s += d; sq += d * d;
+    }
+    s = block_sum(s, shd);
+    sq = block_sum(sq, shd);
+    const float mean = (float)(s / T_pad);  // norm.py:62  (mean over the padded signal)
+    double ss = 0;
+#pragma unroll
+    for (int k = 0; k < NREG; k++) {
+      asm volatile("" : "+v"(v[k]), "+v"(ss));
+      const double d = k < nk ? (double)(v[k] - mean) : 0.0; ss += d * d;
+    }
+    ss = block_sum(ss, shd);
+    ss += (double)(T_pad - T_raw) * (double)(0.f - mean) * (double)(0.f - mean);
+    float sd = (float)sqrt(ss / (double)(T_pad - 1));  // unbiased std, norm.py:22-23
+    sd = fmaxf(sd, 1e-5f);
+    const float gain = level / sd;
+    // a sample past the end is 0 here, i.e. exactly the padding value (0 - mean) * gain of the position it lands on
+#pragma unroll
+    for (int k = 0; k < NREG; k++) buf_store((v[k] - mean) * gain, ry, (pad_left + tid) * 4, k * 4096);
+    const float pv = (0.f - mean) * gain;  // the rest of the padding
+    for (int t = tid; t < pad_left; t += 1024) yb[t] = pv;
+    for (int t = pad_left + NREG * 1024 + tid; t < T_pad; t += 1024) yb[t] = pv;
+    if (tid == 0) {
+      stats[b * 4 + 0] = mean;
+      stats[b * 4 + 1] = gain;
+      stats[b * 4 + 2] = (float)sqrt(sq / (double)T_raw);
+      stats[b * 4 + 3] = 0.f;
+    }
+    return;
+  }
   double s = 0, sq = 0;
   {
     int t = tid;
@@ -2771,7 +2820,6 @@ __global__ __launch_bounds__(1024) void pad_normalize_kernel(const float* __rest
   float sd = (float)sqrt(ss / (double)(T_pad - 1));  // unbiased std, norm.py:22-23
   sd = fmaxf(sd, 1e-5f);
   const float gain = level / sd;
-  float* yb = y + (size_t)b * T_pad;
 #pragma unroll 8
   for (int t = tid; t < T_pad; t += 1024) {
     int tr = t - pad_left;
@@ -2791,6 +2839,70 @@ hipError_t launch_pad_normalize(const float* mix, float* y, float* stats, int B,
   return hipGetLastError();
 }
 
+// post_kernel for utterances of up to 65 536 samples: as in pad_normalize_kernel the thread's samples stay in registers -- one
+// trip to memory with all loads in flight instead of three dependent passes (25 -> ~6 us at batch 1, where this kernel is the
+// last link of the chain).  Same elements per thread, same order of the double sum.  (A kernel of its own: sharing a
+// function with the general loops below costs SGPR spills.)
+constexpr int POST_NREG = 64;
+__global__ __launch_bounds__(1024) void post_reg_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                        float* __restrict__ out, int T_raw, int T_pad, int pad_left,
+                                                        int keep_rms, int peak_guard) {
+  constexpr int NREG = POST_NREG;
+  __shared__ double shd[16];
+  __shared__ float shf[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* xb = x + (size_t)b * T_pad + pad_left;
+  float g = 1.f;
+  {
+    float v[NREG];
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)T_raw * 4u);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)b * T_raw, (unsigned)T_raw * 4u);
+    int so = 0;  // the k-th access 4096 k bytes further: ONE scalar offset stepped by asm (64 constants would spill SGPRs)
+#pragma unroll
+    for (int k = 0; k < NREG; k++) {
+      v[k] = buf_load(rx, tid * 4, so);  // 0 past the end
+      asm volatile("s_add_u32 %0, %0, 0x1000" : "+s"(so) : : "scc");
+    }
+    if (keep_rms) {  // universe.py:352-354
+      double sq = 0;
+#pragma unroll
+      for (int k = 0; k < NREG; k++) {
+        // the conversion as asm that also "touches" the running sum: one sample at a time (see pad_normalize_kernel); the
+        // sample registers themselves stay untouched -- redefining them inside this branch costs 64 phi copies at its end
+        double d;
+        asm volatile("v_cvt_f64_f32 %0, %2" : "=v"(d), "+v"(sq) : "v"(v[k]));
+        sq += d * d;
+      }
+      sq = block_sum(sq, shd);
+      const float x_rms = fmaxf((float)sqrt(sq / T_raw), 1e-5f);
+      g = stats[b * 4 + 2] / x_rms;
+    }
+    // scaled in place once (g = 1 without keep_rms: x * 1 is x): the same product feeds the peak and the output
+#pragma unroll
+    for (int k = 0; k < NREG; k++) v[k] = v[k] * g;
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < NREG; k++) mx = fmaxf(mx, fabsf(v[k]));
+    mx = block_max(mx, shf);
+    const bool div = peak_guard && mx > 1.0f;  // universe.py:356-357
+    if (div) {
+      so = 0;
+#pragma unroll
+      for (int k = 0; k < NREG; k++) {
+        buf_store(v[k] / mx, ro, tid * 4, so);  // (dropped past the end)
+        asm volatile("s_add_u32 %0, %0, 0x1000" : "+s"(so) : : "scc");
+        __builtin_amdgcn_sched_barrier(0);      // one division's worth of temporaries at a time
+      }
+    } else {
+      so = 0;
+#pragma unroll
+      for (int k = 0; k < NREG; k++) {
+        buf_store(v[k], ro, tid * 4, so);
+        asm volatile("s_add_u32 %0, %0, 0x1000" : "+s"(so) : : "scc");
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(1024) void post_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                     float* __restrict__ out, int T_raw, int T_pad, int pad_left,
                                                     int keep_rms, int peak_guard) {
@@ -2824,8 +2936,12 @@ __global__ __launch_bounds__(1024) void post_kernel(const float* __restrict__ x,
 }
 hipError_t launch_post(const float* x, const float* stats, float* out, int B, int T_raw, int T_pad, int pad_left,
                        int keep_rms, int peak_guard, hipStream_t st) {
-  hipLaunchKernelGGL(post_kernel, dim3(B), dim3(1024), 0, st, x, stats, out, T_raw, T_pad, pad_left, keep_rms,
-                     peak_guard);
+  if (T_raw <= POST_NREG * 1024)
+    hipLaunchKernelGGL(post_reg_kernel, dim3(B), dim3(1024), 0, st, x, stats, out, T_raw, T_pad, pad_left, keep_rms,
+                       peak_guard);
+  else
+    hipLaunchKernelGGL(post_kernel, dim3(B), dim3(1024), 0, st, x, stats, out, T_raw, T_pad, pad_left, keep_rms,
+                       peak_guard);
   return hipGetLastError();
 }
 
