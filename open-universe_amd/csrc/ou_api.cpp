@@ -98,7 +98,7 @@ struct Tensor {
 // Tuning / debug switches, read ONCE per C-ABI call: a forward walks ~400 launches and used to call getenv
 // eight times for each of them (a linear scan of the environment: a third of the host time of an enhance call).
 struct EnvCfg {
-  int dbg = 0, xcd_map = -1, conv_direct = 3, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1;
+  int dbg = 0, xcd_map = -1, conv_direct = 3, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0;
   int gru_v = 2, gru_bmax = 0, gru_ts = 0, gru_upw = 0, gru_backoff = 0, gru_agent = -1, gru_dbg = 0;
   double tile_min = -1.0;  // < 0: the launcher's default
   int tile_prefetch = 1;
@@ -108,6 +108,7 @@ struct EnvCfg {
     dbg = geti("OU_DBG", 0); xcd_map = geti("OU_XCD_MAP", -1); conv_direct = geti("OU_CONV_DIRECT", 3);
     fuse = geti("OU_FUSE", -1); fuse_nc = geti("OU_FUSE_NC", 0); rate_small = geti("OU_RATE_SMALL", 1);
     fuse_upfir = geti("OU_FUSE_UPFIR", 1);
+    block3 = geti("OU_BLOCK3", 0);
     gru_v = geti("OU_GRU_V", 2); gru_bmax = geti("OU_GRU_BMAX", 0); gru_ts = std::getenv("OU_GRU_TS") ? 1 : 0;
     gru_upw = geti("OU_GRU_UPW", 0); gru_backoff = geti("OU_GRU_BACKOFF", 0); gru_agent = geti("OU_GRU_AGENT_STORES", -1);
     gru_dbg = geti("OU_GRU_DBG", 0);
@@ -200,6 +201,11 @@ struct Runner {
     bool rate_up = false;  // the last up conv on rate_up_kernel (`fir` = the filter AFTER the conv or null, fir_bias / res)
   };
   bool unsupported = false;
+  // conv() in collect mode: the launch arguments are appended here instead of being launched (block(): the three body convs
+  // of a deep-level ConvBlock in one launch, conv_block3_kernel)
+  std::vector<ConvArgs>* collect = nullptr;
+  unsigned* status_words = nullptr;        // workspace header (layout_persist)
+  unsigned long long* block3_bar = nullptr;
   bool gru_shared = false;  // GRU launches enqueued now may run beside another GRU layer (overlapped conditioner / score pass)
 
   Tensor conv(const ConvL& L, const Tensor& in, const std::string& name, const Epi& e, const Tensor* dst = nullptr) {
@@ -225,6 +231,7 @@ struct Runner {
     a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct;
     a.tile_min = env.tile_min; a.tile_prefetch = env.tile_prefetch;
     a.tstamps = h->tstamps;
+    if (collect) { collect->push_back(a); return out; }
     int cfg = -1;
     if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {
       ou_handle::ProfRec rec;
@@ -409,12 +416,41 @@ struct Runner {
         h->n_conv++;
       }
     } else {
-      conv(Bk.c1, hu, nm + ".c1", e1, &c1);
-      conv(Bk.c2, c1, nm + ".c2", Epi(), &c2);
       Epi e3;
       e3.res = hu.p; e3.res_scale = kInvSqrt2;  // blocks.py:399
       if (dry) e3.res = nullptr;
-      conv(Bk.c3, c2, nm + ".v", e3, &v);
+      // Deep levels at batch 1: the three convs in ONE launch (conv_block3_kernel) where the shape fits -- on the caller's
+      // stream only (its workgroups wait for each other: one such kernel at a time), not while profiling per layer.
+      // OFF by default (OU_BLOCK3=1): measured 47.2 / 46.5 us per fused launch (C = 512 / 256) against 41.9 / 41.7 us of
+      // kernel time + two ~1.2 us dispatch gaps for the three launches it replaces, 7.59-7.66 vs 7.33 ms per enhance
+      // (DESIGN.md 4.6).
+      bool fused = false;
+      if (!dry && ok() && env.block3 != 0 && B == 1 && st == main_st && block3_bar && !h->profile && !h->tstamps &&
+          h->force_cfg < 0 && env.conv_direct >= 2) {
+        std::vector<ConvArgs> cv;
+        collect = &cv;
+        conv(Bk.c1, hu, nm + ".c1", e1, &c1);
+        conv(Bk.c2, c1, nm + ".c2", Epi(), &c2);
+        conv(Bk.c3, c2, nm + ".v", e3, &v);
+        collect = nullptr;
+        int cfg = -1;
+        const hipError_t le = cv.size() == 3 ? launch_conv_block3(cv.data(), block3_bar, status_words, h->num_cu, st, &cfg)
+                                             : hipErrorInvalidConfiguration;
+        if (le == hipSuccess) {
+          fused = true;
+          h->last_cfg = cfg;
+          h->n_conv++;
+          if (h->trace)
+            std::fprintf(stderr, "OU_TRACE block3 %-62s cfg=%d C=%d T=%d\n", nm.c_str(), cfg, Bk.C, hu.T);
+        } else if (le != hipErrorInvalidConfiguration) {
+          chk(le, nm.c_str());
+        }
+      }
+      if (!fused) {
+        conv(Bk.c1, hu, nm + ".c1", e1, &c1);
+        conv(Bk.c2, c1, nm + ".c2", Epi(), &c2);
+        conv(Bk.c3, c2, nm + ".v", e3, &v);
+      }
     }
     BlockOut o;
     o.v = v; o.c1 = c1; o.h_next = v;
@@ -496,7 +532,9 @@ struct Persist {
 Persist layout_persist(Runner& r, int T) {
   const Model& m = r.h->m;
   Persist P;
-  P.status = (unsigned*)r.alloc_raw(64);
+  P.status = (unsigned*)r.alloc_raw(128);  // 64 status / diagnostics words + the fused ConvBlock kernel's barrier words
+  r.status_words = P.status;
+  r.block3_bar = (unsigned long long*)(P.status + 64);
   int ncoef = kMaxSteps > r.B ? kMaxSteps : r.B;
   P.coef = (StepCoef*)r.alloc_raw((size_t)ncoef * 8);
   P.stats = r.alloc_raw((size_t)r.B * 4);

@@ -486,6 +486,7 @@ static size_t conv_smem_bytes(const ConvCfg& c, const ConvArgs& a) {
 
 static hipError_t init_chain_kernels();
 static hipError_t init_direct3_kernels();
+static hipError_t init_block3_kernels();
 hipError_t init_conv_kernels() {
   hipError_t e_d3 = hipSuccess;
   for (int i = 0; i < kNumConvCfgs; i++) {
@@ -500,6 +501,8 @@ hipError_t init_conv_kernels() {
     if (e != hipSuccess) return e;
   }
   e_d3 = init_direct3_kernels();
+  if (e_d3 != hipSuccess) return e_d3;
+  e_d3 = init_block3_kernels();
   if (e_d3 != hipSuccess) return e_d3;
   return init_chain_kernels();
 }
@@ -725,8 +728,10 @@ struct DirectEpilogue {
     }
   }
 
+  // [c_lo, c_hi): output columns this tile may STORE (plain up == 1 path only; the fused ConvBlock kernel computes halo
+  // columns that belong to a neighbouring tile group)
   static __device__ __forceinline__ void run(const ConvArgs& p, const floatx16 (&acc)[TN], float* Es, int tid, int kw,
-                                             int b, int m0, int n0) {
+                                             int b, int m0, int n0, int c_lo = 0, int c_hi = 0x7fffffff) {
     const int lane = tid & 63, lhalf = lane >> 5, l31 = lane & 31;
     const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
     int m_hi = m0 + BM - 1;
@@ -737,12 +742,15 @@ struct DirectEpilogue {
     // staged, so their latency overlaps the LDS traffic and the barrier
     const bool plain = p.up == 1 && !p.fir;
     const int eq = (tid % C4) * 4, er = tid / C4;
-    const bool e_on = plain && er < BM && m0 + er <= m_hi && n0 + eq < p.Nq;
+    const bool e_on = plain && er < BM && m0 + er <= m_hi && n0 + eq < p.Nq && n0 + eq + 4 > c_lo && n0 + eq < c_hi;
     const int m = m0 + er;
     const size_t eidx = ybase + (size_t)m * p.Tout + n0 + eq;
     int e_n = p.Nq - (n0 + eq);
     if (e_n > 4) e_n = 4;
-    const bool vec4 = (p.Tout & 3) == 0;  // (then Nq is a multiple of 4 too and the quad is complete)
+    if (e_n > c_hi - (n0 + eq)) e_n = c_hi - (n0 + eq);
+    const int e_0 = c_lo - (n0 + eq) > 0 ? c_lo - (n0 + eq) : 0;  // first element of the quad inside the store range
+    // 16-byte accesses: rows are 16-byte multiples (then Nq is a multiple of 4 too) and the quad is inside the store range
+    const bool vec4 = (p.Tout & 3) == 0 && e_0 == 0 && e_n == 4;
     f32x4 ad = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
     float bi = 0.f, ga = 1.f, be = 0.f;
     if (e_on) {
@@ -752,8 +760,8 @@ struct DirectEpilogue {
       } else {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          if (p.add && j < e_n) ad[j] = p.add[eidx + j];
-          if (p.res && j < e_n) rs[j] = p.res[eidx + j];
+          if (p.add && j >= e_0 && j < e_n) ad[j] = p.add[eidx + j];
+          if (p.res && j >= e_0 && j < e_n) rs[j] = p.res[eidx + j];
         }
       }
       bi = p.bias[m];
@@ -801,7 +809,7 @@ struct DirectEpilogue {
       } else {
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (j < e_n) p.y[eidx + j] = v[j];
+          if (j >= e_0 && j < e_n) p.y[eidx + j] = v[j];
       }
       return;
     }
@@ -1007,8 +1015,10 @@ __device__ __forceinline__ void direct2_mma(const f32x4& a4, float a1, const f32
 // 16-byte load returns the neighbouring row's samples, not zeros.  Same K order per output element as
 // conv_direct_kernel (pairs in ring order, taps ascending): bit-identical results.
 // ---------------------------------------------------------------------------------------------------------
+// (the tile body is a device function: conv_direct2_kernel runs it once per block, conv_block3_kernel three times with a
+// group barrier in between; [c_lo, c_hi) = columns the tile may store)
 template <int KW, int TN>
-__global__ __launch_bounds__(512) void conv_direct2_kernel(ConvArgs p) {
+__device__ __forceinline__ void direct2_tile(const ConvArgs& p, float* smem, int b, int m0, int n0, int c_lo, int c_hi) {
   constexpr int D = 4, W = KW + TN - 1, KWP = KW == 3 ? 4 : 8, PAD = (KW - 1) / 2;
   constexpr int B2 = W - 4;                    // elements in the second B load: 0 (none), 1 (dword), 2 (dwordx2)
   constexpr int A2 = KW - 4 > 0 ? KW - 4 : 0;  // elements in the second A load: 0 / 1
@@ -1016,13 +1026,8 @@ __global__ __launch_bounds__(512) void conv_direct2_kernel(ConvArgs p) {
   static_assert(KW == 3 || KW == 5, "k3 / k5");
   static_assert(B2 >= -1 && B2 <= 2 && D * LPS <= 60, "window / vmcnt");
   constexpr int BN = 32 * TN;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int kw = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int tile_m, tile_n;
-  if (!direct_tile(p, tile_m, tile_n)) return;
-  const int n0 = tile_n * BN, m0 = tile_m * 32, b = blockIdx.z;
-  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
   const int lhalf = lane >> 5, l31 = lane & 31;
   const int Tin = p.Tin, Mp = p.Mp;
   const float alpha = p.act ? p.alpha_val : 1.0f;
@@ -1097,14 +1102,149 @@ __global__ __launch_bounds__(512) void conv_direct2_kernel(ConvArgs p) {
   if (ts_on) c4 = __builtin_readcyclecounter();
 #undef OU_ISSUE
 #undef OU_MMA
-  DirectEpilogue<TN, true>::run(p, acc, smem, tid, kw, b, m0, n0);
+  DirectEpilogue<TN, true>::run(p, acc, smem, tid, kw, b, m0, n0, c_lo, c_hi);
   if (ts_on && lane == 0) {
     const long long c5 = __builtin_readcyclecounter();
     long long* o = p.tstamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + kw) * 8;
     o[0] = r0; o[1] = c1 - c0; o[2] = (NR > 1 ? c2 : c4) - c1; o[3] = NR > 1 ? c3 - c2 : 0; o[4] = c4 - c3; o[5] = c5 - c4;
     o[6] = 0; o[7] = (long long)__builtin_amdgcn_s_memrealtime();
   }
-  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+template <int KW, int TN>
+__global__ __launch_bounds__(512) void conv_direct2_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int tile_m, tile_n;
+  if (!direct_tile(p, tile_m, tile_n)) return;
+  if (p.prof && threadIdx.x == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  direct2_tile<KW, TN>(p, smem, blockIdx.z, tile_m * 32, tile_n * 32 * TN, 0, 0x7fffffff);
+  if (p.prof && threadIdx.x == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_block3_kernel: the three body convs of a deep-level ConvBlock (k5 -> k3 -> k3, C >= 256, a few hundred to a few
+// thousand frames, batch 1) in ONE launch.  The time axis is cut into eight windows, one per XCD: the 32 workgroups that
+// the dispatcher places on XCD x (block ids congruent to x mod 8) compute ALL output channels of window x for all three
+// convs, so everything a conv reads from its predecessor was written on the same XCD and is served by that XCD's L2 --
+// plain stores, plain loads, no write-back, and only a 32-member barrier between the convs.  The halo (2 + 1 columns either
+// side) is recomputed inside the window: it fits the columns the 32-column tiles waste today (401 frames = 8 x 51, window 55,
+// two tiles = 64; 2005 = 8 x 251, window 255, four 64-column tiles = 256), and a window stores, per conv, only the columns
+// that are valid there (conv1: the whole window -- it depends on the block input alone; conv2: own range +- 1; conv3: own
+// range); overlapping stores of neighbouring windows carry bit-identical values.  Same tile body, same K order, same
+// epilogues as three conv_direct2_kernel launches: bit-identical results.
+// The placement is checked, not assumed: every workgroup adds its XCC id to its group's mask, a group that spans XCDs
+// raises status bit 32 (the host falls back to separate launches for good); the barrier itself uses agent-scope atomics and
+// is correct under any placement; spins are bounded (status bit 16).
+// ---------------------------------------------------------------------------------------------------------
+struct Block3Args {
+  ConvArgs cv[3];
+  unsigned long long* bar;  // per XCD: {generation << 32 | arrivals}, XCC mask  (2 x 8 bytes)
+  unsigned* err;            // sticky status word
+  int cpx;                  // columns per window = ceil(T / 8)
+  int ncolt;                // column tiles per window
+  int nrow;                 // 32-row tiles
+};
+__device__ __attribute__((noinline)) void block3_barrier(unsigned long long* word, unsigned nact, unsigned* err,
+                                                         unsigned* clear) {
+  const unsigned long long old = __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned g = (unsigned)(old >> 32);
+  if ((unsigned)old == nact - 1u) {  // last arrival: arrivals -> 0, generation + 1, in one atomic
+    if (clear) __hip_atomic_store(clear, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(word, (1ull << 32) - (unsigned long long)nact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  unsigned spins = 0;
+  while ((unsigned)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == g) {
+    if (++spins > 20000000u) { atomicOr(err, 16u); return; }
+  }
+}
+template <int TN>
+__global__ __launch_bounds__(512) void conv_block3_kernel(Block3Args a) {
+  constexpr int BN = 32 * TN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const unsigned nact = (unsigned)(a.nrow * a.ncolt);
+  const int T = a.cv[0].Nq;
+  const int own_lo = xcd * a.cpx, own_hi = own_lo + a.cpx < T ? own_lo + a.cpx : T;
+  if ((unsigned)slot >= nact || own_lo >= T) return;  // (whole groups: the members of a group agree on both)
+  const int tile_m = slot / a.ncolt, jt = slot - tile_m * a.ncolt;
+  const int win0 = xcd == 0 ? 0 : own_lo - 2;
+  const int m0 = tile_m * 32, n0 = win0 + BN * jt;
+  unsigned long long* word = a.bar + 2 * xcd;
+  unsigned* mask = reinterpret_cast<unsigned*>(a.bar + 2 * xcd + 1);
+  if (tid == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    __hip_atomic_fetch_or(mask, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  direct2_tile<5, TN>(a.cv[0], smem, 0, m0, n0, 0, 0x7fffffff);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores are in L2
+  __syncthreads();
+  __shared__ int sh_cross;
+  if (tid == 0) {
+    block3_barrier(word, nact, a.err, nullptr);
+    const unsigned mk = __hip_atomic_load(mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // a group that spans XCDs (never observed; OU_DBG 64 forces the path for the tests): its plain stores are not visible
+    // to all members -- status word 34 counts, and the hand-overs below become agent-scope release / acquire pairs
+    sh_cross = (__popc(mk) != 1 || (a.cv[0].dbg & 64)) ? 1 : 0;
+    if (sh_cross && slot == 0) atomicAdd(a.err + 34, 1u);
+  }
+  __syncthreads();
+  const bool cross = sh_cross != 0;
+  if (cross) {  // conv1's stores were plain: write the L2 back, meet again, drop what this L2 / L1 hold of other XCDs' lines
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) block3_barrier(word, nact, a.err, nullptr);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  direct2_tile<3, TN>(a.cv[1], smem, 0, m0, n0, xcd == 0 ? 0 : own_lo - 1, own_hi + 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (cross) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  // (everybody has read the mask by now: the last arrival clears it for the next launch)
+  if (tid == 0) block3_barrier(word, nact, a.err, mask);
+  __syncthreads();
+  if (cross) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  direct2_tile<3, TN>(a.cv[2], smem, 0, m0, n0, own_lo, own_hi);
+}
+static hipError_t init_block3_kernels() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+}
+// cv[0..2] = conv1 (k5), conv2 (k3), conv3 (k3) of one ConvBlock as conv() would launch them.  hipErrorInvalidConfiguration:
+// not a shape for this kernel (the caller launches the three convs separately).
+hipError_t launch_conv_block3(const ConvArgs* cv, unsigned long long* bar, unsigned* err, int num_cu, hipStream_t st,
+                              int* cfg_out) {
+  if (num_cu != 256 || !bar || !err) return hipErrorInvalidConfiguration;
+  const int C = cv[0].Cin, T = cv[0].Nq;
+  const int kws[3] = {5, 3, 3};
+  for (int s = 0; s < 3; s++) {
+    const ConvArgs& a = cv[s];
+    if (a.B != 1 || a.KW != kws[s] || a.stride != 1 || a.up != 1 || a.pad != (a.KW - 1) / 2 || !a.wd || a.fir || a.in_scale ||
+        a.Cin != C || a.M != C || a.Cout != C || a.Nq != T || a.Tin != T || a.Tout != T || a.force_cfg >= 0 || a.prof ||
+        a.tstamps)
+      return hipErrorInvalidConfiguration;
+    if ((long)a.Cin * a.Tin * 4 >= (1L << 31) || (long)a.Cin * a.Mp * 8 * 4 >= (1L << 31)) return hipErrorInvalidConfiguration;
+  }
+  if (C % 64 || C < 256 || T < 64) return hipErrorInvalidConfiguration;
+  if (cv[1].x != cv[0].y || cv[2].x != cv[1].y) return hipErrorInvalidConfiguration;
+  const int nrow = C / 32, cpx = (T + 7) / 8, win = cpx + 4;
+  int tn = 0, ncolt = 0;
+  for (int t = 1; t <= 2; t++) {
+    const int n = (win + 32 * t - 1) / (32 * t);
+    if (nrow * n <= 32) { tn = t; ncolt = n; break; }
+  }
+  if (!tn) return hipErrorInvalidConfiguration;
+  Block3Args ba;
+  for (int s = 0; s < 3; s++) ba.cv[s] = cv[s];
+  ba.bar = bar; ba.err = err; ba.cpx = cpx; ba.ncolt = ncolt; ba.nrow = nrow;
+  const size_t smem = (size_t)8 * 32 * (32 * tn + 4) * 4;
+  if (cfg_out) *cfg_out = 300 + tn;
+  if (tn == 1) hipLaunchKernelGGL(conv_block3_kernel<1>, dim3(256), dim3(512), smem, st, ba);
+  else hipLaunchKernelGGL(conv_block3_kernel<2>, dim3(256), dim3(512), smem, st, ba);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------

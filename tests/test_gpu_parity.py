@@ -506,3 +506,26 @@ def test_throughput_conv_kernel_matches_split_k_kernels(name, B, T, monkeypatch)
     e_ref = O.enhance(sd, sdict, mix, n_steps=3, noise=nz)
     record(f"direct3_vs_oracle.{name}.b{B}", O.si_sdr(e_ref, out.cpu()), 80)
     assert n_conv > 0
+
+
+@pytest.mark.parametrize("T", [64000, 7213])
+def test_fused_deep_convblock_is_bit_identical(T, monkeypatch):
+    """OU_BLOCK3=1: the three body convs (k5, k3, k3) of the 256- / 512-channel ConvBlocks of UNIVERSE++ at batch 1 in ONE
+    launch (conv_block3_kernel: one time window per XCD, halo recomputed, a 32-workgroup barrier between the convs; off by
+    default -- it is slower than three launches).  Same tile body, same K order: the enhanced signal is
+    bit-identical to the separate launches', with fewer launches; OU_DBG=64 forces the agent-scope release / acquire
+    hand-over that a group spanning XCDs would take."""
+    model, spec, sd = get_model("PP16")
+    mix = synth_mix(spec, 1, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(43, 2, 1, Tp)
+    ref = run_enhance(model, mix, nz, n_steps=2)
+    n_ref = sum(model.launch_stats())
+    monkeypatch.setenv("OU_BLOCK3", "1")
+    out = run_enhance(model, mix, nz, n_steps=2)
+    n_fused = sum(model.launch_stats())
+    assert torch.equal(ref, out)
+    if T == 64000:
+        assert n_fused < n_ref  # (short signals: windows of < 64 frames are not taken)
+    monkeypatch.setenv("OU_DBG", "64")
+    assert torch.equal(ref, run_enhance(model, mix, nz, n_steps=2))
