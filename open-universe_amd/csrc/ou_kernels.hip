@@ -1177,10 +1177,18 @@ __global__ __launch_bounds__(512) void conv_block3_kernel(Block3Args a) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     __hip_atomic_fetch_or(mask, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  const int dbg = a.cv[0].dbg;  // timing experiments (results invalid): 128 no barriers, 256 conv1 only, 512 conv1 + conv2
   direct2_tile<5, TN>(a.cv[0], smem, 0, m0, n0, 0, 0x7fffffff);
+  if (dbg & 256) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores are in L2
   __syncthreads();
   __shared__ int sh_cross;
+  if (dbg & 128) {
+    direct2_tile<3, TN>(a.cv[1], smem, 0, m0, n0, xcd == 0 ? 0 : own_lo - 1, own_hi + 1);
+    __syncthreads();
+    direct2_tile<3, TN>(a.cv[2], smem, 0, m0, n0, own_lo, own_hi);
+    return;
+  }
   if (tid == 0) {
     block3_barrier(word, nact, a.err, nullptr);
     const unsigned mk = __hip_atomic_load(mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1199,6 +1207,7 @@ __global__ __launch_bounds__(512) void conv_block3_kernel(Block3Args a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   direct2_tile<3, TN>(a.cv[1], smem, 0, m0, n0, xcd == 0 ? 0 : own_lo - 1, own_hi + 1);
+  if (dbg & 512) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (cross) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
