@@ -421,9 +421,8 @@ struct Runner {
       if (dry) e3.res = nullptr;
       // Deep levels at batch 1: the three convs in ONE launch (conv_block3_kernel) where the shape fits -- on the caller's
       // stream only (its workgroups wait for each other: one such kernel at a time), not while profiling per layer.
-      // OFF by default (OU_BLOCK3=1): measured 47.2 / 46.5 us per fused launch (C = 512 / 256) against 41.9 / 41.7 us of
-      // kernel time + two ~1.2 us dispatch gaps for the three launches it replaces, 7.59-7.66 vs 7.33 ms per enhance
-      // (DESIGN.md 4.6).
+      // OFF by default (OU_BLOCK3=1): 41.7 / 42.3 us per fused launch (C = 512 / 256) against 44.3 / 44.1 us for the three
+      // launches with their gaps, and no difference in the enhance time.
       bool fused = false;
       if (!dry && ok() && env.block3 != 0 && B == 1 && st == main_st && block3_bar && !h->profile && !h->tstamps &&
           h->force_cfg < 0 && env.conv_direct >= 2) {
@@ -532,7 +531,8 @@ struct Persist {
 Persist layout_persist(Runner& r, int T) {
   const Model& m = r.h->m;
   Persist P;
-  P.status = (unsigned*)r.alloc_raw(128);  // 64 status / diagnostics words + the fused ConvBlock kernel's barrier words
+  // 64 status / diagnostics words + the fused ConvBlock kernel's barrier area (8 groups x 40 x 8 bytes)
+  P.status = (unsigned*)r.alloc_raw(64 + 8 * 40 * 2);
   r.status_words = P.status;
   r.block3_bar = (unsigned long long*)(P.status + 64);
   int ncoef = kMaxSteps > r.B ? kMaxSteps : r.B;

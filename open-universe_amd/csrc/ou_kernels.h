@@ -161,7 +161,7 @@ struct ChainArgs {
 double chain_cost(const ChainArgs& a, int num_cu, int* nc_out);
 hipError_t launch_chain(const ChainArgs& a, int num_cu, hipStream_t st, int* variant);
 // the three body convs of a deep-level ConvBlock (k5, k3, k3; batch 1) in one launch; hipErrorInvalidConfiguration = not a
-// shape for it.  `bar`: 16 x 8 zero-initialised bytes that only this kernel touches, `err`: the status words
+// shape for it.  `bar`: 8 x 40 x 8 zero-initialised bytes that only this kernel touches, `err`: the status words
 hipError_t launch_conv_block3(const ConvArgs* cv, unsigned long long* bar, unsigned* err, int num_cu, hipStream_t st,
                               int* cfg_out);
 
