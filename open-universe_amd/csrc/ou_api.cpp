@@ -422,7 +422,7 @@ struct Runner {
       // Deep levels at batch 1: the three convs in ONE launch (conv_block3_kernel) where the shape fits -- on the caller's
       // stream only (its workgroups wait for each other: one such kernel at a time), not while profiling per layer.
       // OFF by default (OU_BLOCK3=1): 41.7 / 42.3 us per fused launch (C = 512 / 256) against 44.3 / 44.1 us for the three
-      // launches with their gaps, and no difference in the enhance time.
+      // launches with their gaps, and the enhance as a whole 0.1 ms SLOWER with it.
       bool fused = false;
       if (!dry && ok() && env.block3 != 0 && B == 1 && st == main_st && block3_bar && !h->profile && !h->tstamps &&
           h->force_cfg < 0 && env.conv_direct >= 2) {
