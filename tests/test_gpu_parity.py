@@ -529,3 +529,21 @@ def test_fused_deep_convblock_is_bit_identical(T, monkeypatch):
         assert n_fused < n_ref  # (short signals: windows of < 64 frames are not taken)
     monkeypatch.setenv("OU_DBG", "64")
     assert torch.equal(ref, run_enhance(model, mix, nz, n_steps=2))
+
+
+@pytest.mark.parametrize("T", [65535, 65536, 65537])
+@pytest.mark.parametrize("keep_rms", [False, True])
+def test_pad_and_post_kernels_around_their_register_limit(T, keep_rms):
+    """pad_normalize / post keep an utterance of up to 65 536 samples in registers (one trip to memory) and fall back to the
+    three-pass loops beyond: both sides of the limit, with and without the rms restore (universe.py:352-357), against the
+    oracle.  B = 2."""
+    name = "PP16s"
+    model, spec, sd = get_model(name)
+    B = 2
+    mix = synth_mix(spec, B, T, seed=5)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(19, 2, B, Tp)
+    ref = O.enhance(sd, spec.to_dict(), mix, n_steps=2, noise=nz, keep_rms=keep_rms)
+    out = run_enhance(model, mix, nz, n_steps=2, keep_rms=keep_rms)
+    assert out.shape == ref.shape == (B, T)
+    record(f"padpost.T{T}.rms{int(keep_rms)}", O.si_sdr(ref, out))
