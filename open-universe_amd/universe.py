@@ -176,6 +176,11 @@ class Universe:
             # [32] max tag seen, [36..]: (step << 8 | xcc now << 4 | xcc at the rendezvous) of every member of that cluster
             # that was itself stuck in a long wait (0xFFFFFFFF: slot not of this launch); [21..29]: first-recovery record
             members = [("-" if m == -1 else f"{(m & 0xFFFFFFFF) >> 8}@x{m & 0xFF:02x}") for m in diag[36:60]]
+            if v & 16 and not v & ~16:
+                # bit 16: the barrier of the fused deep-ConvBlock launch (conv_block3_kernel, OU_BLOCK3=1 only) ran out
+                raise RuntimeError("device-side timeout in the fused ConvBlock launch's group barrier (status word 16, "
+                                   "OU_BLOCK3=1); the output of that call is invalid and the workspace has to be "
+                                   "re-initialised (Universe.reset_workspace())")
             raise RuntimeError(f"device-side timeout in the GRU cluster exchange (status word {v}, diagnostics "
                                f"{diag[8:20]}, max tag {diag[32] & 0xFFFFFFFF}, first recovery record {diag[21:30]}, "
                                f"members' waits {members}); the output of that call is invalid")
