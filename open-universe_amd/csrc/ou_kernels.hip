@@ -2565,6 +2565,55 @@ __global__ __launch_bounds__(64 * MT * NWN) void rate_up_kernel(ConvArgs p) {
   const int Cout = p.Cout;
   const int span = BV * R;  // output samples per channel
   const int total = Cout * span;
+  // Rows that are 16-byte multiples: four consecutive samples per thread -- one float4 of the residual in, one float4 out
+  // (a tile's samples of a channel start at a multiple of span, itself a multiple of 4).  Same arithmetic per sample as the
+  // scalar loop below: bit-identical.  (B = 8: 198 MB per launch at 2.7 TB/s with 4-byte accesses.)
+  if ((p.Tout & 3) == 0 && ((BF * R) & 3) == 0 && ((2 * R) & 3) == 0) {
+    constexpr int QPT = (32 * MT / R * BF * R / 4 + NT - 1) / NT;
+    f32x4 rs4[QPT];
+    size_t idx4[QPT];
+    int co4[QPT], tl4[QPT];
+#pragma unroll
+    for (int u = 0; u < QPT; u++) {
+      const int e = 4 * (tid + u * NT);
+      const int co = e / span, tl = e - co * span + H * R;
+      const long t = (long)q0 * R + tl;
+      const bool on = e < total && t < p.Tout;
+      co4[u] = on ? co : -1; tl4[u] = tl;
+      idx4[u] = on ? ((size_t)b * Cout + co) * p.Tout + (size_t)t : 0;
+      rs4[u] = (on && p.res) ? *reinterpret_cast<const f32x4*>(p.res + idx4[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < QPT; u++) {
+      if (co4[u] < 0) continue;
+      const float* urow = smem + (co4[u] * R) * UP;
+      const float bi = p.bias[co4[u]];
+      f32x4 o;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        const int tl = tl4[u] + s4;
+        float v;
+        if (fir) {
+          int tau = tl - R, qf = tau / R, ph = tau - qf * R;
+          v = 0.f;
+#pragma unroll
+          for (int j = 0; j <= 2 * R; j++) {
+            v = fmaf(f[j], urow[ph * UP + qf], v);
+            if (++ph == R) { ph = 0; qf++; }
+          }
+        } else {
+          const int qf = tl / R, ph = tl - qf * R;
+          v = urow[ph * UP + qf];
+        }
+        v += bi;
+        if (p.res) v = (v + rs4[u][s4]) * p.res_scale;
+        o[s4] = v;
+      }
+      *reinterpret_cast<f32x4*>(p.y + idx4[u]) = o;
+    }
+    if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    return;
+  }
   // outputs in batches of EB per thread: the residual loads of a batch go out together, ahead of the filter
   constexpr int EPT = (32 * MT / R * BF * R + NT - 1) / NT, EB = 8;
   static_assert(EPT % EB == 0, "output batches");
