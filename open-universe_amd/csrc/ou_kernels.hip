@@ -9,6 +9,8 @@ namespace ou {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// a float4 at any 4-byte boundary: global dwordx4 accesses need dword alignment only (rows of 401 / 2005 frames)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -749,14 +751,14 @@ struct DirectEpilogue {
     if (e_n > 4) e_n = 4;
     if (e_n > c_hi - (n0 + eq)) e_n = c_hi - (n0 + eq);
     const int e_0 = c_lo - (n0 + eq) > 0 ? c_lo - (n0 + eq) : 0;  // first element of the quad inside the store range
-    // 16-byte accesses: rows are 16-byte multiples (then Nq is a multiple of 4 too) and the quad is inside the store range
-    const bool vec4 = (p.Tout & 3) == 0 && e_0 == 0 && e_n == 4;
+    // 16-byte accesses wherever the whole quad is stored (dwordx4 at dword alignment: the 401- / 2005-frame levels too)
+    const bool vec4 = e_0 == 0 && e_n == 4;
     f32x4 ad = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
     float bi = 0.f, ga = 1.f, be = 0.f;
     if (e_on) {
       if (vec4) {
-        if (p.add) ad = *reinterpret_cast<const f32x4*>(p.add + eidx);
-        if (p.res) rs = *reinterpret_cast<const f32x4*>(p.res + eidx);
+        if (p.add) ad = *reinterpret_cast<const f32x4u*>(p.add + eidx);
+        if (p.res) rs = *reinterpret_cast<const f32x4u*>(p.res + eidx);
       } else {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -805,7 +807,7 @@ struct DirectEpilogue {
       if (filmb) v = ga * v + be;
       if (p.res) v = (v + rs) * p.res_scale;
       if (vec4) {
-        *reinterpret_cast<f32x4*>(p.y + eidx) = v;
+        *reinterpret_cast<f32x4u*>(p.y + eidx) = v;
       } else {
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -1512,7 +1514,7 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
   const int c0 = n0 + TN * l15;
   int ncol = p.Nq - c0;
   if (ncol > 4) ncol = 4;
-  const bool vec4 = (p.Tout & 3) == 0 && ncol == 4;
+  const bool vec4 = ncol == 4;  // (16-byte accesses at dword alignment: rows of 2005 frames too)
   // PRE (chosen by the launcher: an operand exists, rows are 16-byte multiples -- then every lane has a whole quad or none --
   // and the LDS was provided).  A template parameter, not a branch: a branch here would split the control flow while ring
   // loads are in flight, and the copies the compiler places at the join read registers whose data has not landed.
@@ -1566,8 +1568,8 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
         if (on && filmb) { ga[r] = filmb[row]; be[r] = filmb[p.Cout + row]; }
         if (on && vec4) {
           const f32x4 pq = pre_on ? *reinterpret_cast<const f32x4*>(slab + (4 * i + r) * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-          if (p.add) ad[r] = (pre_on && !p.res) ? pq : *reinterpret_cast<const f32x4*>(p.add + idx);
-          if (p.res) rs[r] = pre_on ? pq : *reinterpret_cast<const f32x4*>(p.res + idx);
+          if (p.add) ad[r] = (pre_on && !p.res) ? pq : f32x4(*reinterpret_cast<const f32x4u*>(p.add + idx));
+          if (p.res) rs[r] = pre_on ? pq : f32x4(*reinterpret_cast<const f32x4u*>(p.res + idx));
         } else if (on) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {
@@ -1588,7 +1590,7 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
         if (filmb) v = ga[r] * v + be[r];
         if (p.res) v = (v + rs[r]) * p.res_scale;
         if (vec4) {
-          *reinterpret_cast<f32x4*>(p.y + idx) = v;
+          *reinterpret_cast<f32x4u*>(p.y + idx) = v;
         } else {
 #pragma unroll
           for (int j = 0; j < 4; j++)
@@ -1711,21 +1713,21 @@ __global__ __launch_bounds__(256, 2) void conv_direct3s_kernel(ConvArgs p) {
     v += p.bias[co];
     if (p.add) {
       f32x4 ad;
-      if (full) ad = *reinterpret_cast<const f32x4*>(p.add + idx);
+      if (full) ad = *reinterpret_cast<const f32x4u*>(p.add + idx);
       else { ad = f32x4{0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; e++) if (e < ncol) ad[e] = p.add[idx + e]; }
       v = (v + ad) * p.add_scale;
     }
     if (filmb) v = filmb[co] * v + filmb[p.Cout + co];
     if (p.res) {
       f32x4 rs;
-      if (full) rs = *reinterpret_cast<const f32x4*>(p.res + idx);
+      if (full) rs = *reinterpret_cast<const f32x4u*>(p.res + idx);
       else { rs = f32x4{0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; e++) if (e < ncol) rs[e] = p.res[idx + e]; }
       v = (v + rs) * p.res_scale;
     }
-    if (full) *reinterpret_cast<f32x4*>(p.y + idx) = v;
+    if (full) *reinterpret_cast<f32x4u*>(p.y + idx) = v;
     else for (int e = 0; e < 4; e++) if (e < ncol) p.y[idx + e] = v[e];
   };
-  const bool al4 = (p.Tout & 3) == 0;
+  const bool al4 = true;  // (16-byte accesses at dword alignment)
   if (up == 1) {
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -3463,7 +3465,7 @@ __global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, c
     y[row + t] = acc;
   }
 }
-// The same pass with 16-byte accesses (rows that are 16-byte multiples, <= 17 taps): a thread loads one float4 of the tile,
+// The same pass with 16-byte accesses (<= 17 taps; global dwordx4 needs dword alignment only, so any row length): a thread loads one float4 of the tile,
 // filters FOUR consecutive outputs from a register window read from LDS with aligned 16-byte reads, and stores one float4
 // (+ one float4 of the residual).  Same tap order per output: bit-identical to fir_kernel.  At batch 8 the scalar form moves
 // 130 MB per launch at 4.0 TB/s.
@@ -3482,7 +3484,7 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
   {
     const int t = t0 + 4 * tid;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t + 3 < T) v = *reinterpret_cast<const f32x4*>(x + row + t);
+    if (t + 3 < T) v = *reinterpret_cast<const f32x4u*>(x + row + t);
     else {
 #pragma unroll
       for (int e = 0; e < 4; e++) if (t + e < T) v[e] = x[row + t + e];
@@ -3511,7 +3513,7 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
   f32x4 rs = {0.f, 0.f, 0.f, 0.f};
   const bool full = t + 3 < T;
   if (res) {
-    if (full) rs = *reinterpret_cast<const f32x4*>(res + row + t);
+    if (full) rs = *reinterpret_cast<const f32x4u*>(res + row + t);
     else {
 #pragma unroll
       for (int e = 0; e < 4; e++) if (t + e < T) rs[e] = res[row + t + e];
@@ -3527,7 +3529,7 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
     if (res) acc = (acc + rs[e]) * res_scale;
     o[e] = acc;
   }
-  if (full) *reinterpret_cast<f32x4*>(y + row + t) = o;
+  if (full) *reinterpret_cast<f32x4u*>(y + row + t) = o;
   else {
 #pragma unroll
     for (int e = 0; e < 4; e++) if (t + e < T) y[row + t + e] = o[e];
@@ -3538,7 +3540,7 @@ hipError_t launch_fir(const float* x, const float* taps, int ntaps, float alpha,
   if (ntaps > 39 || !(ntaps & 1)) return hipErrorInvalidValue;
   const dim3 grid((T + FIR_TILE - 1) / FIR_TILE, C, B);
   static const bool wide = [] { const char* e = getenv("OU_FIR_WIDE"); return !e || atoi(e) != 0; }();
-  if (wide && (T & 3) == 0) {
+  if (wide) {  // (dwordx4 accesses at dword alignment: any T)
     void (*k)(const float*, const float*, float, int, const float*, const float*, float, float*, int, int) = nullptr;
     switch (ntaps) {
       case 5: k = fir4_kernel<5>; break;
