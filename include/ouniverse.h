@@ -108,10 +108,13 @@ void ou_destroy(ou_handle* h);
 
 /* Workspace needed for a batch of B signals of padded length T (T % prod(rate_factors) == 0). */
 int ou_workspace_bytes(const ou_handle* h, int32_t B, int32_t T, size_t* nbytes);
-/* Once per workspace buffer, before its first use (and after every change of (B, T)): clears the header -- the sticky
+/* Once per workspace buffer, before its first use (and after every change of B): clears the header -- the sticky
  * device status word and the GRU exchange granules (whose tags continue from launch to launch, so the forward calls
- * themselves enqueue no memset).  Enqueued on `stream`.  The handle remembers (buffer, size, B, T): ou_condition,
- * ou_score and ou_enhance return OU_EINVAL for a workspace that was not prepared for their shape. */
+ * themselves enqueue no memset).  Enqueued on `stream`.  The handle remembers (buffer, size, B): ou_condition,
+ * ou_score and ou_enhance return OU_EINVAL for a workspace that was not prepared for their batch size.  A buffer
+ * prepared for (B, T) serves every shorter length of the same batch size too (the header's layout depends on B alone):
+ * a set of utterances of different lengths -- the reference CLI's loop over a directory, bin/enhance.py:173-192 -- runs on
+ * ONE workspace sized for the longest; a buffer that is too small for a call is refused with OU_ENOMEM. */
 int ou_workspace_init(ou_handle* h, int32_t B, int32_t T, void* ws, size_t ws_bytes, ou_stream_t stream);
 
 /* Sampler constants, universe.py:301-311: sigma[n] (fp32, n = 0..n_steps-1), eta, beta. */
@@ -182,8 +185,24 @@ int ou_transform_inverse(const float* spec, int32_t B, int32_t n_frames, const f
  * switch to 1 for good the first time that counter moves. */
 int ou_set_gru_publish_mode(ou_handle* h, int32_t agent_scope);
 
+/* ... and what the handle currently uses (1 after ou_set_gru_publish_mode(h, 1) or after ou_check_device_status found
+ * that the safety net had to act).  A hipGraph captured earlier keeps the form it was captured with: re-capture. */
+int ou_get_gru_publish_mode(const ou_handle* h);
+
+/* K enhance calls in flight side by side in ONE process (extension; the reference's loop over files is serial,
+ * bin/enhance.py:173-192): create K handles on the same weight blob, give each its own stream and workspace, and tell
+ * every handle `lanes` = K and its own index `lane` (0 .. K - 1) BEFORE its first forward call.  A handle itself stays
+ * non-re-entrant.  What the numbers are for: the workgroups of a GRU cluster wait for each other, so every GRU launch that
+ * can be on the device at a time has to fit there whole -- the library sizes the launches of a lane to its share of the
+ * XCDs and deals the clusters of lane l to XCDs of their own (2 B l, 2 B l + 1, ..).  Results do not depend on the lane
+ * (K <= 4 at batch 1: bit-identical to the single-lane call; beyond that the recurrence may pick a different split of the
+ * hidden units: equal to fp32 rounding).  1 <= lanes <= 8. */
+int ou_set_lanes(ou_handle* h, int32_t lanes, int32_t lane);
+
 /* After the stream has been synchronised: OU_OK, or OU_ESYNC if a device-side timeout flag was raised.  The status
- * word (first 4 bytes of the workspace) is sticky: it stays raised until ou_workspace_init() / this call clears it. */
+ * word (first 4 bytes of the workspace) is sticky: it stays raised until ou_workspace_init() / this call clears it.
+ * Also reads the recovery counter of the GRU hand-offs (word 20): once it has moved, the handle publishes with
+ * agent-scope stores from the next call on (see ou_set_gru_publish_mode). */
 int ou_check_device_status(ou_handle* h, void* ws);
 
 /* ---- introspection (tests, profiling) ------------------------------------------------------------------- */

@@ -81,6 +81,10 @@ def build_parser():
                              "(always on when the files are sharded over several processes)")
     parser.add_argument("--batch-size", type=int, default=1,
                         help="Enhance up to this many consecutive files of equal rate and length in one call")
+    parser.add_argument("--in-flight", type=int, default=1,
+                        help="Keep this many enhance calls in flight side by side on the device (one stream and workspace "
+                             "each, 1..8): the mode for directories of files of DIFFERENT lengths -- same result as the "
+                             "file-by-file loop, bit for bit, at a multiple of its throughput")
     parser.add_argument("--pad-batch", action="store_true",
                         help="With --batch-size: also batch files of different lengths, zero-padded to the longest "
                              "(reference batch semantics: the padding is not masked)")
@@ -165,6 +169,44 @@ def main(argv=None, model=None):
         return args.output
 
     done = []
+    if args.batch_size <= 1 and args.in_flight > 1 and enhance_kwargs.get("target") is None \
+            and getattr(model, "fork", None) is not None:
+        # The serial loop below with K calls in flight: file k + K is read, resampled and enqueued while files k .. k + K - 1
+        # are still on the device; a file is written when its lane comes round again.  The noise is drawn at enqueue time
+        # in processing order, so the shared generator advances exactly as in the serial loop.
+        from ..lanes import LanePool
+
+        def finish(item):
+            lane, output_path, enh, fs = item
+            pool.wait(lane)
+            save(output_path, enh.cpu(), fs)
+            done.append(output_path)
+
+        with LanePool(model, min(int(args.in_flight), LanePool.MAX_LANES)) as pool:
+            pending = []
+            for k, path in todo:
+                output_path = out_path(path)
+                audio, fs = load(path)
+                audio = audio.to(device)
+                if per_file_seed:
+                    # a generator of its own per file: the draws of a call in flight must not see the next file's re-seed
+                    file_rng = torch.Generator(device=device)
+                    file_rng.manual_seed(args.seed + k)
+                else:
+                    file_rng = rng
+                if len(pending) >= pool.lanes:
+                    finish(pending.pop(0))
+
+                def work(m, audio=audio, fs=fs, file_rng=file_rng):
+                    with torch.no_grad():
+                        x = resample(audio, fs, m.fs)
+                        return resample(m.enhance(x, **dict(enhance_kwargs, rng=file_rng)), m.fs, fs)
+
+                lane, enh = pool.submit(work, audio)
+                pending.append((lane, output_path, enh, fs))
+            for item in pending:
+                finish(item)
+        return done
     if args.batch_size <= 1:
         for k, path in todo:
             output_path = out_path(path)

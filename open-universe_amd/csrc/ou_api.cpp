@@ -71,10 +71,19 @@ struct ou_handle {
   // recurrence kernels a garbage epoch and garbage tags
   struct WsRec { const void* ws; size_t bytes; int B, T; };
   std::vector<WsRec> ws_ready;
-  int gru_agent_stores = 0;  // ou_set_gru_publish_mode
+  int gru_agent_stores = 0;  // ou_set_gru_publish_mode; also set by ou_check_device_status when the safety net had to act
+  unsigned gru_recoveries_seen = 0;
+  // enhance calls in flight side by side in this process, one handle + stream + workspace each (ou_set_lanes): the GRU
+  // launches of all lanes have to be resident together
+  int lanes = 1, lane = 0;
+  // A workspace prepared for (B, T0) serves every T of the same batch size that fits into it: everything ou_workspace_init
+  // prepares (status words, tag epochs, GRU exchange areas) lies in a header whose layout depends on B alone, and the tag
+  // epochs advance monotonically whatever the length of a pass -- a directory of files of different lengths runs on ONE
+  // workspace sized for the longest.  (Too small a buffer is caught by the walk itself: OU_ENOMEM.)
   bool ws_ok(const void* ws, size_t bytes, int B, int T) const {
+    (void)T;
     for (const WsRec& r : ws_ready)
-      if (r.ws == ws) return r.B == B && r.T == T && r.bytes <= bytes;
+      if (r.ws == ws) return r.B == B && r.bytes <= bytes;
     return false;
   }
 };
@@ -98,16 +107,18 @@ struct Tensor {
 // Tuning / debug switches, read ONCE per C-ABI call: a forward walks ~400 launches and used to call getenv
 // eight times for each of them (a linear scan of the environment: a third of the host time of an enhance call).
 struct EnvCfg {
-  int dbg = 0, xcd_map = -1, conv_direct = 3, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0;
+  int dbg = 0, xcd_map = -1, conv_direct = 4, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1, d4_force = 0;
   int gru_v = 2, gru_bmax = 0, gru_ts = 0, gru_upw = 0, gru_backoff = 0, gru_agent = -1, gru_dbg = 0;
   double tile_min = -1.0;  // < 0: the launcher's default
   int tile_prefetch = 1;
   std::string chain_ts;
   static int geti(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
   EnvCfg() {
-    dbg = geti("OU_DBG", 0); xcd_map = geti("OU_XCD_MAP", -1); conv_direct = geti("OU_CONV_DIRECT", 3);
+    dbg = geti("OU_DBG", 0); xcd_map = geti("OU_XCD_MAP", -1); conv_direct = geti("OU_CONV_DIRECT", 4);
     fuse = geti("OU_FUSE", -1); fuse_nc = geti("OU_FUSE_NC", 0); rate_small = geti("OU_RATE_SMALL", 1);
     fuse_upfir = geti("OU_FUSE_UPFIR", 1);
+    d4_fir = geti("OU_D4_FIR", 1);
+    d4_force = geti("OU_D4_FORCE", 0);
     block3 = geti("OU_BLOCK3", 0);
     gru_v = geti("OU_GRU_V", 2); gru_bmax = geti("OU_GRU_BMAX", 0); gru_ts = std::getenv("OU_GRU_TS") ? 1 : 0;
     gru_upw = geti("OU_GRU_UPW", 0); gru_backoff = geti("OU_GRU_BACKOFF", 0); gru_agent = geti("OU_GRU_AGENT_STORES", -1);
@@ -207,6 +218,13 @@ struct Runner {
   unsigned* status_words = nullptr;        // workspace header (layout_persist)
   unsigned long long* block3_bar = nullptr;
   bool gru_shared = false;  // GRU launches enqueued now may run beside another GRU layer (overlapped conditioner / score pass)
+  // GRU launches that can meet on one XCD: this call's own two layers when they overlap, times the lanes whose clusters are
+  // dealt to the same XCDs (lane l deals its 2 B clusters from XCD 2 B l on)
+  static int gru_share_of(int lanes, int B, bool overlap) {
+    const int ncl = 2 * B < 8 ? 2 * B : 8;
+    const int by_lanes = lanes > 1 ? (ncl * lanes + 7) / 8 : 1;
+    return by_lanes * (overlap ? 2 : 1);
+  }
 
   Tensor conv(const ConvL& L, const Tensor& in, const std::string& name, const Epi& e, const Tensor* dst = nullptr) {
     int Nq, Tout;
@@ -228,7 +246,7 @@ struct Runner {
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
     a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
-    a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct;
+    a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct; a.d4_fir_unfused = env.d4_fir; a.d4_force = env.d4_force;
     a.tile_min = env.tile_min; a.tile_prefetch = env.tile_prefetch;
     a.tstamps = h->tstamps;
     if (collect) { collect->push_back(a); return out; }
@@ -494,19 +512,32 @@ struct Runner {
     a.gx = gx.p; a.whh = W(G.whh_off); a.bhn = W(G.bhn_off); a.out = out.p; a.res = res; a.res_scale = res_scale;
     a.xchg = xchg; a.err = errw; a.epoch = epoch; a.B = B; a.T = in.T; a.H = G.H;
     // kernel generation: the ring kernel (every wave gathers h straight from L2, no polling wave, no workgroup barrier)
-    // for every batch size -- its publishes are agent-scope (sc1) stores by default, the documented form of the hand-off;
-    // OU_GRU_V=1 selects the polling-wave kernel of round 1.
+    // for every batch size; OU_GRU_V=1 selects the polling-wave kernel of round 1.  Its publishes: see below.
     a.version = env.gru_v;
-    a.shared = gru_shared ? 1 : 0;
+    a.lanes = h->lanes;
+    a.share = gru_share_of(h->lanes, B, gru_shared);
+    a.xcd_rot = h->lanes > 1 ? (2 * B * h->lane) % 8 : 0;
     a.force_bmax = env.gru_bmax;
     if (env.gru_ts) a.tstamps = (long long*)(base + cap - (1u << 20));
     a.force_upw = env.gru_upw;
     a.poll_backoff = env.gru_backoff;
-    // publishes: plain stores inside a cluster that shares one XCD (the L2 is that XCD's point of coherence; the
-    // rendezvous proves the placement), agent-scope (sc1) stores otherwise or on request -- ou_set_gru_publish_mode(), which
-    // the host wrapper calls for good the first time the safety net of the kernel had to repeat a publish
+    // publishes: PLAIN stores by default inside a cluster that shares one XCD (the L2 is that XCD's point of coherence; the
+    // rendezvous proves the placement at every launch), agent-scope (sc1) stores otherwise, on request
+    // (ou_set_gru_publish_mode) and -- for good -- from the moment ou_check_device_status sees that the kernel's safety net
+    // had to repeat a publish on this handle (status word 20).  A hipGraph captured before such a switch keeps the publish
+    // form it was captured with: re-capture after a switch.
     a.agent_stores = env.gru_agent >= 0 ? (env.gru_agent != 0) : h->gru_agent_stores;
     a.dbg = env.gru_dbg;
+    if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {
+      // the recurrence proper (the input projection is a conv launch of its own): 2 directions x T steps x (3H x H) MACs
+      ou_handle::ProfRec rec;
+      rec.flops = 2.0 * 2.0 * 3.0 * G.H * G.H * (double)in.T * B;
+      rec.bytes = 4.0 * ((double)B * (6.0 + 2.0 + (res ? 2.0 : 0.0)) * G.H * in.T + 2.0 * 3.0 * G.H * G.H);
+      rec.cfg = 1000 + in.T;  // 1000 + steps per pass
+      a.prof = h->prof_dev + 32 * h->prof_used;
+      h->prof.push_back(rec);
+      h->prof_used++;
+    }
     chk(launch_gru(a, h->num_cu, st), G.name.c_str());
     return out;
   }
@@ -1021,7 +1052,9 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
     r.chk(launch_film(P.g, r.W(m.film.w_off), r.W(m.film.b_off), P.film, n_steps, m.film.rows, m.film.D, st), "film");
     // (only when two GRU layers fit on the machine side by side: their clusters spin on each other's publishes and must
     // all be resident)
-    const bool gru_fit = gru_ring_batch_cap(m.s_gru.H, h->num_cu, 1, 0, B) >= 1 && gru_ring_batch_cap(m.c_gru0.H, h->num_cu, 1, 0, B) >= 1;
+    const int share2 = Runner::gru_share_of(h->lanes, B, true);
+    const bool gru_fit = gru_ring_batch_cap(m.s_gru.H, h->num_cu, share2, 0, B, h->lanes) >= 1 &&
+                         gru_ring_batch_cap(m.c_gru0.H, h->num_cu, share2, 0, B, h->lanes) >= 1;
     if (warm_start < 0 && h->overlap && gru_fit) {
       r.gru_shared = true;
       r.chk(launch_init_x(noise, nullptr, sigma[n_start], P.x.p, nBT, st), "init x");  // universe.py:325-327
@@ -1102,9 +1135,15 @@ int ou_transform_inverse(const float* spec, int32_t B, int32_t n_frames, const f
 
 int ou_check_device_status(ou_handle* h, void* ws) {
   if (!h || !ws) return fail(h, OU_EINVAL, "bad argument");
-  unsigned v = 0;
-  hipError_t e = hipMemcpy(&v, ws, sizeof(v), hipMemcpyDeviceToHost);
+  unsigned hdr[32];
+  hipError_t e = hipMemcpy(hdr, ws, sizeof(hdr), hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(h, OU_EHIP, hipGetErrorString(e));
+  const unsigned v = hdr[0];
+  // word 20: publishes the GRU clusters' safety net had to repeat on this workspace.  The first time it moves the cheap
+  // publish form has shown that it cannot be relied upon on this device / in this process mix: agent-scope publishes from
+  // now on (+0.1 ms per GRU pass, no more 0.1 ms recoveries).  Results are unaffected either way.
+  if (hdr[20] != 0u && !h->gru_agent_stores) h->gru_agent_stores = 1;
+  h->gru_recoveries_seen = hdr[20];
   if (v) {
     (void)hipMemset(ws, 0, sizeof(v));  // sticky until read
     return fail(h, OU_ESYNC, "device-side timeout in the GRU cluster exchange (status word " + std::to_string(v) + ")");
@@ -1134,6 +1173,15 @@ int ou_workspace_init(ou_handle* h, int32_t B, int32_t T, void* ws, size_t ws_by
   }
   return rc;
 }
+
+int ou_set_lanes(ou_handle* h, int32_t lanes, int32_t lane) {
+  if (!h || lanes < 1 || lanes > 8 || lane < 0 || lane >= lanes) return fail(h, OU_EINVAL, "ou_set_lanes: 1 <= lanes <= 8, 0 <= lane < lanes");
+  h->lanes = lanes;
+  h->lane = lane;
+  return OU_OK;
+}
+
+int ou_get_gru_publish_mode(const ou_handle* h) { return h ? h->gru_agent_stores : 0; }
 
 int ou_set_gru_publish_mode(ou_handle* h, int32_t agent_scope) {
   if (!h) return fail(h, OU_EINVAL, "bad argument");

@@ -1,0 +1,675 @@
+// gfx950 (CDNA4 / MI355X) kernels of the UNIVERSE(++) enhance path: fused ConvBlock body of the wide levels (conv_chain_kernel) and the small-K rate-change kernels
+// (one translation unit per kernel family; shared device helpers in ou_dev.h, cross-file launchers in ou_internal.h)
+#include "ou_kernels.h"
+#include "ou_internal.h"
+#include "ou_dev.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+namespace ou {
+
+// =========================================================================================================
+// Fused ConvBlock body for the wide, shallow levels (C = 32 / 64 channels, tens of thousands of samples)
+//   conv1 (k5) -> (+cond)/sqrt2 -> FiLM -> conv2 (k3) -> conv3 (k3) -> (+h)/sqrt2        (blocks.py:377-399)
+// As separate launches each of these is one short pipeline stage per block: load everything, ~80 MFMAs per wave,
+// store everything, with the intermediate (B, C, T) tensors going out to L2/HBM and back.  Here a block owns TN output
+// samples and walks the whole chain on LDS-resident tiles: stage s computes NC = 32 * (waves / MT) columns
+// (time t0 - R_s + u, R_s = halo still needed downstream), masks columns outside [0, T) to the zero padding the
+// next conv must see, applies that conv's PReLU and leaves the tile in LDS; only the last stage writes HBM.
+// The halo (2 + 1 + 1 samples each side for depth 3) is recomputed per tile: TN = NC - 2 R_0.
+//   * weights are streamed: one packed chunk ([KW][CK][C], <= 96 rows) per pipeline slot, register-prefetched one
+//     slot ahead into a 2-slot LDS ring, one barrier per slot -- the slot sequence runs straight through the conv
+//     boundaries, so the next conv's first chunk is already in flight while the previous epilogue runs.
+//   * every wave owns one 32 x 32 output tile of every stage (no split-K, no cross-wave reduction); the k-loop is
+//     the generic kernel's: tap-outer, channel-pair-inner, fragment groups of 4 software-pipelined.
+//   * depth 2 (conv2, conv3 only; conv1 stays a generic launch) exists because of tile quantisation at B = 1:
+//     T = 32000 over 256 CUs is 125 samples per CU -- 126-sample tiles fit one round, 124-sample tiles do not.
+// =========================================================================================================
+// Addressing: every global access is a buffer instruction -- the per-lane byte offset is computed once, the row
+// (channel) part of the address is a wave-uniform SGPR offset -- so the prologue / epilogues spend their VALU
+// cycles on the arithmetic only (they are a third of a block's time at C = 32).
+template <int MT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void conv_chain_kernel(ChainArgs p, int TN, int ntiles) {
+  constexpr int C = 32 * MT, NTN = NWV / MT, NC = 32 * NTN, XS = NC + 4, NTH = 64 * NWV;
+  constexpr int WSLOT = 96 * C;  // floats per weight slot (KW * CK <= 96 rows of C)
+  constexpr int MAXW = (WSLOT / 4 + NTH - 1) / NTH;
+  constexpr int RPW = C / NWV, NCG = NC / 64;  // input-tile rows per wave, full 64-column groups per row
+  constexpr int U = 4;
+  static_assert(NC % 64 == 0 && RPW * 4 <= 64 && C % NWV == 0, "input tile mapping");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufA = smem;            // [C][XS]
+  float* bufB = bufA + C * XS;   // [C][XS]
+  float* Wb = bufB + C * XS;     // [2][WSLOT]
+  float* prm = Wb + 2 * WSLOT;   // bias[3][C], gamma[C], beta[C]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % MT, wn = wave / MT;
+  const int lhalf = lane >> 5, l31 = lane & 31;
+  const int tile = blockIdx.x % ntiles, b = blockIdx.x / ntiles;
+  const int D = p.depth, T = p.T;
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const bool ts_on = p.tstamps != nullptr;
+  long long tsv[3] = {0, 0, 0}, t_mma = 0, t_epi = 0, t_bar = 0, t_iss = 0, t_ws = 0;
+  if (ts_on) tsv[0] = __builtin_readcyclecounter();
+
+  // halo still needed downstream of stage s (the conv index is a compile-time constant everywhere below: a
+  // run-time index into p.cv[] would be re-read from the kernarg segment at every use)
+  const int h1 = (p.cv[1].KW - 1) / 2, h2 = D == 3 ? (p.cv[2].KW - 1) / 2 : 0;
+  const int R0 = h1 + h2, R1 = h2;
+  const int t0 = tile * TN;
+  const size_t rowbase = (size_t)b * C * T;
+  const unsigned plane = (unsigned)C * (unsigned)T * 4u;  // bytes of one batch element (launcher: < 2^31)
+  const int Tb = T * 4;
+
+  // weight slot (conv s, chunk c) -> registers; rows past the chunk read as 0 (buffer bounds)
+  int wvoff[MAXW];
+#pragma unroll
+  for (int i = 0; i < MAXW; i++) {
+    const int f = tid + i * NTH;
+    wvoff[i] = ((f / (C / 4)) * p.Mp + (f % (C / 4)) * 4) * 4;
+  }
+  u32x4 wr[MAXW];
+  auto load_slot = [&](auto SC, int c) {
+    constexpr int s = decltype(SC)::value;
+    const int rows = p.cv[s].KW * p.cv[s].CK;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.cv[s].w + (size_t)c * rows * p.Mp, (unsigned)(rows * p.Mp * 4));
+#pragma unroll
+    for (int i = 0; i < MAXW; i++)
+      if ((i + 1) * NTH <= WSLOT / 4 || tid + i * NTH < WSLOT / 4)
+        wr[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[i], 0, 0);
+  };
+  auto store_slot = [&](int buf) {
+    u32x4* wd = reinterpret_cast<u32x4*>(Wb + buf * WSLOT);
+#pragma unroll
+    for (int i = 0; i < MAXW; i++)
+      if ((i + 1) * NTH <= WSLOT / 4 || tid + i * NTH < WSLOT / 4) wd[tid + i * NTH] = wr[i];
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+
+  load_slot(S0{}, 0);
+  {  // input tile: column j <-> time t0 - R_0 - h_0 + j, PReLU of the first conv applied while staging.
+     // wave w stages rows w, w + NWV, ...: NCG full 64-column groups per row + one 4-column tail per row
+    const int tin0 = t0 - R0 - (p.cv[0].KW - 1) / 2;
+    const float a0 = p.cv[0].alpha;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + rowbase, plane);
+    float xr[RPW][NCG], xt = 0.f;
+    int voff[NCG];
+    bool okc[NCG];
+#pragma unroll
+    for (int g = 0; g < NCG; g++) {
+      const int t = tin0 + g * 64 + lane;
+      okc[g] = t >= 0 && t < T;
+      voff[g] = t * 4;
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+      const int soff = (wave + NWV * k) * Tb;
+#pragma unroll
+      for (int g = 0; g < NCG; g++) xr[k][g] = okc[g] ? buf_load(rx, voff[g], soff) : 0.f;
+    }
+    const int trow = wave + NWV * (lane >> 2), tt = tin0 + NC + (lane & 3);
+    if (lane < 4 * RPW && tt >= 0 && tt < T) xt = buf_load(rx, (trow * T + tt) * 4, 0);
+    float* dst = bufA + wave * XS + lane;
+#pragma unroll
+    for (int k = 0; k < RPW; k++)
+#pragma unroll
+      for (int g = 0; g < NCG; g++) {
+        const float v = xr[k][g];
+        dst[k * NWV * XS + g * 64] = v >= 0.f ? v : a0 * v;
+      }
+    if (lane < 4 * RPW) bufA[trow * XS + NC + (lane & 3)] = xt >= 0.f ? xt : a0 * xt;
+  }
+  for (int i = tid; i < C; i += NTH) {
+    prm[i] = p.cv[0].bias[i];
+    prm[C + i] = p.cv[1].bias[i];
+    prm[2 * C + i] = D == 3 ? p.cv[2].bias[i] : 0.f;
+    prm[3 * C + i] = p.film ? p.film[(size_t)b * p.film_bstride + i] : 1.f;
+    prm[4 * C + i] = p.film ? p.film[(size_t)b * p.film_bstride + C + i] : 0.f;
+  }
+  for (int i = tid; i < C * 4; i += NTH) bufB[(i >> 2) * XS + NC + (i & 3)] = 0.f;  // never-written pad columns
+  if (ts_on) tsv[1] = __builtin_readcyclecounter();
+  store_slot(0);
+  __syncthreads();
+  if (ts_on) tsv[2] = __builtin_readcyclecounter();
+
+  const int u = wn * 32 + l31;                       // this lane's column in every stage
+  const int lrow = wm * 32 + 4 * lhalf;              // lane part of the accumulator row: row(r) = lrow + KR(r)
+  const float* prm_l = prm + lrow;
+  int q = 0;
+
+  auto run_stage = [&](auto SC) {
+    constexpr int s = decltype(SC)::value;
+    using SN = std::integral_constant<int, (s < 2 ? s + 1 : 2)>;
+    const int KW = p.cv[s].KW, CK = p.cv[s].CK, nch = C / CK;
+    const float* inb = (s & 1) ? bufB : bufA;
+    float* outb = (s & 1) ? bufA : bufB;
+    const bool last = s == D - 1;
+    const bool first3 = s == 0 && D == 3;
+    const int t = t0 - (s == 0 ? R0 : (s == 1 ? R1 : 0)) + u;
+    const bool inside = t >= 0 && t < T;
+    const int evoff = (lrow * T + t) * 4;
+    floatx16 acc;
+    float ev[16];  // epilogue operand (cond add of conv1 / residual of the last conv), fetched one slot early
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc[r] = 0.f; ev[r] = 0.f; }
+    for (int c = 0; c < nch; c++, q++) {
+      const bool more = c + 1 < nch;
+      const bool has_next = more || !last;
+      long long ta = 0, tb = 0, tc = 0, td = 0, te = 0;
+      if (ts_on) ta = __builtin_readcyclecounter();
+      if (more) load_slot(SC, c + 1);
+      else if (!last) load_slot(SN{}, 0);
+      if (!more) {
+        const float* src = last ? p.res : (first3 ? p.add : nullptr);
+        if (src && inside) {
+          const __amdgpu_buffer_rsrc_t rs = make_rsrc(src + rowbase, plane);
+#pragma unroll
+          for (int r = 0; r < 16; r++) ev[r] = buf_load(rs, evoff, ((r & 3) + 8 * (r >> 2)) * Tb);
+        }
+      }
+      if (ts_on) td = __builtin_readcyclecounter();
+      {
+        const float* wsb = Wb + (q & 1) * WSLOT + lhalf * C + wm * 32 + l31;
+        const float* xsb = inb + (c * CK + lhalf) * XS + u;
+        const int gpt = CK / (2 * U);  // fragment groups per tap
+        const int ngroups = gpt * KW;
+        int cur_tap = 0, cur_jg = 0;
+        auto load_group = [&](float (&av)[U], float (&bv)[U]) {
+          const float* wt = wsb + (cur_tap * CK + cur_jg * (2 * U)) * C;
+          const float* xq = xsb + cur_jg * (2 * U) * XS + cur_tap;
+#pragma unroll
+          for (int k = 0; k < U; k++) { av[k] = wt[k * 2 * C]; bv[k] = xq[k * 2 * XS]; }
+          if (++cur_jg == gpt) { cur_jg = 0; ++cur_tap; }
+        };
+        auto mma_group = [&](float (&av)[U], float (&bv)[U]) {
+#pragma unroll
+          for (int k = 0; k < U; k++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bv[k], acc, 0, 0, 0);
+        };
+        float a0[U], b0[U], a1[U], b1[U];
+        load_group(a0, b0);
+        for (int g = 0; g < ngroups; g += 2) {
+          if (g + 1 < ngroups) load_group(a1, b1);
+          mma_group(a0, b0);
+          if (g + 1 < ngroups) {
+            if (g + 2 < ngroups) load_group(a0, b0);
+            mma_group(a1, b1);
+          }
+        }
+      }
+      if (ts_on) tb = __builtin_readcyclecounter();
+      if (!more) {
+        const float* bias_l = prm_l + s * C;
+        if (!last) {
+          const float an = p.cv[s < 2 ? s + 1 : 2].alpha;
+          const bool own = inside && t >= t0 && t < t0 + TN;
+          const bool all_in = __builtin_amdgcn_ballot_w64(!inside) == 0ull;  // wave-uniform: no masking needed
+          float* out_l = outb + lrow * XS + u;
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; r++) v[r] = acc[r] + bias_l[(r & 3) + 8 * (r >> 2)];
+          if (first3) {
+            if (p.add) {
+#pragma unroll
+              for (int r = 0; r < 16; r++) v[r] = (v[r] + ev[r]) * p.add_scale;
+            }
+            if (p.film) {
+#pragma unroll
+              for (int r = 0; r < 16; r++) {
+                const int kr = (r & 3) + 8 * (r >> 2);
+                v[r] = prm_l[3 * C + kr] * v[r] + prm_l[4 * C + kr];
+              }
+            }
+            if (p.c1_out && own) {
+              const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.c1_out + rowbase, plane);
+#pragma unroll
+              for (int r = 0; r < 16; r++) buf_store(v[r], rc, evoff, ((r & 3) + 8 * (r >> 2)) * Tb);
+            }
+          }
+          if (!all_in) {  // the zero padding the next conv sees outside the signal
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = inside ? v[r] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const float x = v[r];
+            out_l[((r & 3) + 8 * (r >> 2)) * XS] = x >= 0.f ? x : an * x;
+          }
+        } else if (u < TN && inside) {
+          const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + rowbase, plane);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            float x = acc[r] + bias_l[(r & 3) + 8 * (r >> 2)];
+            if (p.res) x = (x + ev[r]) * p.res_scale;
+            buf_store(x, ry, evoff, ((r & 3) + 8 * (r >> 2)) * Tb);
+          }
+        }
+      }
+      if (ts_on) te = __builtin_readcyclecounter();
+      if (has_next) store_slot((q + 1) & 1);
+      if (ts_on) tc = __builtin_readcyclecounter();
+      __syncthreads();
+      if (ts_on) { t_mma += tb - td; t_iss += td - ta; t_epi += te - tb; t_ws += tc - te; t_bar += __builtin_readcyclecounter() - tc; }
+    }
+  };
+  run_stage(S0{});
+  run_stage(S1{});
+  if (D == 3) run_stage(S2{});
+
+  if (ts_on && lane == 0) {
+    long long* o = p.tstamps + ((size_t)blockIdx.x * NWV + wave) * 8;
+    o[0] = tsv[1] - tsv[0]; o[1] = tsv[2] - tsv[1]; o[2] = t_mma; o[3] = t_epi; o[4] = t_bar;
+    o[5] = __builtin_readcyclecounter() - tsv[0]; o[6] = t_iss; o[7] = t_ws;
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+struct ChainVariant {
+  int C, NC, NWV;
+  void (*kern)(ChainArgs, int, int);
+};
+static const ChainVariant kChainVariants[] = {
+    {32, 128, 4, conv_chain_kernel<1, 4>},
+    {32, 256, 8, conv_chain_kernel<1, 8>},
+    {64, 128, 8, conv_chain_kernel<2, 8>},
+};
+constexpr int kNumChainVariants = sizeof(kChainVariants) / sizeof(kChainVariants[0]);
+static size_t chain_smem_bytes(const ChainVariant& v) {
+  return 4 * ((size_t)2 * v.C * (v.NC + 4) + 2 * 96 * v.C + 5 * v.C);
+}
+
+static bool chain_shape_ok(const ChainArgs& a) {
+  if (a.depth != 2 && a.depth != 3) return false;
+  if (a.C != 32 && a.C != 64) return false;
+  if (a.Mp < a.C || a.Mp % 4 || a.T < 1 || (long)a.C * a.T * 4 >= (1L << 31)) return false;
+  for (int s = 0; s < a.depth; s++) {
+    const ChainConv& c = a.cv[s];
+    if ((c.KW != 3 && c.KW != 5) || c.CK < 8 || (c.CK & (c.CK - 1)) || a.C % c.CK || c.KW * c.CK > 96) return false;
+  }
+  return true;
+}
+
+// Estimated duration in core cycles of variant v: rounds x (MFMA time of one block at its SIMD sharing + fixed part)
+static double chain_variant_cost(const ChainArgs& a, const ChainVariant& v, int num_cu) {
+  int R0 = 0, mf = 0;
+  for (int s = 0; s < a.depth; s++) {
+    if (s) R0 += (a.cv[s].KW - 1) / 2;
+    mf += a.C * a.cv[s].KW / 2;  // MFMAs per wave
+  }
+  const int TN = v.NC - 2 * R0;
+  const long blocks = (long)a.B * ((a.T + TN - 1) / TN);
+  const int occ = (int)(160 * 1024 / chain_smem_bytes(v));
+  const long slots = (long)num_cu * (occ < 1 ? 1 : occ);
+  const long rounds = (blocks + slots - 1) / slots;
+  const int resident = (int)((blocks < slots ? blocks : slots) + num_cu - 1) / num_cu;  // blocks sharing a CU
+  const double per_block = mf * 64.0 * (v.NWV / 4.0) * resident / 0.8 + 8000.0;
+  return rounds * per_block;
+}
+
+double chain_cost(const ChainArgs& a, int num_cu, int* nc_out) {
+  if (!chain_shape_ok(a)) return -1.0;
+  double best = -1.0;
+  for (int i = 0; i < kNumChainVariants; i++) {
+    const ChainVariant& v = kChainVariants[i];
+    if (v.C != a.C || (a.force_nc && v.NC != a.force_nc)) continue;
+    const double c = chain_variant_cost(a, v, num_cu);
+    if (best < 0 || c < best) { best = c; if (nc_out) *nc_out = v.NC; }
+  }
+  return best;
+}
+
+hipError_t init_chain_kernels() {
+  for (int i = 0; i < kNumChainVariants; i++) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kChainVariants[i].kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(kChainVariants[i]));
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_chain(const ChainArgs& a, int num_cu, hipStream_t st, int* variant) {
+  int nc = 0;
+  if (chain_cost(a, num_cu, &nc) < 0) return hipErrorInvalidConfiguration;
+  for (int i = 0; i < kNumChainVariants; i++) {
+    const ChainVariant& v = kChainVariants[i];
+    if (v.C != a.C || v.NC != nc) continue;
+    int R0 = 0;
+    for (int s = 1; s < a.depth; s++) R0 += (a.cv[s].KW - 1) / 2;
+    const int TN = v.NC - 2 * R0;
+    const int ntiles = (a.T + TN - 1) / TN;
+    if (variant) *variant = 100 + 10 * a.depth + i;
+    hipLaunchKernelGGL(v.kern, dim3(ntiles * a.B), dim3(64 * v.NWV), chain_smem_bytes(v), st, a, TN, ntiles);
+    return hipGetLastError();
+  }
+  return hipErrorInvalidConfiguration;
+}
+
+// =========================================================================================================
+// Small-K rate-change convs of the wide levels, with the anti-alias FIR fused (blocks.py:205-227)
+//   down:  y = conv_{k=s=R}(FIR_{2R+1}(prelu(x))) + bias        K = Cin R <= 96, M = Cout <= 96
+// At T = 64 160 the first rate-change conv is a 0.26 GFLOP GEMM with K = 64: bandwidth- and latency-sized work that used
+// to take a FIR pass (6.5 us) + a generic conv launch (11.4 us) + a dispatch gap; here 11.6 us in one launch.  (The next
+// level -- K = 256, M = 128, 251 workgroups with one wave per SIMD -- came out at 19.6 us against 10.6 + 6.5: its phases
+// run back to back with nothing to overlap them, so it stays on the FIR pass + the strided direct kernel.)
+// One workgroup owns BQ output frames and ALL output channels, so nothing is split or reduced across waves:
+//   1. every thread loads runs of the input, applies PReLU and the FIR in registers (same tap order as fir_kernel) and
+//      writes the filtered tile to LDS once;
+//   2. the whole weight matrix of the layer sits in registers (K/2 A operands per lane, issued before step 1);
+//   3. K/2 MFMAs per wave on B operands read from LDS; bias in the epilogue, stores straight from the accumulators.
+// =========================================================================================================
+template <int R, int MT, int NWN, int K2>
+__global__ __launch_bounds__(64 * MT * NWN) void rate_down_kernel(ConvArgs p) {
+  constexpr int NW = MT * NWN, NT = 64 * NW, BQ = 32 * NWN, SP = BQ * R, ROW = SP + 4, NCH = SP / 4;
+  static_assert(SP % 4 == 0, "runs of 4 samples");
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // xf[Cin][ROW]
+  const int tid = threadIdx.x, lane = tid & 63, lhalf = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % MT, wn = wave / MT;
+  const int q0 = blockIdx.x * BQ, b = blockIdx.y;
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const int Cin = p.Cin, Tin = p.Tin, Mp = p.Mp, CK = p.CK, lck = 31 - __clz(CK);
+  // ---- filtered input tile -> LDS.  Work item = (channel, run of 4 output samples); the raw windows of IB items are
+  // loaded first (wide loads where the window is inside the row), then filtered: with one wave per SIMD nothing else
+  // hides a dependent load -> FIR -> store chain per item.
+  const bool fir = p.fir != nullptr;
+  float f[2 * R + 1];
+#pragma unroll
+  for (int j = 0; j <= 2 * R; j++) f[j] = fir ? p.fir[j] : 0.f;
+  const float alpha = p.alpha_val;
+  const bool act = p.act != 0;
+  const float* xb = p.x + (size_t)b * Cin * Tin;
+  constexpr int CIN = 2 * K2 / R, ITEMS = CIN * NCH / NT, IB = ITEMS < 4 ? ITEMS : 4, WIN = 4 + 2 * R;
+  static_assert(CIN * NCH % NT == 0 && ITEMS % IB == 0, "items per thread");
+  // (the K/2 A operands -- the layer's whole weight matrix -- are requested right after the first batch of input
+  // windows: loads return in order, so the filter only waits for the windows and the weights land behind it)
+  float a[K2];
+#pragma unroll 1
+  for (int i0 = 0; i0 < ITEMS; i0 += IB) {
+    float v[IB][WIN];
+#pragma unroll
+    for (int u = 0; u < IB; u++) {
+      const int item = tid + (i0 + u) * NT;
+      const int ci = item / NCH, c = item - ci * NCH;
+      const int ts = q0 * R + 4 * c - (fir ? R : 0);  // first sample of the window (a multiple of 2 / of 4 for R = 4)
+      const int nwin = fir ? WIN : 4;
+      const float* xr = xb + (size_t)ci * Tin;
+      if (ts >= 0 && ts + nwin <= Tin) {
+        if (!fir) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(xr + ts);
+          v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < WIN; i += 2) {
+            const f32x2 q = *reinterpret_cast<const f32x2*>(xr + ts + i);
+            v[u][i] = q.x; v[u][i + 1] = q.y;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < WIN; i++) {
+          const int t = ts + i;
+          v[u][i] = (i < nwin && t >= 0 && t < Tin) ? xr[t] : 0.f;
+        }
+      }
+    }
+    if (i0 == 0) {
+      // K index 2 ks + half = (ci, tap), packed row ((ci / CK) R + tap) CK + ci % CK
+#pragma unroll
+      for (int ks = 0; ks < K2; ks++) {
+        const int idx = 2 * ks + lhalf, ci = idx / R, tap = idx - ci * R;
+        const int row = (((ci >> lck) * R + tap) << lck) + (ci & (CK - 1));
+        a[ks] = p.w[(size_t)row * Mp + 32 * wm + l31];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < IB; u++) {
+      const int item = tid + (i0 + u) * NT;
+      const int ci = item / NCH, c = item - ci * NCH;
+#pragma unroll
+      for (int i = 0; i < WIN; i++) v[u][i] = (act && v[u][i] < 0.f) ? alpha * v[u][i] : v[u][i];  // blocks.py:213
+      f32x4 o;
+      if (fir) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float acc = 0.f;
+#pragma unroll
+          for (int i = 0; i <= 2 * R; i++) acc = fmaf(f[i], v[u][j + i], acc);
+          o[j] = acc;
+        }
+      } else {
+        o = f32x4{v[u][0], v[u][1], v[u][2], v[u][3]};
+      }
+      *reinterpret_cast<f32x4*>(&smem[ci * ROW + 4 * c]) = o;
+    }
+  }
+  __syncthreads();
+  // ---- K/2 MFMAs per wave
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+  const float* bs = smem + (32 * wn + l31) * R;
+#pragma unroll
+  for (int ks = 0; ks < K2; ks++) {
+    const int idx = 2 * ks + lhalf, ci = idx / R, tap = idx - ci * R;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], bs[ci * ROW + tap], acc, 0, 0, 0);
+  }
+  // ---- epilogue
+  const int q = q0 + 32 * wn + l31;
+  if (q < p.Nq) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+      if (m < p.M) p.y[((size_t)b * p.Cout + m) * p.Nq + q] = acc[r] + p.bias[m];
+    }
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+struct RateDownCfg {
+  int R, M, Cin;
+  void (*kern)(ConvArgs);
+  int threads, bq;
+};
+static const RateDownCfg kRateDownCfgs[] = {
+    {2, 64, 32, rate_down_kernel<2, 2, 2, 32>, 256, 64},    // PP16 / OR16: 32 -> 64 channels, T -> T/2
+    {2, 96, 48, rate_down_kernel<2, 3, 1, 48>, 192, 32},    // PP24: 48 -> 96
+};
+bool rate_down_supported(const ConvArgs& a) {
+  if (a.up != 1 || a.stride != a.KW || a.pad != 0 || a.Tin != a.Nq * a.stride || a.add || a.film || a.res || a.in_scale)
+    return false;
+  if (a.fir && a.fir_len != 2 * a.stride + 1) return false;
+  for (const RateDownCfg& c : kRateDownCfgs)
+    if (c.R == a.stride && c.M == a.M && c.Cin == a.Cin) return true;
+  return false;
+}
+hipError_t launch_rate_down(const ConvArgs& a, hipStream_t st, int* cfg_out) {
+  if (!rate_down_supported(a)) return hipErrorNotSupported;
+  for (const RateDownCfg& c : kRateDownCfgs) {
+    if (c.R != a.stride || c.M != a.M || c.Cin != a.Cin) continue;
+    const size_t smem = (size_t)a.Cin * (c.bq * c.R + 4) * 4;
+    if (cfg_out) *cfg_out = 40 + c.R;
+    hipLaunchKernelGGL(c.kern, dim3((a.Nq + c.bq - 1) / c.bq, a.B), dim3(c.threads), smem, st, a);
+    return hipGetLastError();
+  }
+  return hipErrorNotSupported;
+}
+
+//   up:    y = FIR_{2R+1}(convT_{k=s=R}(prelu(x))) + bias ; y = res ? (y + res) res_scale : y      K = Cin <= 96
+// The last up conv (64 -> 32 channels x 2 phases, K = 64, T/2 -> T): the same idea the other way round.  A workgroup owns
+// BF input frames (the outer two are halo when there is a FIR) and all M = Cout R phase rows: A (the whole weight matrix)
+// and B (this lane's K/2 input samples, PReLU applied) go straight from global memory to registers, K/2 MFMAs per wave,
+// the phase-GEMM result is laid out in LDS as [row = co R + phase][frame] and filtered from there -- same tap order as
+// fir_kernel -- with bias and residual on the way out.  Replaces a generic launch (14.2 us) + a FIR pass (6.5 us).
+template <int R, int MT, int NWN, int K2>
+__global__ __launch_bounds__(64 * MT * NWN) void rate_up_kernel(ConvArgs p) {
+  constexpr int NW = MT * NWN, NT = 64 * NW, BF = 32 * NWN, UP = BF + 1;  // UP: LDS row pitch (M = 32 MT rows)
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // U[M][UP]
+  const int tid = threadIdx.x, lane = tid & 63, lhalf = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % MT, wn = wave / MT;
+  const bool fir = p.fir != nullptr;
+  const int H = fir ? 1 : 0, BV = BF - 2 * H;  // halo frames, frames this block completes
+  const int q0 = blockIdx.x * BV - H, b = blockIdx.y;
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const int Tin = p.Tin, Mp = p.Mp;
+  // ---- operands: B first (older loads return first), then A
+  const int fq = q0 + 32 * wn + l31;
+  const bool inside = fq >= 0 && fq < Tin;
+  const float* xb = p.x + ((size_t)b * p.Cin + lhalf) * Tin + (inside ? fq : 0);
+  float bx[K2], a[K2];
+#pragma unroll
+  for (int ks = 0; ks < K2; ks++) bx[ks] = inside ? xb[(size_t)2 * ks * Tin] : 0.f;
+#pragma unroll
+  for (int ks = 0; ks < K2; ks++) a[ks] = p.w[(size_t)(2 * ks + lhalf) * Mp + 32 * wm + l31];
+  const float alpha = p.alpha_val;
+  const bool act = p.act != 0;
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < K2; ks++) {
+    const float x = bx[ks];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], (act && x < 0.f) ? alpha * x : x, acc, 0, 0, 0);
+  }
+  // ---- phase-GEMM tile -> LDS (frames outside the signal are zero: the 'same' padding of the FIR)
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int row = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+    smem[row * UP + 32 * wn + l31] = inside ? acc[r] : 0.f;
+  }
+  __syncthreads();
+  float f[2 * R + 1];
+#pragma unroll
+  for (int j = 0; j <= 2 * R; j++) f[j] = fir ? p.fir[j] : 0.f;
+  const int Cout = p.Cout;
+  const int span = BV * R;  // output samples per channel
+  const int total = Cout * span;
+  // Rows that are 16-byte multiples: four consecutive samples per thread -- one float4 of the residual in, one float4 out
+  // (a tile's samples of a channel start at a multiple of span, itself a multiple of 4).  Same arithmetic per sample as the
+  // scalar loop below: bit-identical.  (B = 8: 198 MB per launch at 2.7 TB/s with 4-byte accesses.)
+  if ((p.Tout & 3) == 0 && ((BF * R) & 3) == 0 && ((2 * R) & 3) == 0) {
+    constexpr int QPT = (32 * MT / R * BF * R / 4 + NT - 1) / NT;
+    f32x4 rs4[QPT];
+    size_t idx4[QPT];
+    int co4[QPT], tl4[QPT];
+#pragma unroll
+    for (int u = 0; u < QPT; u++) {
+      const int e = 4 * (tid + u * NT);
+      const int co = e / span, tl = e - co * span + H * R;
+      const long t = (long)q0 * R + tl;
+      const bool on = e < total && t < p.Tout;
+      co4[u] = on ? co : -1; tl4[u] = tl;
+      idx4[u] = on ? ((size_t)b * Cout + co) * p.Tout + (size_t)t : 0;
+      rs4[u] = (on && p.res) ? *reinterpret_cast<const f32x4*>(p.res + idx4[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < QPT; u++) {
+      if (co4[u] < 0) continue;
+      const float* urow = smem + (co4[u] * R) * UP;
+      const float bi = p.bias[co4[u]];
+      f32x4 o;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        const int tl = tl4[u] + s4;
+        float v;
+        if (fir) {
+          int tau = tl - R, qf = tau / R, ph = tau - qf * R;
+          v = 0.f;
+#pragma unroll
+          for (int j = 0; j <= 2 * R; j++) {
+            v = fmaf(f[j], urow[ph * UP + qf], v);
+            if (++ph == R) { ph = 0; qf++; }
+          }
+        } else {
+          const int qf = tl / R, ph = tl - qf * R;
+          v = urow[ph * UP + qf];
+        }
+        v += bi;
+        if (p.res) v = (v + rs4[u][s4]) * p.res_scale;
+        o[s4] = v;
+      }
+      *reinterpret_cast<f32x4*>(p.y + idx4[u]) = o;
+    }
+    if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    return;
+  }
+  // outputs in batches of EB per thread: the residual loads of a batch go out together, ahead of the filter
+  constexpr int EPT = (32 * MT / R * BF * R + NT - 1) / NT, EB = 8;
+  static_assert(EPT % EB == 0, "output batches");
+#pragma unroll 1
+  for (int e0 = 0; e0 < EPT; e0 += EB) {
+    float rs[EB];
+    size_t idx[EB];
+    int co_[EB], tl_[EB];
+#pragma unroll
+    for (int u = 0; u < EB; u++) {
+      const int e = tid + (e0 + u) * NT;
+      const int co = e / span, tl = e - co * span + H * R;  // sample index inside the tile (frame tl / R, phase tl % R)
+      const long t = (long)q0 * R + tl;
+      const bool on = e < total && t < p.Tout;
+      co_[u] = on ? co : -1; tl_[u] = tl;
+      idx[u] = on ? ((size_t)b * Cout + co) * p.Tout + (size_t)t : 0;
+      rs[u] = (on && p.res) ? p.res[idx[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < EB; u++) {
+      if (co_[u] < 0) continue;
+      const float* urow = smem + (co_[u] * R) * UP;
+      float v;
+      if (fir) {
+        int tau = tl_[u] - R, qf = tau / R, ph = tau - qf * R;  // tau >= 0: one halo frame in front
+        v = 0.f;
+#pragma unroll
+        for (int j = 0; j <= 2 * R; j++) {
+          v = fmaf(f[j], urow[ph * UP + qf], v);
+          if (++ph == R) { ph = 0; qf++; }
+        }
+      } else {
+        const int qf = tl_[u] / R, ph = tl_[u] - qf * R;
+        v = urow[ph * UP + qf];
+      }
+      v += p.bias[co_[u]];
+      if (p.res) v = (v + rs[u]) * p.res_scale;
+      p.y[idx[u]] = v;
+    }
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+struct RateUpCfg {
+  int R, M, Cin;
+  void (*kern)(ConvArgs);
+  int threads, bf;
+};
+static const RateUpCfg kRateUpCfgs[] = {
+    {2, 64, 64, rate_up_kernel<2, 2, 2, 32>, 256, 64},  // PP16 / OR16: 64 -> 32 channels x 2 phases, T/2 -> T
+    {2, 96, 96, rate_up_kernel<2, 3, 1, 48>, 192, 32},  // PP24: 96 -> 48 x 2
+};
+bool rate_up_supported(const ConvArgs& a) {
+  if (a.up < 2 || a.stride != 1 || a.KW != 1 || a.pad != 0 || a.add || a.film || a.in_scale || a.Nq != a.Tin ||
+      a.Tout != a.Tin * a.up || a.M != a.Cout * a.up)
+    return false;
+  if (a.fir && a.fir_len != 2 * a.up + 1) return false;
+  for (const RateUpCfg& c : kRateUpCfgs)
+    if (c.R == a.up && c.M == a.M && c.Cin == a.Cin) return true;
+  return false;
+}
+hipError_t launch_rate_up(const ConvArgs& a, hipStream_t st, int* cfg_out) {
+  if (!rate_up_supported(a)) return hipErrorNotSupported;
+  for (const RateUpCfg& c : kRateUpCfgs) {
+    if (c.R != a.up || c.M != a.M || c.Cin != a.Cin) continue;
+    const int bv = c.bf - (a.fir ? 2 : 0);
+    const size_t smem = (size_t)c.M * (c.bf + 1) * 4;
+    if (cfg_out) *cfg_out = 45 + c.R;
+    hipLaunchKernelGGL(c.kern, dim3((a.Tin + bv - 1) / bv, a.B), dim3(c.threads), smem, st, a);
+    return hipGetLastError();
+  }
+  return hipErrorNotSupported;
+}
+
+
+}  // namespace ou

@@ -1,0 +1,357 @@
+// gfx950 (CDNA4 / MI355X) kernels of the UNIVERSE(++) enhance path: conv_direct4_kernel -- the 1x1 convs, the transposed
+// convs as phase GEMMs and the k = s = r rate-change convs at FEW output columns (batch 1 .. 4), with 16-byte operand loads.
+// (one translation unit per kernel family; shared device helpers in ou_dev.h, cross-file launchers in ou_internal.h)
+#include "ou_kernels.h"
+#include "ou_internal.h"
+#include "ou_dev.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+namespace ou {
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_direct4_kernel<R, TM, WN, WK, D>
+// What it replaces: conv_direct_kernel<1, ..> / conv_direct_strided_kernel (first-generation register-direct split-K kernels:
+// ONE DWORD per lane and MFMA operand, 1.5 load instructions per MFMA -- bound by the CU's vector-memory issue rate, 25 % of the
+// fp32 MFMA peak at batch 1) for the layers whose reduction is plain channels (x R taps of whole frames):
+//   reference ops: blocks.py:264-283 (rate-change Conv1d / ConvTranspose1d), score.py:189-194 (signal_cond_proj 1x1),
+//   condition.py:33-65 (st convs after space-to-depth), the GRU input projections (score.py:83-89).
+// Operand scheme = conv_direct3s_kernel's (v_mfma_f32_16x16x4_f32, four channels per MFMA):
+//   A (tap k, channels 4J + kk): lane (m, kk) loads TM ADJACENT ROWS m0 + TM m .. of packed weight row (channel, tap) with one
+//     16-byte (TM = 4) / 8-byte (TM = 2) load; the TM 16-row accumulator tiles are row-interleaved (tile i = rows m0 + TM m + i);
+//   B: lane (n, kk) loads the 4 R consecutive samples of its four adjacent output columns (R 16-byte loads); the four column
+//     tiles are column-interleaved (tile j = columns n0 + 4 n + j), column j / tap k is window element j R + k.
+//   2 R load instructions per 4 TM R MFMAs (first generation: 3 R dword loads per 2 R MFMAs of twice the size).
+// What is new against conv_direct3s_kernel (which needs >= 1.2 wave tiles per SIMD, i.e. batch >= 4):
+//   * the reduction can be SPLIT over the WK waves of a block (slot g of wave wk = channel group wk + WK g), and the tile can
+//     be 32 rows (TM = 2): a 512 x 401 layer gets 8 x 7 x WK = 448 waves instead of 56;
+//   * ONE epilogue for every (up, R, WK): the accumulators go through LDS (16-byte writes, one slab per wave), are reduced over
+//     the K slices on read and leave as 16-byte stores of four CONSECUTIVE output samples -- for the phase GEMMs too (up = 2,
+//     4, 5, 8: sample t = q up + phase is row co up + phase, column q of the tile), where the first generation stored sample by
+//     sample.  With WK = 1 every wave reads back only its own slab: no barrier.
+// Summation order per output: channel groups wk, wk + WK, .. ascending inside a wave (4 channels per MFMA, taps ascending),
+// then the WK partial sums in wave order -- fixed, but not the first generation's (results agree to fp32 rounding).
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+
+template <int R, int TM, int WN, int WK, int D>
+__global__ __launch_bounds__(64 * WN * WK) void conv_direct4_kernel(ConvArgs p) {
+  constexpr int TN = 4, LPS = 2 * R, BM = 16 * TM, NW = WN * WK, EP = 68;
+  static_assert(WN == 1 || WK == 1, "a block is either WN column tiles or WK slices of the reduction");
+  static_assert(TM == 2 || TM == 4, "32- or 64-row tiles");
+  static_assert(D * LPS <= 60, "loads in flight must fit vmcnt");
+  static_assert(D == 2 || D == 4, "ring depth");
+  typedef typename std::conditional<TM == 4, f32x4, f32x2>::type avec;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = WK == 1 ? wv : 0, wk = WK == 1 ? 0 : wv;
+  // blocks L, L + 8, .. (one XCD) walk the row groups of one (batch element, column chunk) pair: a chunk's activations are
+  // fetched into ONE L2; the pairs are numbered through (a short signal has only a chunk or two per element)
+  const int L = blockIdx.x, q8 = L >> 3, rg = q8 % p.grid_m, cidx = (q8 / p.grid_m) * 8 + (L & 7);
+  const int b = cidx / p.grid_n, chunk = cidx - b * p.grid_n;
+  const int n0 = (chunk * WN + wn) * 64, m0 = rg * BM;
+  if (b >= p.B) return;                  // (block-uniform)
+  if (WK == 1 && n0 >= p.Nq) return;     // (wave-uniform; no barrier in the WK = 1 form)
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const int l15 = lane & 15, kk = lane >> 4;
+  const int Tin = p.Tin, Mp = p.Mp, CK = p.CK, lck = 31 - __clz(CK);
+  const float alpha = p.act ? p.alpha_val : 1.0f;
+  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  const u32x4 rw = direct_desc(p.w, (unsigned)p.Cin * (unsigned)R * (unsigned)Mp * 4u);
+  const int avo = (kk * Mp + m0 + TM * l15) * 4;
+  const int c0 = n0 + TN * l15;  // this lane's first output column
+  const int bvo = c0 < p.Nq ? (kk * Tin + c0 * R) * 4 : (int)0x80000000;  // past the buffer: reads as 0
+
+  const int NS = (p.Cin >> 2) / WK;  // ring slots of this wave = groups of 4 channels (launcher: a multiple of D)
+  avec a4[D][R];
+  f32x4 b4[D][R];
+#pragma unroll
+  for (int d0 = 0; d0 < D; d0++)
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      if constexpr (TM == 4) a4[d0][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      else a4[d0][k] = f32x2{0.f, 0.f};
+      b4[d0][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  f32x4acc acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) acc[i][j] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+
+  // Loads and counted waits are inline asm (see conv_direct_kernel: left to the compiler a register ring carried around a loop
+  // resolves to vmcnt(0) at the loop header); ring registers are tied "+v" operands, values are used only after the empty "+v"
+  // asm that follows the wait; tools/check_isa.py verifies the generated code.
+#define OU_ISSUE(g_, d)                                                                                                  \
+  {                                                                                                                      \
+    const int c4 = (wk + WK * (g_)) * 4;                                                                                 \
+    const int wrow = ((c4 >> lck) * R) * CK + (c4 & (CK - 1)); /* packed row of (channel 4 J, tap 0) */                  \
+    const int xso = c4 * Tin * 4;                                                                                        \
+    _Pragma("unroll") for (int k = 0; k < R; k++) {                                                                      \
+      if constexpr (TM == 4)                                                                                             \
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(a4[d][k]) : "v"(avo), "s"(rw), "s"((wrow + k * CK) * Mp * 4)); \
+      else                                                                                                               \
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(a4[d][k]) : "v"(avo), "s"(rw), "s"((wrow + k * CK) * Mp * 4)); \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int k = 0; k < R; k++)                                                                        \
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "+v"(b4[d][k]) : "v"(bvo), "s"(rx), "s"(xso), "n"(16 * k)); \
+  }
+#define OU_MMA(d, out)                                                                                                   \
+  {                                                                                                                      \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS));                                                              \
+    _Pragma("unroll") for (int k = 0; k < R; k++) { asm volatile("" : "+v"(a4[d][k])); asm volatile("" : "+v"(b4[d][k])); } \
+    float X[4 * R];                                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < R; k++) {                                                                      \
+      X[4 * k + 0] = b4[d][k].x; X[4 * k + 1] = b4[d][k].y; X[4 * k + 2] = b4[d][k].z; X[4 * k + 3] = b4[d][k].w;        \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int e = 0; e < 4 * R; e++) X[e] = X[e] >= 0.f ? X[e] : alpha * X[e];                          \
+    _Pragma("unroll") for (int k = 0; k < R; k++)                                                                        \
+      _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                   \
+        const float av = a4[d][k][i];                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < TN; j++)                                                                   \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, X[j * R + k], acc[i][j], 0, 0, 0);                        \
+      }                                                                                                                  \
+  }
+  const bool ts_on = p.tstamps != nullptr;
+  long long tc0 = 0, tc1 = 0, tc2 = 0, tr0 = 0;
+  if (ts_on) { tr0 = (long long)__builtin_amdgcn_s_memrealtime(); tc0 = __builtin_readcyclecounter(); }
+  if constexpr (D == 4) {
+    OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
+    if (ts_on) tc1 = __builtin_readcyclecounter();
+    const int NR = NS / 4;
+    for (int r = 0; r + 1 < NR; r++) {
+      const int g = r * 4;
+      OU_MMA(0, 3); OU_ISSUE(g + 4, 0);
+      OU_MMA(1, 3); OU_ISSUE(g + 5, 1);
+      OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
+      OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
+    }
+    OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
+  } else {
+    OU_ISSUE(0, 0); OU_ISSUE(1, 1);
+    if (ts_on) tc1 = __builtin_readcyclecounter();
+    const int NR = NS / 2;
+    for (int r = 0; r + 1 < NR; r++) {
+      const int g = r * 2;
+      OU_MMA(0, 1); OU_ISSUE(g + 2, 0);
+      OU_MMA(1, 1); OU_ISSUE(g + 3, 1);
+    }
+    OU_MMA(0, 1); OU_MMA(1, 0);
+  }
+  if (ts_on) tc2 = __builtin_readcyclecounter();
+#undef OU_ISSUE
+#undef OU_MMA
+
+  // ---- epilogue.  Accumulator (i, j) of lane (n = l15, q = kk), register r = row TM (4 q + r) + i, column 4 n + j of the tile:
+  // one 16-byte LDS write per (i, r) into this wave's slab [BM][EP].
+  float* Ew = smem + (size_t)wv * BM * EP;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      *reinterpret_cast<f32x4*>(&Ew[(TM * (4 * kk + r) + i) * EP + 4 * l15]) =
+          f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+  if constexpr (WK > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (LDS operations of one wave complete in order)
+
+  // readers: with WK > 1 the whole block shares the tile (slab k = K slice k, summed on read); with WK = 1 every wave reads
+  // back its own slab
+  const int rt = WK == 1 ? lane : tid;
+  constexpr int RNT = WK == 1 ? 64 : 64 * WK;
+  const float* Er = WK == 1 ? Ew : smem;
+  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+  const size_t ybase = (size_t)b * p.Cout * p.Tout;
+  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+  const int nvalid = p.Nq - n0;  // columns of this tile inside the signal (>= 1)
+  if (p.up == 1) {
+    // quad e = (row, four adjacent columns): 16 consecutive lanes = 256 contiguous bytes of one output row
+    constexpr int NQ = BM * 16, QPT = NQ / RNT;
+    static_assert(NQ % RNT == 0, "quads per thread");
+#pragma unroll
+    for (int u = 0; u < QPT; u++) {
+      const int e = rt + u * RNT;
+      const int row = e >> 4, cq = (e & 15) * 4;
+      const int m = m0 + row;
+      if (m >= p.M || cq >= nvalid) continue;
+      const size_t idx = ybase + (size_t)m * p.Tout + n0 + cq;
+      const bool full = cq + 4 <= nvalid;
+      f32x4 ad = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+      if (full) {
+        if (p.add) ad = *reinterpret_cast<const f32x4u*>(p.add + idx);
+        if (p.res) rs = *reinterpret_cast<const f32x4u*>(p.res + idx);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          if (p.add && cq + s < nvalid) ad[s] = p.add[idx + s];
+          if (p.res && cq + s < nvalid) rs[s] = p.res[idx + s];
+        }
+      }
+      f32x4 v = *reinterpret_cast<const f32x4*>(&Er[row * EP + cq]);
+#pragma unroll
+      for (int k = 1; k < WK; k++) v += *reinterpret_cast<const f32x4*>(&Er[(k * BM + row) * EP + cq]);
+      if (p.in_scale) v *= insc;
+      v += p.bias[m];
+      if (p.add) v = (v + ad) * p.add_scale;
+      if (filmb) v = filmb[m] * v + filmb[p.Cout + m];
+      if (p.res) v = (v + rs) * p.res_scale;
+      if (full) {
+        *reinterpret_cast<f32x4u*>(p.y + idx) = v;
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          if (cq + s < nvalid) p.y[idx + s] = v[s];
+      }
+    }
+  } else {
+    // transposed conv as `up` phase GEMMs: row m = co up + phase, column q -> sample t = q up + phase.  Quad e = (channel, four
+    // CONSECUTIVE samples); a channel whose phases straddle two row tiles is completed by both (disjoint samples).
+    const int up = p.up;
+    const int m_hi = (m0 + BM - 1 < p.M - 1) ? m0 + BM - 1 : p.M - 1;
+    const int co_lo = (int)__umulhi((unsigned)m0, p.magic_up);
+    const int nco = (int)__umulhi((unsigned)m_hi, p.magic_up) - co_lo + 1;
+    const int qpc = 16 * up;  // quads per channel: 64 frames x up samples / 4
+    const int total = nco * qpc;
+    for (int e = rt; e < total; e += RNT) {
+      const int cl = (int)__umulhi((unsigned)(e >> 4), p.magic_up);  // e / (16 up)
+      const int tl = (e - cl * qpc) * 4;                              // first local sample of the quad, 0 .. 64 up - 4
+      const int co = co_lo + cl;
+      const int q0 = (int)__umulhi((unsigned)tl, p.magic_up);         // tl / up
+      int ph = tl - q0 * up, q = q0;
+      f32x4 v;
+      bool ok[4];
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int row = co * up + ph - m0;
+        ok[s] = row >= 0 && row < BM && m0 + row <= m_hi && q < nvalid;
+        float a = 0.f;
+        if (ok[s]) {
+          a = Er[row * EP + q];
+#pragma unroll
+          for (int k = 1; k < WK; k++) a += Er[(k * BM + row) * EP + q];
+        }
+        v[s] = a;
+        if (++ph == up) { ph = 0; q++; }
+      }
+      const size_t idx = ybase + (size_t)co * p.Tout + (size_t)n0 * up + tl;
+      const bool full = ok[0] && ok[1] && ok[2] && ok[3];
+      if (!(ok[0] || ok[1] || ok[2] || ok[3])) continue;
+      f32x4 ad = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+      if (full) {
+        if (p.add) ad = *reinterpret_cast<const f32x4u*>(p.add + idx);
+        if (p.res) rs = *reinterpret_cast<const f32x4u*>(p.res + idx);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          if (p.add && ok[s]) ad[s] = p.add[idx + s];
+          if (p.res && ok[s]) rs[s] = p.res[idx + s];
+        }
+      }
+      if (p.in_scale) v *= insc;
+      v += p.bias[co];
+      if (p.add) v = (v + ad) * p.add_scale;
+      if (filmb) v = filmb[co] * v + filmb[p.Cout + co];
+      if (p.res) v = (v + rs) * p.res_scale;
+      if (full) {
+        *reinterpret_cast<f32x4u*>(p.y + idx) = v;
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          if (ok[s]) p.y[idx + s] = v[s];
+      }
+    }
+  }
+  if (ts_on && lane == 0) {  // tuning only (OU_TS): {start ticks, cycles: prologue, main loop, epilogue, -, -, -, end ticks}
+    const long long tc3 = __builtin_readcyclecounter();
+    long long* o = p.tstamps + ((size_t)blockIdx.x * NW + wv) * 8;
+    o[0] = tr0; o[1] = tc1 - tc0; o[2] = tc2 - tc1; o[3] = tc3 - tc2; o[4] = 0; o[5] = 0; o[6] = 0;
+    o[7] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+// ---- dispatch -----------------------------------------------------------------------------------------------
+struct Direct4Cfg {
+  int R, TM, WN, WK, D;
+  void (*kern)(ConvArgs);
+};
+#define OU_D4(R, TM, WN, WK, D) {R, TM, WN, WK, D, conv_direct4_kernel<R, TM, WN, WK, D>}
+// ring depth: 4 slots of 2 R loads while that fits the 6-bit vmcnt and the register file (R <= 2), else 2
+#define OU_D4_SHAPES(R, D)                                                                                    \
+  OU_D4(R, 4, 4, 1, D), OU_D4(R, 2, 4, 1, D), OU_D4(R, 4, 1, 2, D), OU_D4(R, 2, 1, 2, D), OU_D4(R, 4, 1, 4, D), \
+  OU_D4(R, 2, 1, 4, D), OU_D4(R, 4, 1, 8, D), OU_D4(R, 2, 1, 8, D)
+static const Direct4Cfg kDirect4Cfgs[] = {
+    OU_D4_SHAPES(1, 4), OU_D4_SHAPES(2, 4), OU_D4_SHAPES(3, 2), OU_D4_SHAPES(4, 2), OU_D4_SHAPES(5, 2), OU_D4_SHAPES(8, 2),
+};
+static size_t direct4_smem(const Direct4Cfg& c) { return (size_t)c.WN * c.WK * 16 * c.TM * 68 * 4; }
+hipError_t init_direct4_kernels() {
+  for (const Direct4Cfg& c : kDirect4Cfgs) {
+    if (direct4_smem(c) <= 64 * 1024) continue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)direct4_smem(c));
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// Estimated cycles of one launch of shape (TM, WK) -- what the choice between the shapes is based on.  All waves of these
+// launches start together (two resident per SIMD share the matrix pipe), so a launch takes about ceil(waves / SIMDs) wave
+// times; a wave costs its MFMAs (32 cycles each) + a fixed part (prologue / first data / epilogue through LDS, which grows
+// with the slabs the readers sum).
+static double direct4_cost(int R, int TM, int WK, long tiles, int slots, int num_cu) {
+  const long waves = tiles * WK, simds = 4L * num_cu;
+  const double per_wave = (double)(slots / WK) * 4.0 * TM * R * 32.0;
+  const double fixed = 2500.0 + 350.0 * TM + (WK > 1 ? 600.0 + 120.0 * WK * TM / 4.0 : 0.0);
+  const double rounds = (double)((waves + simds - 1) / simds);
+  // a partially filled round still pays the whole wave time; two co-resident waves per SIMD overlap their fixed parts
+  return rounds * per_wave + fixed * (rounds > 1.0 ? 0.5 * (rounds + 1.0) : 1.0);
+}
+
+// force_cfg 300 + 10 * TM + log2(WK): tuning (ou_bench_conv / tools/direct_sweep.py)
+hipError_t launch_conv_direct4(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out, bool probe) {
+  const int R = a.stride > 1 ? a.stride : 1;
+  if (a.KW != R || a.pad != 0 || (a.stride > 1 && (a.up != 1 || a.Tin != a.Nq * R)) || a.Cin % 16 || a.CK % 4 || a.fir ||
+      (a.in_scale != nullptr && a.act))
+    return hipErrorInvalidConfiguration;
+  if ((long)a.Cin * a.Tin * 4 >= (1L << 31) || (long)a.Cin * a.KW * a.Mp * 4 >= (1L << 31)) return hipErrorInvalidConfiguration;
+  if (a.up > 1 && (a.Cout * a.up != a.M || a.Tout != a.Nq * a.up)) return hipErrorInvalidConfiguration;
+  const int slots = a.Cin / 4;
+  const long ct = (a.Nq + 63) / 64;
+  const Direct4Cfg* best = nullptr;
+  double best_cost = 0;
+  auto code = [](const Direct4Cfg& c) { return 10 * c.TM + (c.WK == 1 ? 0 : c.WK == 2 ? 1 : c.WK == 4 ? 2 : 3); };
+  for (int pass = 0; pass < 2 && !best; pass++) {
+    // pass 0: the shape asked for (force_cfg / OU_D4_FORCE) where the layer admits it; pass 1: the cheapest by the estimate
+    const int want = a.force_cfg >= 300 ? a.force_cfg - 300 : (pass == 0 ? a.d4_force : 0);
+    if (pass == 0 && want == 0) continue;
+    if (pass == 1 && a.force_cfg >= 300) break;
+    for (const Direct4Cfg& c : kDirect4Cfgs) {
+      if (c.R != R) continue;
+      if (slots % (c.WK * c.D)) continue;
+      if (want) {
+        if (want != code(c)) continue;
+      } else if (c.TM == 4 && a.M <= 32) {
+        continue;
+      }
+      const long gy = (a.M + 16 * c.TM - 1) / (16 * c.TM);
+      const double cost = direct4_cost(R, c.TM, c.WK, gy * ct * a.B, slots, num_cu);
+      if (!best || cost < best_cost) { best = &c; best_cost = cost; }
+    }
+  }
+  if (!best) return hipErrorInvalidConfiguration;
+  if (probe) return hipSuccess;
+  const Direct4Cfg& c = *best;
+  ConvArgs aa = a;
+  const long gy = (a.M + 16 * c.TM - 1) / (16 * c.TM);
+  aa.grid_m = (int)gy;
+  aa.magic_up = a.up == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.up) + 1u;
+  const long chunks = (ct + c.WN - 1) / c.WN, total8 = (chunks * a.B + 7) / 8 * 8;
+  aa.grid_n = (int)chunks;
+  if (cfg_out) *cfg_out = 300 + code(c);
+  hipLaunchKernelGGL(c.kern, dim3((unsigned)(total8 * gy)), dim3(64 * c.WN * c.WK), direct4_smem(c), stream, aa);
+  return hipGetLastError();
+}
+
+}  // namespace ou

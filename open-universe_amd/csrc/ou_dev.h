@@ -1,0 +1,81 @@
+// Device-side helpers shared by the kernel files: vector typedefs, buffer descriptors, LDS-DMA, counted waits.
+// No portability layer: wave = 64, fp32 MFMA, DPP row reductions, agent-scope granule hand-offs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ou_kernels.h"
+
+namespace ou {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// a float4 at any 4-byte boundary: global dwordx4 accesses need dword alignment only (rows of 401 / 2005 frames)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+// global -> LDS copies (LDS-DMA): the destination is wave-uniform `lds` + lane * size.  Kept in non-template device
+// functions: the generic -> LDS address-space cast must not be instantiated on the host side of a kernel template.
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void dma_b32(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds, 4, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void dma_b128(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds, 16, voff, soff, 0, 0);
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): vmcnt = bits [3:0] | [15:14],
+// expcnt / lgkmcnt left at their maxima.
+#define OU_VMCNT_CASE(n) case n: __builtin_amdgcn_s_waitcnt(((n) & 0xF) | (((n) >> 4) << 14) | 0x0F70); break;
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+    OU_VMCNT_CASE(1) OU_VMCNT_CASE(2) OU_VMCNT_CASE(3) OU_VMCNT_CASE(4) OU_VMCNT_CASE(5) OU_VMCNT_CASE(6)
+    OU_VMCNT_CASE(7) OU_VMCNT_CASE(8) OU_VMCNT_CASE(9) OU_VMCNT_CASE(10) OU_VMCNT_CASE(11) OU_VMCNT_CASE(12)
+    OU_VMCNT_CASE(13) OU_VMCNT_CASE(14) OU_VMCNT_CASE(15) OU_VMCNT_CASE(16)
+    default: __builtin_amdgcn_s_waitcnt(0x0F70); break;  // 0, or out of table: wait for everything (always safe)
+  }
+}
+
+// Block -> output tile of the direct kernels (same XCD-aware mappings as conv_mfma_kernel).  false: padding block.
+__device__ __forceinline__ bool direct_tile(const ConvArgs& p, int& tile_m, int& tile_n) {
+  const int L = blockIdx.x, gx = p.grid_n, gy = p.grid_m;
+  if (p.xcd_map == 1) {
+    const int q = L >> 3, mg = q / gx;
+    tile_n = q - mg * gx;
+    tile_m = mg * 8 + (L & 7);
+  } else if (p.xcd_map == 2) {
+    const int q = L >> 3, ng = q / gy;
+    tile_m = q - ng * gy;
+    tile_n = ng * 8 + (L & 7);
+    if (tile_n >= gx) return false;
+  } else {
+    tile_m = L / gx;
+    tile_n = L - tile_m * gx;
+  }
+  return true;
+}
+__device__ __forceinline__ u32x4 direct_desc(const void* base, unsigned bytes) {
+  // buffer descriptor as a plain SGPR quad (base, bounds, raw-dword format) for the inline-asm loads
+  const unsigned long long a = (unsigned long long)base;
+  u32x4 d;
+  d.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  d.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+  d.z = __builtin_amdgcn_readfirstlane(bytes);
+  d.w = 0x00020000u;
+  return d;
+}
+
+__device__ __forceinline__ float prelu(float v, float a) { return v >= 0.f ? v : a * v; }
+
+}  // namespace ou

@@ -36,9 +36,13 @@ struct ConvArgs {
   int force_xcd_map = -1;              // tuning: 0 / 1 / 2
   double tile_min = -1.0;              // OU_TILE_MIN (< 0: the launcher's default of 1.2 wave tiles per SIMD)
   int tile_prefetch = 1;               // OU_TILE_PREFETCH: LDS prefetch of the epilogue operand in conv_direct3_kernel
-  int direct = 3;                      // OU_CONV_DIRECT: 0 = never use the register-direct kernels, 1 = only the first
+  int direct = 4;                      // OU_CONV_DIRECT: 0 = never use the register-direct kernels, 1 = only the first
                                        // generation (dword loads), 2 = + wide-load split-K variant where a layer has `wd`,
-                                       // 3 = + the no-split-K throughput kernel (conv_direct3_kernel) for many-column launches
+                                       // 3 = + the no-split-K throughput kernel (conv_direct3_kernel) for many-column launches,
+                                       // 4 = + the wide-load split-K kernel for 1x1 / phase-GEMM / rate-change layers
+                                       //     (conv_direct4_kernel)
+  int d4_fir_unfused = 1;              // OU_D4_FIR=0: up convs with a fusable FIR stay on the first-generation fused kernel
+  int d4_force = 0;                    // OU_D4_FORCE = 10 TM + log2(WK): that tile shape wherever a layer admits it (tests / tuning)
   // Anti-alias FIR of the up path fused into the epilogue (direct kernel, up > 1, KW == 1 only; launch_conv returns
   // hipErrorNotSupported otherwise and the caller runs launch_fir after a plain launch):
   //   y = FIR_{2 up + 1}(u) + bias ; y = res ? (y + res) * res_scale : y,   u = the transposed conv's output WITHOUT bias
@@ -184,13 +188,17 @@ struct GruArgs {
   int agent_stores = 1;  // 1 (default): publish with agent-scope (sc1) stores; 0: plain stores when the cluster shares one XCD
   int dbg = 0;           // experiments (OU_GRU_DBG): bit 0 = no republish safety net, bit 1 = system-scope publishes from the start,
                          // bit 2 = fault injection: one workgroup drops its publishes of step 50
-  int shared = 0;      // 1: another GRU layer may be resident at the same time (side streams): size launches to half the chip
+  int share = 1;       // GRU launches that may be resident on one XCD at the same time, this one included (2: another layer on a
+                       // side stream; more: other lanes of the process, ou_set_lanes): a launch takes 1 / share of an XCD
+  int lanes = 1;       // enhance calls in flight side by side in this process
+  int xcd_rot = 0;     // cluster c of the launch is dealt to XCD (c + xcd_rot) % 8
+  unsigned long long* prof = nullptr;  // measurement: 16 x min block start, 16 x ~max block end (10 ns ticks), like ConvArgs
   int force_bmax = 0;  // testing: cap the utterances per launch (forces the chunked path at small batches)
   int force_upw = 0;  // tuning: 16 / 32 / 64 hidden units per workgroup (0: chosen from the batch size)
 };
 hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st);
 // utterances one ring-kernel launch can carry with its whole grid resident (0: hidden size not supported)
-int gru_ring_batch_cap(int H, int num_cu, int shared, int force_upw, int B);
+int gru_ring_batch_cap(int H, int num_cu, int share, int force_upw, int B, int lanes);
 // 8-byte exchange granules needed for a batch of B sequences with hidden size H (both kernel generations)
 inline size_t gru_granules(int B, int H) { return (size_t)2 * B * (2 * H + 64); }
 

@@ -159,7 +159,8 @@ def plan_batches(lengths, indices, batch_size, pad_batch=False):
     return groups
 
 
-def enhance_sharded(model, signals, seed=1028282, gather=True, batch_size=1, pad_batch=False, **enhance_kwargs):
+def enhance_sharded(model, signals, seed=1028282, gather=True, batch_size=1, pad_batch=False, in_flight=1,
+                    **enhance_kwargs):
     """Enhance a list of 1-D signals (any lengths) across the ranks of the current process group.
 
     Rank r takes its LPT shard (`shard_utterances`) and walks it in `plan_batches` groups: up to `batch_size`
@@ -168,6 +169,13 @@ def enhance_sharded(model, signals, seed=1028282, gather=True, batch_size=1, pad
     would use, so with pad_batch=False the result of an utterance does not depend on the sharding or the grouping
     beyond fp32 summation order (the conv tilings are chosen from the total column count of a call: batched vs single
     agree to > 100 dB, same grouping = bit-identical; a 1-rank and an N-rank run with batch_size=1 are bit-identical).
+
+    in_flight=K > 1: K calls of the shard are in flight side by side on K streams of this rank's GPU (`lanes.LanePool`:
+    one handle + workspace per lane) -- the mode for RAGGED sets, which cannot be batched without changing their
+    results: every call is exactly the call of the serial loop (same kernels, tilings, summation orders), so the
+    outputs are bit-identical to in_flight=1 while the device overlaps the GRU passes and the small launches of one
+    utterance with the kernels of the others.
+
     Results are gathered on rank 0 in the original order (None on the other ranks; with gather=False every rank
     returns {index: tensor} of its shard)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
@@ -176,30 +184,43 @@ def enhance_sharded(model, signals, seed=1028282, gather=True, batch_size=1, pad
     mine = shard_utterances(lengths, world)[rank]
     outs = {}
     batched_ok = not any(enhance_kwargs.get(k) is not None for k in ("target", "ensemble"))
-    # The shard runs free: no host synchronisation between the calls (the device status word is sticky and is examined once
-    # after the loop), so the host work of the next call -- generator seeding, the walk of the network, ~400 launches --
-    # overlaps the kernels of the current one.  With a sync after every call that work sat between the calls: 8.27 instead
-    # of 7.4 ms per utterance at batch_size=1.
-    sync_mode = getattr(model, "check_status", None)
-    if sync_mode is not None:
-        model.check_status = False
-    try:
-        for group in plan_batches(lengths, mine, batch_size if batched_ok else 1, pad_batch):
-            if len(group) == 1:
-                i = group[0]
-                outs[i] = model.enhance(signals[i].to(model.device), rng=utterance_generator(model.device, seed, i),
-                                        **enhance_kwargs)
-                continue
-            res = model.enhance_many([signals[i].to(model.device) for i in group],
-                                     [utterance_generator(model.device, seed, i) for i in group], pad_batch=pad_batch,
-                                     **enhance_kwargs)
-            for i, o in zip(group, res):
-                outs[i] = o
-    finally:
+    groups = plan_batches(lengths, mine, batch_size if batched_ok else 1, pad_batch)
+
+    def run_group(m, group):
+        if len(group) == 1:
+            i = group[0]
+            return [m.enhance(signals[i].to(m.device), rng=utterance_generator(m.device, seed, i), **enhance_kwargs)]
+        return m.enhance_many([signals[i].to(m.device) for i in group],
+                              [utterance_generator(m.device, seed, i) for i in group], pad_batch=pad_batch,
+                              **enhance_kwargs)
+
+    in_flight = max(1, int(in_flight))
+    if in_flight > 1 and getattr(model, "fork", None) is not None and enhance_kwargs.get("target") is None:
+        from .lanes import LanePool
+
+        with LanePool(model, min(in_flight, LanePool.MAX_LANES)) as pool:
+            for group in groups:
+                _, res = pool.submit(lambda m, g=group: run_group(m, g))
+                for i, o in zip(group, res):
+                    outs[i] = o
+            pool.synchronize()  # raises on a device-side time-out of any call of the shard
+    else:
+        # The shard runs free: no host synchronisation between the calls (the device status word is sticky and is examined
+        # once after the loop), so the host work of the next call -- generator seeding, the walk of the network, ~400
+        # launches -- overlaps the kernels of the current one.  With a sync after every call that work sat between the
+        # calls: 8.27 instead of 7.4 ms per utterance at batch_size=1.
+        sync_mode = getattr(model, "check_status", None)
         if sync_mode is not None:
-            model.check_status = sync_mode
-    if sync_mode is not None:
-        model.synchronize()  # raises on a device-side time-out of any call of the shard
+            model.check_status = False
+        try:
+            for group in groups:
+                for i, o in zip(group, run_group(model, group)):
+                    outs[i] = o
+        finally:
+            if sync_mode is not None:
+                model.check_status = sync_mode
+        if sync_mode is not None:
+            model.synchronize()  # raises on a device-side time-out of any call of the shard
     if not gather:
         return outs
     return gather_outputs([outs[i] for i in mine], mine, len(signals))

@@ -79,7 +79,27 @@ class Universe:
         self._ws = None
         self._ws_key = None
         self._ws_cache = {}
+        self._ws_need = {}
         self._cond_key = None
+        self._lanes = (1, 0)
+
+    # ---- several enhance calls in flight in one process -----------------------------------------------------------
+    def fork(self):
+        """A second model object on the SAME packed weights (no copy) with a handle, workspace and status record of its
+        own: what one lane of `LanePool` runs on.  A handle is not re-entrant; several handles side by side are fine."""
+        twin = type(self)(self.spec, packed_weights=self._weights, device=self.device)
+        twin.check_status = self.check_status
+        if self.gru_agent_scope:
+            twin.gru_agent_scope = True
+            _lib.check(twin._L.ou_set_gru_publish_mode(twin._handle, 1), twin._handle)
+        return twin
+
+    def set_lanes(self, lanes, lane):
+        """This object is lane `lane` of `lanes` models whose calls are in flight side by side on this device (one stream
+        each): the library then sizes and places the GRU clusters of every lane so that all of them fit on the device
+        together (include/ouniverse.h, ou_set_lanes)."""
+        _lib.check(self._L.ou_set_lanes(self._handle, int(lanes), int(lane)), self._handle)
+        self._lanes = (int(lanes), int(lane))
 
     # ------------------------------------------------------------------------------------------------
     def __del__(self):
@@ -109,42 +129,70 @@ class Universe:
     def _stream(self):
         return c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    # workspaces kept alive (most recently used last): a directory of files alternates between a handful of
-    # (batch, length) shapes, and a workspace costs an allocation plus ou_workspace_init
+    # workspaces kept alive, ONE per batch size (most recently used last): a buffer prepared by ou_workspace_init for
+    # (B, T) serves every shorter length of the same batch size (include/ouniverse.h), so a directory of files of different
+    # lengths runs on one buffer that grows to the longest file seen; a workspace costs an allocation plus the init
     WS_CACHE_ENTRIES = 4
     WS_CACHE_BYTES = 16 << 30
 
+    def _workspace_bytes(self, B, T):
+        n = self._ws_need.get((B, T))
+        if n is None:
+            c = c_size_t()
+            _lib.check(self._L.ou_workspace_bytes(self._handle, B, T, byref(c)), self._handle)
+            n = self._ws_need[(B, T)] = c.value
+            if len(self._ws_need) > 4096:
+                self._ws_need.clear()
+        return n
+
     def _workspace(self, B, T):
         key = (B, T)
-        if self._ws_key != key:
+        if self._ws_key == key:
+            return self._ws
+        need = self._workspace_bytes(B, T)
+        cache = self._ws_cache
+        ws = cache.get(B)
+        if ws is None or ws.numel() < need:
             # free-running mode: the status copy of the previous call belongs to the workspace that is left now -- the next
             # call's copy would replace it unexamined
             if self._status_event is not None and not self.check_status:
                 self._status_event.synchronize()
                 self._raise_on_status()
-            cache = self._ws_cache
-            if key in cache:
-                cache[key] = cache.pop(key)  # move to the back
-            else:
-                n = c_size_t()
-                _lib.check(self._L.ou_workspace_bytes(self._handle, B, T, byref(n)), self._handle)
-                while cache and (len(cache) >= self.WS_CACHE_ENTRIES
-                                 or sum(w.numel() for w in cache.values()) + n.value > self.WS_CACHE_BYTES):
-                    cache.pop(next(iter(cache)))
-                self._ws = None
-                ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
-                with torch.cuda.device(self.device):
-                    _lib.check(self._L.ou_workspace_init(self._handle, B, T, c_void_p(ws.data_ptr()),
-                                                         c_size_t(n.value), self._stream()), self._handle)
-                cache[key] = ws
-            self._ws = cache[key]
-            self._ws_key = key
-            self._cond_key = None
+            cache.pop(B, None)
+            while cache and (len(cache) >= self.WS_CACHE_ENTRIES
+                             or sum(w.numel() for w in cache.values()) + need > self.WS_CACHE_BYTES):
+                cache.pop(next(iter(cache)))
+            self._ws = ws = None
+            try:
+                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            except torch.OutOfMemoryError:
+                # give the idle workspaces (and the allocator's cached blocks) back and try once more
+                cache.clear()
+                torch.cuda.empty_cache()
+                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(self._L.ou_workspace_init(self._handle, B, T, c_void_p(ws.data_ptr()),
+                                                     c_size_t(need), self._stream()), self._handle)
+        elif self._ws is not ws and self._status_event is not None and not self.check_status:
+            self._status_event.synchronize()
+            self._raise_on_status()
+        cache.pop(B, None)
+        cache[B] = ws  # most recently used last
+        self._ws = ws
+        self._ws_key = key
+        self._cond_key = None
         return self._ws
 
     def reset_workspace(self):
         """Drop every cached workspace: the next call allocates and initialises a fresh one (tests; after switching
         between kernel generations that lay the GRU exchange area out differently)."""
+        if self._status_event is not None:
+            # a status copy of an earlier call may still be pending: look at it while its workspace is still known
+            self._status_event.synchronize()
+            try:
+                self._raise_on_status()
+            finally:
+                self._status_event = None
         self._ws_cache.clear()
         self._ws = None
         self._ws_key = None
@@ -460,6 +508,11 @@ class Universe:
         for k in ("target", "ensemble", "fake_score_snr"):
             if other.get(k) is not None:
                 raise ValueError(f"enhance_many does not take `{k}` (call enhance per input)")
+        unknown = set(other) - {"target", "ensemble", "fake_score_snr", "ensemble_stat", "rng"}
+        if unknown:  # (a typo must not change behaviour on the batched path only)
+            raise TypeError(f"enhance_many() got unexpected keyword argument(s): {sorted(unknown)}")
+        if other.get("rng") is not None:
+            raise ValueError("enhance_many takes the generators as `rngs` (one per input, or one shared)")
         if not signals:
             return []
         rows, dims = [], []

@@ -1,0 +1,152 @@
+"""GPU (-m gpu): K enhance calls in flight side by side in one process (open_universe_amd.lanes.LanePool,
+`enhance_sharded(..., in_flight=K)`, `bin/enhance.py --in-flight K`) -- the mode for RAGGED utterance sets, the reference
+CLI's real workload (bin/enhance.py:173-192 walks a directory of files of arbitrary lengths one by one).  Every utterance is
+computed by exactly the launches of the one-at-a-time call, so the outputs must be BIT-IDENTICAL to the serial loop's; what
+changes is only what runs beside what (GRU clusters of all lanes resident together, one workspace per lane that serves every
+length)."""
+import os
+import sys
+
+import pytest
+import torch
+
+import restatement as O
+from helpers import get_spec, record, synth_mix
+from open_universe_amd import state_dict as S
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_models = {}
+
+
+def get_model(name):
+    from open_universe_amd import Universe, UniverseGAN
+
+    if name not in _models:
+        spec = get_spec(name)
+        sd = S.synthetic_state_dict(spec, seed=0)
+        cls = UniverseGAN if spec.kind == "universe_gan" else Universe
+        _models[name] = (cls(spec, state_dict=sd, device="cuda:0"), spec, sd)
+    return _models[name]
+
+
+def ragged(spec, n, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    cand = sorted({int(v) for v in torch.randint(lo, hi, (4 * n,), generator=g).tolist()})
+    lens = cand[::max(1, len(cand) // n)][:n]  # n different lengths spread over [lo, hi)
+    assert len(lens) == n
+    g2 = torch.Generator().manual_seed(seed + 1)
+    order = torch.randperm(n, generator=g2).tolist()
+    return [synth_mix(spec, 1, lens[i], seed=300 + i)[0] for i in order]
+
+
+@pytest.mark.parametrize("name,n,lo,hi,lanes", [("PP16m", 12, 900, 9000, 4), ("PP16", 8, 16000, 64000, 4),
+                                                ("PP16", 6, 8000, 40000, 2), ("OR16", 6, 4000, 24000, 3),
+                                                ("PP24", 5, 6000, 30000, 4), ("PP16", 9, 3000, 20000, 8)])
+def test_in_flight_is_bit_identical_to_the_serial_loop(name, n, lo, hi, lanes):
+    from open_universe_amd import distributed as D
+
+    model, spec, sd = get_model(name)
+    sigs = ragged(spec, n, lo, hi, seed=11)
+    assert len({int(s.shape[-1]) for s in sigs}) == n  # all lengths different: nothing here can be batched
+    serial = D.enhance_sharded(model, sigs, seed=5, n_steps=3)
+    flying = D.enhance_sharded(model, sigs, seed=5, n_steps=3, in_flight=lanes)
+    again = D.enhance_sharded(model, sigs, seed=5, n_steps=3, in_flight=lanes)
+    st = model.gru_exchange_stats()
+    for k, (a, b, c) in enumerate(zip(serial, flying, again)):
+        assert a.shape == sigs[k].shape
+        if lanes <= 4:
+            assert torch.equal(a, b), (name, k, float(O.si_sdr(a, b)))
+        else:  # beyond 4 lanes the recurrence may split the hidden units differently (16 per workgroup): fp32 rounding
+            record(f"lanes{lanes}.{name}.{k}", O.si_sdr(a, b), 100)
+        assert torch.equal(b, c)
+    assert st["recoveries"] == 0, st
+    # the primary model is back in single-lane mode and still agrees with itself
+    solo = model.enhance(sigs[0].cuda(), n_steps=3, rng=D.utterance_generator(model.device, 5, 0)).cpu()
+    assert torch.equal(solo, serial[0])
+
+
+def test_in_flight_vs_oracle_and_one_workspace_for_all_lengths():
+    """A lane's workspace is prepared once (ou_workspace_init) and serves every shorter length of the same batch size."""
+    from open_universe_amd import distributed as D
+
+    model, spec, sd = get_model("PP16m")
+    sigs = ragged(spec, 6, 700, 5000, seed=23)
+    longest = max(sigs, key=lambda s: s.shape[-1])
+    model.reset_workspace()
+    model.enhance(longest.cuda(), n_steps=2)  # sizes the batch-1 workspace for the longest
+    ws = model._ws
+    outs = D.enhance_sharded(model, sigs, seed=9, n_steps=3, in_flight=3)
+    assert model._ws is ws and len(model._ws_cache) == 1
+    sdict = spec.to_dict()
+    for k, s in enumerate(sigs):
+        # (the device generator's draws cannot be reproduced on the CPU: the oracle gets explicit noise, and so does the
+        # HIP path -- on the workspace that was prepared for the longest signal)
+        g = torch.Generator().manual_seed(9 + k)
+        T = s.shape[-1] + (spec.tot_ds - s.shape[-1] % spec.tot_ds)
+        nz = [torch.randn(1, 1, T, generator=g) for _ in range(3)]
+        ref = O.enhance(sd, sdict, s[None], n_steps=3, noise=nz)[0]
+        hip = model._enhance(s[None].cuda(), 3, None, None, None, None, False, False, None, "median", None,
+                             [z.cuda() for z in nz]).cpu()[0]
+        record(f"lanes.ws_reuse.PP16m.{k}", O.si_sdr(ref, hip), 80)
+        assert outs[k].shape == s.shape
+
+
+def test_growing_lengths_regrow_the_workspace():
+    model, spec, sd = get_model("PP16m")
+    model.reset_workspace()
+    a = synth_mix(spec, 1, 1000)[0].cuda()
+    b = synth_mix(spec, 1, 6000)[0].cuda()
+    g = lambda: torch.Generator(device="cuda").manual_seed(3)  # noqa: E731
+    ya = model.enhance(a, n_steps=2, rng=g())
+    n_small = model._ws.numel()
+    yb = model.enhance(b, n_steps=2, rng=g())
+    assert model._ws.numel() > n_small and len(model._ws_cache) == 1
+    ya2 = model.enhance(a, n_steps=2, rng=g())  # the short one again, now on the big workspace
+    assert torch.equal(ya, ya2)
+    model.reset_workspace()
+    yb2 = model.enhance(b, n_steps=2, rng=g())
+    assert torch.equal(yb, yb2)
+
+
+def test_lane_stress_loop():
+    """30 rounds of 4 lanes x ragged headline-size utterances: no time-out, no safety-net recovery, same bits every round."""
+    from open_universe_amd import distributed as D
+
+    model, spec, sd = get_model("PP16")
+    sigs = ragged(spec, 8, 30000, 64000, seed=31)
+    first = None
+    for it in range(30):
+        outs = D.enhance_sharded(model, sigs, seed=1, n_steps=2, in_flight=4)
+        if first is None:
+            first = outs
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(first, outs)), it
+    assert model.gru_exchange_stats()["recoveries"] == 0
+
+
+def test_cli_in_flight_matches_file_by_file(tmp_path):
+    """`--in-flight K` writes the same files as the serial loop, with the shared generator (draws in processing order) and
+    with --per-file-seed."""
+    from open_universe_amd import audio
+    from open_universe_amd.bin import enhance as cli
+
+    model, spec, sd = get_model("PP16m")
+    src = tmp_path / "in"
+    src.mkdir()
+    g = torch.Generator().manual_seed(4)
+    for i, n in enumerate([3100, 1800, 4100, 2500, 3333, 900, 2750]):
+        audio.save(src / f"f{i}.wav", 0.3 * torch.randn(1, n, generator=g).clamp(-1, 1), spec.fs)
+    for extra in ([], ["--per-file-seed"]):
+        o1, o2 = tmp_path / ("a" + str(len(extra))), tmp_path / ("b" + str(len(extra)))
+        o1.mkdir()
+        o2.mkdir()
+        cli.main([str(src), str(o1), "--n_steps", "3", "--seed", "5"] + extra, model=model)
+        cli.main([str(src), str(o2), "--n_steps", "3", "--seed", "5", "--in-flight", "3"] + extra, model=model)
+        names = sorted(p.name for p in o1.iterdir())
+        assert names == sorted(p.name for p in o2.iterdir()) and len(names) == 7
+        for nme in names:
+            a, fa = audio.load(o1 / nme)
+            b, fb = audio.load(o2 / nme)
+            assert fa == fb and torch.equal(a, b), nme

@@ -411,7 +411,7 @@ def test_wide_load_direct_kernel_is_bit_identical_to_the_dword_one(name, B, T, m
     nz = noise_list(47, 2, B, Tp)
     monkeypatch.setenv("OU_CONV_DIRECT", "1")
     ref = run_enhance(model, mix, nz, n_steps=2)
-    monkeypatch.delenv("OU_CONV_DIRECT")
+    monkeypatch.setenv("OU_CONV_DIRECT", "2")  # (level 4 would move the 1x1 / rate-change layers to conv_direct4_kernel)
     out = run_enhance(model, mix, nz, n_steps=2)
     assert torch.equal(ref, out)  # (T <= 32 768: both generations take the same layers)
 
@@ -423,7 +423,7 @@ def test_wide_load_direct_kernel_at_the_headline_size(monkeypatch):
     nz = noise_list(49, 2, 1, 64160)
     monkeypatch.setenv("OU_CONV_DIRECT", "1")
     ref = run_enhance(model, mix, nz, n_steps=2)
-    monkeypatch.delenv("OU_CONV_DIRECT")
+    monkeypatch.setenv("OU_CONV_DIRECT", "2")
     out = run_enhance(model, mix, nz, n_steps=2)
     record("direct2_vs_direct1.PP16.64000", O.si_sdr(ref[0], out[0]), 100)
 
@@ -437,6 +437,9 @@ def test_fused_up_fir_epilogue_is_bit_identical_to_the_fir_pass(name, B, T, monk
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(41, 2, B, Tp)
+    # (the first-generation split-K kernel is the one with the fused FIR epilogue; by default those up convs now run on
+    # conv_direct4_kernel + the FIR pass)
+    monkeypatch.setenv("OU_CONV_DIRECT", "3")
     monkeypatch.setenv("OU_FUSE_UPFIR", "0")
     ref = run_enhance(model, mix, nz, n_steps=2)
     n_ref = model.launch_stats()
@@ -547,3 +550,59 @@ def test_pad_and_post_kernels_around_their_register_limit(T, keep_rms):
     out = run_enhance(model, mix, nz, n_steps=2, keep_rms=keep_rms)
     assert out.shape == ref.shape == (B, T)
     record(f"padpost.T{T}.rms{int(keep_rms)}", O.si_sdr(ref, out))
+
+
+def _d4_launches(model):
+    """conv launches of the profiled calls that ran on conv_direct4_kernel (variant 300 + 10 TM + log2 WK)"""
+    return [r[3] for r in model.profile_read() if 300 <= r[3] < 400]
+
+
+@pytest.mark.parametrize("name,B,T", [("PP16", 1, 64000), ("PP16", 2, 23517), ("PP24", 1, 30011), ("OR16", 3, 9000),
+                                      ("PP16m", 2, 3000), ("PP16", 1, 777)])
+def test_wide_load_1x1_kernel_matches_the_first_generation(name, B, T, monkeypatch):
+    """conv_direct4_kernel (16-byte operand loads, 16x16x4 MFMA, split-K over the waves where a layer has few tiles, one
+    LDS-staged epilogue with 16-byte stores for every `up`) takes the 1x1 convs, the phase GEMMs of the transposed convs and
+    the k = s = r rate-change convs that conv_direct_kernel / conv_direct_strided_kernel had (OU_CONV_DIRECT=3): same
+    convolution, different summation order -- >= 100 dB end to end, and against the oracle like every other path.  Ragged
+    lengths put partial column tiles, partial quads and (up = 5, M = 1280) channels that straddle two row tiles into play."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(53, 3, B, Tp)
+    monkeypatch.setenv("OU_CONV_DIRECT", "3")
+    ref = run_enhance(model, mix, nz, n_steps=3)
+    monkeypatch.delenv("OU_CONV_DIRECT")
+    model.profile(True)
+    out = run_enhance(model, mix, nz, n_steps=3)
+    taken = _d4_launches(model)
+    model.profile(False)
+    assert len(taken) >= 10, taken  # the family is what runs by default
+    out2 = run_enhance(model, mix, nz, n_steps=3)
+    assert torch.equal(out, out2)
+    for b in range(B):
+        record(f"direct4_vs_gen1.{name}.T{T}.{b}", O.si_sdr(ref[b], out[b]), 100)
+    if T <= 30011:
+        e_ref = O.enhance(sd, spec.to_dict(), mix, n_steps=3, noise=nz)
+        record(f"direct4_vs_oracle.{name}.T{T}", O.si_sdr(e_ref, out), 80)
+
+
+@pytest.mark.parametrize("shape", [20, 21, 22, 23, 40, 41, 42, 43])
+@pytest.mark.parametrize("name,B,T", [("PP16", 1, 8000), ("PP24", 2, 5000)])
+def test_every_tile_shape_of_the_wide_load_1x1_kernel(name, B, T, shape, monkeypatch):
+    """OU_D4_FORCE = 10 TM + log2(WK): that tile shape on every layer that admits it (channel groups divisible by WK x ring
+    depth), the launcher's own choice elsewhere -- all eight shapes (32 / 64 rows; reduction split over 1 / 2 / 4 / 8 waves)
+    against the first-generation kernels on the same inputs."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(59, 2, B, Tp)
+    monkeypatch.setenv("OU_CONV_DIRECT", "3")
+    ref = run_enhance(model, mix, nz, n_steps=2)
+    monkeypatch.delenv("OU_CONV_DIRECT")
+    monkeypatch.setenv("OU_D4_FORCE", str(shape))
+    model.profile(True)
+    out = run_enhance(model, mix, nz, n_steps=2)
+    taken = _d4_launches(model)
+    model.profile(False)
+    assert taken.count(300 + shape) >= 4, (shape, sorted(set(taken)))
+    record(f"direct4_shape{shape}_vs_gen1.{name}", O.si_sdr(ref, out), 100)
