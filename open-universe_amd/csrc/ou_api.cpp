@@ -598,7 +598,7 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
   const int L = T / m.tot_ds;
   const int n = m.n_levels - 1;
   hipStream_t main = r.st;
-  const bool ov = r.h->overlap && !r.dry;
+  const bool ov = r.h->overlap && !r.dry && r.h->lanes <= 1;
   // --- MelAdapter  condition.py:110-114 (independent of the encoder chain: side stream 0)
   if (ov) { r.fork(main, 0); r.st = r.h->aux[0]; }
   Tensor mel = r.alloc("cond.mel", m.mel.n_mels, L);
@@ -992,7 +992,11 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
   const bool use_aux = (flags & OU_ENH_USE_AUX_SIGNAL) != 0;
   const bool saved_overlap = h->overlap;
   struct OverlapGuard { ou_handle* h; bool v; ~OverlapGuard() { h->overlap = v; } } overlap_guard{h, saved_overlap};
-  if (flags & OU_ENH_SERIAL) h->overlap = false;
+  // Side streams inside the call only when this is the one call on the device.  With several lanes (ou_set_lanes) every lane
+  // is ONE chain on its caller's stream: HIP multiplexes its streams onto a handful of hardware queues, and four lanes with
+  // four streams each alias there -- measured: 4 lanes 122 utt/s with side streams (87 % of the time ONE kernel on the
+  // device), 209 utt/s as four chains (serial loop: 132).
+  if ((flags & OU_ENH_SERIAL) || h->lanes > 1) h->overlap = false;
   if (!use_aux && !noise) return fail(h, OU_EINVAL, "noise must be given");
   if (n_steps < 2 || n_steps > kMaxSteps) return fail(h, OU_EINVAL, "n_steps must be in [2, 256]");
   if (warm_start >= n_steps) return fail(h, OU_EINVAL, "warm_start must be < n_steps");
@@ -1135,14 +1139,16 @@ int ou_transform_inverse(const float* spec, int32_t B, int32_t n_frames, const f
 
 int ou_check_device_status(ou_handle* h, void* ws) {
   if (!h || !ws) return fail(h, OU_EINVAL, "bad argument");
-  unsigned hdr[32];
+  unsigned hdr[40];
   hipError_t e = hipMemcpy(hdr, ws, sizeof(hdr), hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(h, OU_EHIP, hipGetErrorString(e));
   const unsigned v = hdr[0];
-  // word 20: publishes the GRU clusters' safety net had to repeat on this workspace.  The first time it moves the cheap
-  // publish form has shown that it cannot be relied upon on this device / in this process mix: agent-scope publishes from
-  // now on (+0.1 ms per GRU pass, no more 0.1 ms recoveries).  Results are unaffected either way.
-  if (hdr[20] != 0u && !h->gru_agent_stores) h->gru_agent_stores = 1;
+  // word 20: waits the GRU clusters' safety net cut short by repeating a publish (a member that was merely late counts
+  // too); word 33: those among them where the awaited granule was visible to a system-scope load / an atomic but NOT to the
+  // agent-scope load of the gather.  The first time word 33 moves, the cheap publish form has shown that it cannot be
+  // relied upon on this device / in this process mix: agent-scope publishes from now on (+0.1 ms per GRU pass, no more
+  // 0.1 ms recoveries).  Results are unaffected either way.
+  if (hdr[33] != 0u && !h->gru_agent_stores) h->gru_agent_stores = 1;
   h->gru_recoveries_seen = hdr[20];
   if (v) {
     (void)hipMemset(ws, 0, sizeof(v));  // sticky until read

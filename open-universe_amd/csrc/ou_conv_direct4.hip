@@ -48,12 +48,26 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_direct4_kernel(ConvArgs p) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = WK == 1 ? wv : 0, wk = WK == 1 ? 0 : wv;
-  // blocks L, L + 8, .. (one XCD) walk the row groups of one (batch element, column chunk) pair: a chunk's activations are
-  // fetched into ONE L2; the pairs are numbered through (a short signal has only a chunk or two per element)
-  const int L = blockIdx.x, q8 = L >> 3, rg = q8 % p.grid_m, cidx = (q8 / p.grid_m) * 8 + (L & 7);
+  // Which operand an XCD's L2 owns (block L runs on XCD L % 8, private 4 MB L2):
+  //   xcd_map 2 (activations >= weights): blocks L, L + 8, .. walk the row groups of one (batch element, column chunk) pair --
+  //     a chunk's activations are fetched into ONE L2, every XCD reads all the weights; the pairs are numbered through (a
+  //     short signal has only a chunk or two per element);
+  //   xcd_map 1 (weights > activations: the 401-frame levels, the K = 5120 st convs): row groups are dealt to the XCDs, the
+  //     blocks of an XCD walk the column chunks of ITS row groups -- every XCD reads an eighth of the weights and all the
+  //     activations (3 + 8 x 0.8 MB instead of 8 x 3 + 0.8 MB of fabric traffic for the GRU input projection).
+  const int L = blockIdx.x, q8 = L >> 3;
+  int rg, cidx;
+  if (p.xcd_map == 1) {
+    const int gm8 = (p.grid_m + 7) >> 3;
+    rg = (q8 % gm8) * 8 + (L & 7);
+    cidx = q8 / gm8;
+  } else {
+    rg = q8 % p.grid_m;
+    cidx = (q8 / p.grid_m) * 8 + (L & 7);
+  }
   const int b = cidx / p.grid_n, chunk = cidx - b * p.grid_n;
   const int n0 = (chunk * WN + wn) * 64, m0 = rg * BM;
-  if (b >= p.B) return;                  // (block-uniform)
+  if (b >= p.B || rg >= p.grid_m) return;  // (block-uniform)
   if (WK == 1 && n0 >= p.Nq) return;     // (wave-uniform; no barrier in the WK = 1 form)
   if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
   const int l15 = lane & 15, kk = lane >> 4;
@@ -296,17 +310,19 @@ hipError_t init_direct4_kernels() {
   return hipSuccess;
 }
 
-// Estimated cycles of one launch of shape (TM, WK) -- what the choice between the shapes is based on.  All waves of these
-// launches start together (two resident per SIMD share the matrix pipe), so a launch takes about ceil(waves / SIMDs) wave
-// times; a wave costs its MFMAs (32 cycles each) + a fixed part (prologue / first data / epilogue through LDS, which grows
-// with the slabs the readers sum).
-static double direct4_cost(int R, int TM, int WK, long tiles, int slots, int num_cu) {
-  const long waves = tiles * WK, simds = 4L * num_cu;
-  const double per_wave = (double)(slots / WK) * 4.0 * TM * R * 32.0;
-  const double fixed = 2500.0 + 350.0 * TM + (WK > 1 ? 600.0 + 120.0 * WK * TM / 4.0 : 0.0);
-  const double rounds = (double)((waves + simds - 1) / simds);
-  // a partially filled round still pays the whole wave time; two co-resident waves per SIMD overlap their fixed parts
-  return rounds * per_wave + fixed * (rounds > 1.0 ? 0.5 * (rounds + 1.0) : 1.0);
+// Which (TM, WK) a layer gets.  Measured (tools/d4_sweep.py, PP16 at B = 1 / 4 / 8, profiles/r04_d4_sweep_*): 32-row tiles
+// with the reduction split 4 or 8 ways are within ~5 % of the best shape on every layer -- a wave's LDS slab (16 TM x 68
+// floats) caps a CU at 8 waves with 64-row tiles and at 16 with 32-row tiles, and one or two waves per SIMD run their MFMA loop
+// at 55-77 % (operand latency is longer than the ring) -- as long as a wave keeps >= 64 MFMAs of its own and the launch stays
+// under ~12 000 waves.  (An estimate of cycles per launch picked worse shapes than this rule on a third of the layers: block
+// counts just above a multiple of the CU count, LDS-limited residency and the single-wave MFMA rate all enter.)
+static bool direct4_pick(int M, long ct_b, int slots, int R, int D, int* tm_out, int* wk_out) {
+  const long tiles = (long)((M + 31) / 32) * ct_b;
+  int wk = 8;
+  while (wk > 1 && (slots % (wk * D) != 0 || (slots / wk) * 8 * R < 64 || tiles * wk > 12000)) wk >>= 1;
+  if (slots % (wk * D)) return false;
+  *tm_out = 2; *wk_out = wk;
+  return true;
 }
 
 // force_cfg 300 + 10 * TM + log2(WK): tuning (ou_bench_conv / tools/direct_sweep.py)
@@ -319,26 +335,26 @@ hipError_t launch_conv_direct4(const ConvArgs& a, int num_cu, hipStream_t stream
   if (a.up > 1 && (a.Cout * a.up != a.M || a.Tout != a.Nq * a.up)) return hipErrorInvalidConfiguration;
   const int slots = a.Cin / 4;
   const long ct = (a.Nq + 63) / 64;
+  // The 401-frame levels at batch 1 - 2 (7 column tiles per element, M = 512 .. 1536: a few hundred tiles whatever the shape)
+  // stay with the first-generation kernels: 12.1 vs 12.9 us on the GRU input projection, 6.3 vs 8.0 on the 512-channel 1x1,
+  // 33 vs 49 on the K = 5120 st convs; from batch 4 this kernel is 3-8 % ahead there too.
+  if (a.force_cfg < 300 && a.d4_force == 0 && a.Nq < 1024 && a.B < 4) return hipErrorInvalidConfiguration;
   const Direct4Cfg* best = nullptr;
-  double best_cost = 0;
   auto code = [](const Direct4Cfg& c) { return 10 * c.TM + (c.WK == 1 ? 0 : c.WK == 2 ? 1 : c.WK == 4 ? 2 : 3); };
+  const int D = R <= 2 ? 4 : 2;
+  int want = a.force_cfg >= 300 ? a.force_cfg - 300 : a.d4_force;
   for (int pass = 0; pass < 2 && !best; pass++) {
-    // pass 0: the shape asked for (force_cfg / OU_D4_FORCE) where the layer admits it; pass 1: the cheapest by the estimate
-    const int want = a.force_cfg >= 300 ? a.force_cfg - 300 : (pass == 0 ? a.d4_force : 0);
-    if (pass == 0 && want == 0) continue;
-    if (pass == 1 && a.force_cfg >= 300) break;
-    for (const Direct4Cfg& c : kDirect4Cfgs) {
-      if (c.R != R) continue;
-      if (slots % (c.WK * c.D)) continue;
-      if (want) {
-        if (want != code(c)) continue;
-      } else if (c.TM == 4 && a.M <= 32) {
-        continue;
-      }
-      const long gy = (a.M + 16 * c.TM - 1) / (16 * c.TM);
-      const double cost = direct4_cost(R, c.TM, c.WK, gy * ct * a.B, slots, num_cu);
-      if (!best || cost < best_cost) { best = &c; best_cost = cost; }
+    // pass 0: the shape asked for (force_cfg / OU_D4_FORCE) where the layer admits it; pass 1: the rule
+    if (pass == 1) {
+      if (a.force_cfg >= 300) break;
+      int tm = 0, wk = 0;
+      if (!direct4_pick(a.M, ct * a.B, slots, R, D, &tm, &wk)) break;
+      want = 10 * tm + (wk == 1 ? 0 : wk == 2 ? 1 : wk == 4 ? 2 : 3);
+    } else if (want == 0) {
+      continue;
     }
+    for (const Direct4Cfg& c : kDirect4Cfgs)
+      if (c.R == R && slots % (c.WK * c.D) == 0 && code(c) == want) { best = &c; break; }
   }
   if (!best) return hipErrorInvalidConfiguration;
   if (probe) return hipSuccess;
@@ -347,10 +363,15 @@ hipError_t launch_conv_direct4(const ConvArgs& a, int num_cu, hipStream_t stream
   const long gy = (a.M + 16 * c.TM - 1) / (16 * c.TM);
   aa.grid_m = (int)gy;
   aa.magic_up = a.up == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.up) + 1u;
-  const long chunks = (ct + c.WN - 1) / c.WN, total8 = (chunks * a.B + 7) / 8 * 8;
+  const long chunks = (ct + c.WN - 1) / c.WN;
   aa.grid_n = (int)chunks;
+  // which operand an XCD's L2 owns (see the kernel): the larger one
+  const double xb = (double)a.Cin * a.Tin * a.B, wb = (double)a.M * a.Cin * a.KW;
+  aa.xcd_map = wb > xb ? 1 : 2;
+  if (a.force_xcd_map == 1 || a.force_xcd_map == 2) aa.xcd_map = a.force_xcd_map;
+  const long nblocks = aa.xcd_map == 1 ? 8L * ((gy + 7) / 8) * chunks * a.B : (chunks * a.B + 7) / 8 * 8 * gy;
   if (cfg_out) *cfg_out = 300 + code(c);
-  hipLaunchKernelGGL(c.kern, dim3((unsigned)(total8 * gy)), dim3(64 * c.WN * c.WK), direct4_smem(c), stream, aa);
+  hipLaunchKernelGGL(c.kern, dim3((unsigned)nblocks), dim3(64 * c.WN * c.WK), direct4_smem(c), stream, aa);
   return hipGetLastError();
 }
 

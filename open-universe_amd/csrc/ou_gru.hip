@@ -315,6 +315,10 @@ __device__ __attribute__((noinline)) void gru_stale_probe(const unsigned long lo
     const unsigned long long v = __hip_atomic_fetch_or(const_cast<unsigned long long*>(g), 0ull, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_AGENT);
     c = u32x2{(unsigned)v, (unsigned)(v >> 32)};
+    // status word 33: events where the granule HAD arrived for a system-scope load or an atomic but not for the agent-scope
+    // load the gather uses -- the cheap publish form really failed (what the host switches the publish mode on).  Everything
+    // else counted in word 20 is a member that was late (descheduled / starved by the kernels of other streams).
+    if (b.y == want || c.y == want) atomicAdd(err + 33, 1u);
     if (atomicAdd(err + 21, 1u) == 0u) {
       unsigned now;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(now));

@@ -202,18 +202,20 @@ class Universe:
     def _raise_on_status(self):
         self._status_event = None
         v = int(self._status_host[0])
-        # word 20: publishes the GRU clusters' safety net had to repeat on this workspace (0 on a healthy device).  The first
-        # time it moves, the cheaper publish form has shown that it cannot be relied upon on this device / in this process
-        # mix: switch to agent-scope (write-through) publishes for good -- +0.1 ms per GRU pass, no more recoveries.
-        rec = int(self._status_host[20])
-        if rec and not self.gru_agent_scope and not v:
+        # word 20: waits the GRU clusters' safety net cut short by repeating a publish (0 on an idle device; a member that was
+        # merely late -- starved by the kernels of other streams or lanes -- counts too); word 33: those among them where the
+        # awaited granule was visible to a system-scope load / an atomic but not to the agent-scope load of the gather.  The
+        # first time word 33 moves, the cheaper publish form has shown that it cannot be relied upon on this device / in this
+        # process mix: switch to agent-scope (write-through) publishes for good -- +0.1 ms per GRU pass, no more recoveries.
+        rec, lost = int(self._status_host[20]), int(self._status_host[33])
+        if lost and not self.gru_agent_scope and not v:
             import warnings
 
             self.gru_agent_scope = True
             _lib.check(self._L.ou_set_gru_publish_mode(self._handle, 1), self._handle)
-            warnings.warn(f"open_universe_amd: {rec} GRU hand-off(s) had to be repeated by the kernel's safety net "
-                          f"(first event: {self._status_host[21:30].tolist()}); results are unaffected, the recurrence "
-                          "kernels publish with agent-scope stores from now on", RuntimeWarning)
+            warnings.warn(f"open_universe_amd: {lost} of {rec} repeated GRU hand-off(s) were publishes that an agent-scope load "
+                          f"did not see (first event: {self._status_host[21:30].tolist()}); results are unaffected, the "
+                          "recurrence kernels publish with agent-scope stores from now on", RuntimeWarning)
         if v:
             ws = self._status_ws if self._status_ws is not None else self._ws
             diag = ws[:256].view(torch.int32).cpu().tolist()  # who waited for what (see gru_ring_kernel)
@@ -265,9 +267,10 @@ class Universe:
         repeated by the safety net (each costs ~0.1 ms), `system_scope` = waves that finished their GRU pass with
         system-scope publishes after such a recovery (slower steps, no more recoveries).  Both 0 on a healthy device."""
         if self._ws is None:
-            return {"recoveries": 0, "system_scope": 0}
+            return {"recoveries": 0, "lost": 0, "system_scope": 0}
         d = self._ws[:128].view(torch.int32).cpu().tolist()
-        out = {"recoveries": int(d[20]), "system_scope": int(d[31])}
+        # recoveries: waits cut short by the safety net (late members included); lost: publishes that really were invisible
+        out = {"recoveries": int(d[20]), "lost": int(d[33]), "system_scope": int(d[31])}
         out["agent_scope_publishes"] = bool(self.gru_agent_scope)
         if d[21]:  # first recovery on this workspace: what three kinds of loads saw in the stale granule (gru_stale_probe)
             out["first_event"] = {"events": d[21], "cluster": (d[22] >> 16) & 0xFFFF, "member": (d[22] >> 8) & 0xFF,

@@ -1,5 +1,7 @@
 """GPU (-m gpu): the two generations of the GRU cluster kernel (torch.nn.GRU semantics, score.py:83-89,116 /
 condition.py:173-179,212) against each other and the epoch-tag machinery of the ring kernel."""
+import ctypes
+
 import pytest
 import torch
 
@@ -82,21 +84,52 @@ def test_ring_kernel_epoch_wrap(monkeypatch):
 def test_ring_kernel_recovers_a_lost_publish(monkeypatch):
     """Fault injection (OU_GRU_DBG=4): one workgroup of every cluster drops its publishes of step 50.  The safety net --
     every waiting wave repeats its last publish as a system-scope store after 256 poll rounds and keeps publishing that
-    way for the rest of the launch -- has to bring the pass to the same result, bit for bit, without a timeout."""
+    way for the rest of the launch -- has to bring the pass to the same result, bit for bit, without a timeout.  A publish
+    that was never stored looks like a LATE member to the probe (no kind of load sees it): counted as a recovery, not as a
+    lost publish, so the handle keeps the cheap publish form."""
     model, spec, sd = get_model("PP16")
     mix = synth_mix(spec, 1, 32000)
     nz = noise_list(61, 2, 1, 32160)
     ref = run_enhance(model, mix, nz, n_steps=2)
     base = model.gru_exchange_stats()
     monkeypatch.setenv("OU_GRU_DBG", "4")
-    with pytest.warns(RuntimeWarning, match="GRU hand-off"):
-        out = run_enhance(model, mix, nz, n_steps=2)
+    out = run_enhance(model, mix, nz, n_steps=2)
     monkeypatch.delenv("OU_GRU_DBG")
     after = model.gru_exchange_stats()
     assert torch.equal(ref, out)
     assert after["recoveries"] > base["recoveries"] and after["system_scope"] > base["system_scope"]
-    # the host wrapper has seen the recovery counter move and switched the publishes to agent-scope stores for good
-    assert model.gru_agent_scope and after["agent_scope_publishes"] and "first_event" in after
+    assert after["lost"] == base["lost"] and "first_event" in after
+    assert not model.gru_agent_scope and model._L.ou_get_gru_publish_mode(model._handle) == 0
+    assert torch.equal(run_enhance(model, mix, nz, n_steps=2), ref)
+    model.reset_workspace()
+
+
+def test_publish_mode_switches_for_good_when_a_publish_was_invisible(monkeypatch):
+    """Status word 33 = recoveries where the awaited granule was there for a system-scope load / an atomic but not for the
+    agent-scope load of the gather: the cheap (plain-store) publish form has failed on this device.  The Python wrapper
+    (status copy of every call) and the C layer (ou_check_device_status, for callers of the C ABI) both switch the handle to
+    agent-scope publishes for good the first time that word moves.  The word is poked by hand here; results do not change."""
+    model, spec, sd = get_model("PP16m")
+    mix = synth_mix(spec, 1, 4000)
+    T = 4000 + (spec.tot_ds - 4000 % spec.tot_ds)
+    nz = noise_list(63, 2, 1, T)
+    ref = run_enhance(model, mix, nz, n_steps=2)
+    assert not model.gru_agent_scope
+    hdr = model._ws[:256].view(torch.int32)
+    hdr[20] = 3
+    hdr[33] = 1
+    torch.cuda.synchronize()
+    # the C layer on its own
+    assert model._L.ou_get_gru_publish_mode(model._handle) == 0
+    assert model._L.ou_check_device_status(model._handle, ctypes.c_void_p(model._ws.data_ptr())) == 0
+    assert model._L.ou_get_gru_publish_mode(model._handle) == 1
+    model._L.ou_set_gru_publish_mode(model._handle, 0)
+    # the Python wrapper
+    with pytest.warns(RuntimeWarning, match="agent-scope stores from now on"):
+        out = run_enhance(model, mix, nz, n_steps=2)
+    assert model.gru_agent_scope and model.gru_exchange_stats()["agent_scope_publishes"]
+    assert model._L.ou_get_gru_publish_mode(model._handle) == 1
+    assert torch.equal(out, ref)
     assert torch.equal(run_enhance(model, mix, nz, n_steps=2), ref)  # same result with write-through publishes
     model._L.ou_set_gru_publish_mode(model._handle, 0)  # (the model is shared by the other tests: back to the default)
     model.gru_agent_scope = False

