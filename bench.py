@@ -51,6 +51,129 @@ def synth_mix(fs, B, T, seed0):
     return torch.stack(out)
 
 
+def host_cpu_info():
+    """lscpu's view of the host: model name, sockets, physical cores, logical CPUs."""
+    import subprocess
+
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {}
+        for line in out.splitlines():
+            if ":" in line:
+                k, v = line.split(":", 1)
+                kv[k.strip()] = v.strip()
+        info["model"] = kv.get("Model name")
+        sockets = int(kv.get("Socket(s)", "0") or 0)
+        cps = int(kv.get("Core(s) per socket", "0") or 0)
+        info["sockets"] = sockets or None
+        info["physical_cores"] = sockets * cps or None
+        info["threads_per_core"] = int(kv.get("Thread(s) per core", "0") or 0) or None
+    except Exception as e:  # lscpu missing: /proc/cpuinfo has the model at least
+        info["lscpu_error"] = repr(e)[:100]
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    info["model"] = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+    return info
+
+
+class GpuSampler:
+    """sclk / power of the device while a leg runs: a thread polling the amdgpu sysfs files (hwmon freq1_input, power1_average /
+    power1_input) of the card; falls back to `rocm-smi --json` when sysfs has nothing to offer."""
+
+    def __init__(self, period_s=0.25, device_index=0):
+        import glob
+        import threading
+
+        self.period = period_s
+        self.samples = []  # (t, sclk MHz or None, W or None)
+        self._stop = threading.Event()
+        self._freq, self._power = [], []
+        # the sysfs card of THIS HIP device (a box exposes every GPU of the node under /sys/class/drm): match the PCI address
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        except Exception:
+            pass
+        self.card = None
+        cards = []
+        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(os.path.join(card, "vendor")).read().strip() != "0x1002":
+                    continue
+            except OSError:
+                continue
+            cards.append(card)
+        match = [c for c in cards if want and os.path.basename(os.path.realpath(c)).lower().startswith(want)]
+        for card in match or (cards if len(cards) == 1 else []):
+            self._freq = sorted(glob.glob(os.path.join(card, "hwmon/hwmon*/freq1_input")))
+            self._power = sorted(glob.glob(os.path.join(card, "hwmon/hwmon*/power1_average"))) or \
+                sorted(glob.glob(os.path.join(card, "hwmon/hwmon*/power1_input")))
+            if self._freq or self._power:
+                self.card = f"{os.path.basename(os.path.dirname(card))} ({os.path.basename(os.path.realpath(card))})"
+                break
+        self.source = "sysfs hwmon" if (self._freq or self._power) else "rocm-smi"
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(paths, scale):
+        for p in paths:
+            try:
+                return float(open(p).read().strip()) * scale
+            except (OSError, ValueError):
+                continue
+        return None
+
+    def _smi(self):
+        import subprocess
+
+        try:
+            out = subprocess.run(["rocm-smi", "-c", "-P", "--json"], capture_output=True, text=True, timeout=5).stdout
+            d = json.loads(out)
+            card = next(iter(d.values()))
+            sclk = next((v for k, v in card.items() if "sclk" in k.lower() and "(" in str(v)), None)
+            mhz = float(str(sclk).split("(")[1].split("M")[0]) if sclk else None
+            pw = next((float(v) for k, v in card.items() if "power" in k.lower() and str(v).replace(".", "").isdigit()), None)
+            return mhz, pw
+        except Exception:
+            return None, None
+
+    def _run(self):
+        t0 = time.perf_counter()
+        while not self._stop.is_set():
+            if self.source == "sysfs hwmon":
+                mhz, w = self._read(self._freq, 1e-6), self._read(self._power, 1e-6)
+            else:
+                mhz, w = self._smi()
+            self.samples.append((time.perf_counter() - t0, mhz, w))
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=10)
+        return False
+
+    def summary(self):
+        f = [m for _, m, _ in self.samples if m]
+        w = [p for _, _, p in self.samples if p]
+        out = {"source": self.source, "card": self.card, "samples": len(self.samples), "period_s": self.period}
+        if f:
+            out["sclk_MHz"] = {"min": min(f), "max": max(f), "mean": sum(f) / len(f), "first": f[0], "last": f[-1]}
+        if w:
+            out["power_W"] = {"min": min(w), "max": max(w), "mean": sum(w) / len(w)}
+        out["trace_t_s_sclk_MHz_power_W"] = [[round(t, 2), m, p] for t, m, p in self.samples[:: max(1, len(self.samples) // 48)]]
+        return out
+
+
 def cpu_baseline_worker(model_name, n_steps, seconds, budget_s):
     """Runs in a child process: the oracle timed on the host cores.  The intra-op thread count is SWEPT (8 / 16 / 32 /
     64 / 128, capped by the logical CPUs): batch-1 convolutions of this size do not scale to a whole two-socket host --
@@ -101,11 +224,15 @@ def cpu_baseline_worker(model_name, n_steps, seconds, budget_s):
         per_step = max(0.0, (med - t2) / (n_meas - 2))
         med = t2 + per_step * (n_steps - 2)
         how += f" at {n_meas} steps, extended linearly to {n_steps} steps with the 2-step run ({per_step:.2f} s per step)"
+    host = host_cpu_info()
     print("CPU_BASELINE_JSON " + json.dumps({
         "value": seconds / med,
         "unit": "x_realtime",
         "utterances_per_s": 1.0 / med,
         "cores": best,
+        "cores_note": "torch intra-op threads of the best run of the sweep (the threads actually used); the host's sockets / "
+                      "physical cores / logical CPUs are in `host`",
+        "host": host,
         "kind": "port",
         "thread_sweep_s_per_enhance": {str(k): round(v, 3) for k, v in sweep.items()},
         "sample": f"1 utterance of {seconds:.0f} s, {model_name}, {n_steps} steps, {how} "
@@ -135,6 +262,33 @@ def cpu_baseline(model_name, n_steps, seconds, budget_s=30.0, hard_limit_s=180.0
                 "sample": f"cpu baseline did not finish within {hard_limit_s:.0f} s (skipped)"}
 
 
+# tools/ubench/xchg_latency.hip (profiles/r03_final_ubench_xchg_latency.txt): a bare all-gather step of 16 workgroups through
+# L2 -- one store latency + one load latency, no compute -- takes 859 cycles of the 2.4 GHz shader clock
+GRU_HANDOFF_FLOOR_US = 859 / 2400.0
+
+
+def gru_roofline(gru_recs, args, ms_per_enhance):
+    """The recurrence is latency-bound (T sequential steps, one L2 hand-off each), not MFMA- or HBM-bound: its figure of
+    merit is microseconds per step against the measured floor of the hand-off itself."""
+    if not gru_recs:
+        return None
+    n_prof = max(1, args.profile_steps)
+    us = [1e3 * r[0] for r in gru_recs]
+    steps = [r[3] - 1000 for r in gru_recs]
+    per_step = sum(us) / sum(steps)
+    return {"kernel": "ou::gru_ring_kernel (bidirectional GRU recurrence: a cluster of H / 8 workgroups per direction keeps W_hh in "
+                      "registers, h is exchanged through L2 with {value, tag} granules)",
+            "bound": "latency (one store + one load through L2 per time step)",
+            "passes_per_enhance": len(gru_recs) // n_prof, "steps_per_pass": steps[0],
+            "us_per_pass": sum(us) / len(us), "us_per_step": per_step,
+            "handoff_floor_us_per_step": GRU_HANDOFF_FLOOR_US, "frac_of_floor": GRU_HANDOFF_FLOOR_US / per_step,
+            "ms_per_enhance": sum(us) / 1e3 / n_prof, "share_of_enhance": sum(us) / 1e3 / n_prof / ms_per_enhance,
+            "algorithmic_gflop_per_enhance": sum(r[1] for r in gru_recs) / n_prof / 1e9,
+            "tflops": sum(r[1] for r in gru_recs) / (sum(us) * 1e-6) / 1e12,
+            "method": "device-side first-block-start .. last-block-end of every GRU launch of the profiled pass (same stamps as "
+                      "the conv launches); floor = tools/ubench/xchg_latency.hip (859 cycles at 2.4 GHz)"}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +306,13 @@ def parse_args(argv=None):
     ap.add_argument("--share-devices", action="store_true",
                     help="allow more ranks than visible GPUs (ranks wrap around the devices, gloo rendezvous): "
                          "exercises the N > 1 path on a 1-GPU box; not a scaling measurement")
-    ap.add_argument("--batch-sweep", default="1,4",
+    ap.add_argument("--sustained-s", type=float, default=10.0,
+                    help="length of the sustained leg (back-to-back free-running enhance calls with the device clock and power "
+                         "sampled beside them); 0 = off")
+    ap.add_argument("--in-flight", default="4",
+                    help="lanes of the ragged-set leg (32 utterances of 32 different lengths through "
+                         "distributed.enhance_sharded, serial loop vs K calls in flight); '' = off")
+    ap.add_argument("--batch-sweep", default="1,4,8",
                     help="also time these per-GPU batch sizes (short loops after the main one): one invocation gives the "
                          "utterances/s curve of configs[1] (batch 1) and of the batched throughput mode; '' = off")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -304,6 +464,76 @@ def main():
         batch_sweep[str(bs)] = {"ms_per_step": 1e3 * dt_b / k, "utterances_per_s": k * bs * world / dt_b, "steps": k}
     step()  # back on the headline shape (workspace of the main configuration is current again)
 
+    # ---- sustained rate: >= args.sustained_s of back-to-back free-running calls, per-window rates, sclk / power beside them
+    sustained = None
+    if rank == 0 and world == 1 and args.sustained_s > 0 and not args.varlen:
+        model.check_status = False
+        win = 100
+        per_call = dt_async / args.steps
+        n_calls = max(2 * win, int(args.sustained_s / per_call / win + 0.999) * win)
+        marks = []
+        with GpuSampler(device_index=device.index) as smp:
+            torch.cuda.synchronize()
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            t0 = time.perf_counter()
+            for i in range(n_calls):
+                step()
+                if (i + 1) % win == 0:  # a window closes on the DEVICE: an event behind its last call
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    marks.append(e)
+            torch.cuda.synchronize()
+            total = time.perf_counter() - t0
+        model.check_status = True
+        model._status(force=True)
+        ends = [ev0.elapsed_time(e) * 1e-3 for e in marks]
+        wins = [ends[0]] + [ends[i] - ends[i - 1] for i in range(1, len(ends))]
+        rates = [win * args.batch / w for w in wins]
+        sustained = {"seconds": total, "calls": n_calls, "ms_per_step": 1e3 * total / n_calls,
+                     "utterances_per_s": n_calls * args.batch / total, "window_calls": win,
+                     "window_utterances_per_s": {"min": min(rates), "max": max(rates), "first": rates[0], "last": rates[-1]},
+                     "vs_short_loop": (n_calls * args.batch / total) / (args.steps * args.batch / dt_async),
+                     "device": smp.summary(),
+                     "note": "free-running calls (no host sync inside the loop) for >= --sustained-s seconds; windows are closed by "
+                             "events on the stream (device time); vs_short_loop = this rate / the free-running rate of the "
+                             "--steps loop above; `device` = sclk / power of THIS GPU's sysfs card sampled beside the loop"}
+
+    # ---- ragged utterance sets (the reference CLI's real workload): serial loop vs K calls in flight (lanes) -------------
+    in_flight = None
+    if rank == 0 and world == 1 and args.in_flight.strip() and not args.varlen and args.batch == 1:
+        n_utt = 32
+        gl = torch.Generator().manual_seed(17)
+        lens = set()
+        while len(lens) < n_utt:
+            lens.add(int(spec.fs * args.seconds * (0.875 + 0.125 * float(torch.rand(1, generator=gl)))))
+        lens = sorted(lens)
+        lens = [lens[i] for i in torch.randperm(n_utt, generator=gl).tolist()]
+        sigs = [synth_mix(spec.fs, 1, n, 2000 + i)[0].to(device) for i, n in enumerate(lens)]
+
+        def rate(k):
+            best = None
+            for _ in range(2):  # (the first pass creates the lanes and their workspaces)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                o = D.enhance_sharded(model, sigs, seed=3, gather=False, in_flight=k, n_steps=args.n_steps)
+                torch.cuda.synchronize()
+                best = time.perf_counter() - t0
+            return best, o
+
+        t1, ref = rate(1)
+        in_flight = {"utterances": n_utt, "lengths_s": [min(lens) / spec.fs, max(lens) / spec.fs], "all_lengths_different": True,
+                     "serial": {"utterances_per_s": n_utt / t1, "ms_per_utterance": 1e3 * t1 / n_utt}}
+        for k in [int(v) for v in args.in_flight.split(",") if v.strip()]:
+            tk, ok_ = rate(k)
+            in_flight[f"lanes_{k}"] = {"utterances_per_s": n_utt / tk, "ms_per_utterance": 1e3 * tk / n_utt,
+                                       "real_time_factor": sum(lens) / spec.fs / tk,
+                                       "bit_identical_to_serial": all(torch.equal(ref[i], ok_[i]) for i in ref)}
+        in_flight["note"] = ("distributed.enhance_sharded on ONE GPU, 32 utterances of 32 different lengths (cannot be batched "
+                             "without changing their result): one call at a time vs K calls in flight on K streams "
+                             "(open_universe_amd/lanes.py), every call the same launches as in the serial loop")
+        step()
+
     # ---- host side: time to ENQUEUE one enhance (no sync), eager walk of the network vs one hipGraph replay ----
     host_enqueue = None
     if rank == 0 and not args.varlen:
@@ -363,8 +593,11 @@ def main():
         # records: (ms, algorithmic flops, algorithmic bytes, variant); variant < 40: conv_mfma_kernel tile configs,
         # 40-49: rate_down_kernel,
         # 66 / 76: conv_direct2_kernel, other 50-99: conv_direct_kernel / conv_direct_strided_kernel variants,
-        # 100-199: conv_chain_kernel (fused ConvBlock body), >= 200: conv_direct3_kernel (2xx: 200 + 10 TM + KW) /
-        # conv_direct3s_kernel (260 + R).
+        # 100-199: conv_chain_kernel (fused ConvBlock body), 200-299: conv_direct3_kernel (2xx: 200 + 10 TM + KW) /
+        # conv_direct3s_kernel (260 + R), 300-399: conv_direct4_kernel (300 + 10 TM + log2 WK), >= 1000: one GRU pass
+        # (1000 + steps).
+        gru_recs = [r for r in recs if r[3] >= 1000]
+        recs = [r for r in recs if r[3] < 1000]
         def summarise(rr):
             if not rr:
                 return None
@@ -379,8 +612,10 @@ def main():
                     "algorithmic_bytes_per_launch": by_ / len(rr)}
         KERNELS = {
             "direct2": "ou::conv_direct2_kernel (register-direct split-K fp32-MFMA Conv1d, wide operand loads: k3 / k5 layers)",
-            "direct": "ou::conv_direct_kernel / conv_direct_strided_kernel (register-direct split-K: 1x1, phase-GEMM and "
-                      "rate-change convs)",
+            "direct": "ou::conv_direct_kernel / conv_direct_strided_kernel (first-generation register-direct split-K, dword "
+                      "operand loads: 1x1, phase-GEMM and rate-change convs of the 401-frame levels at batch 1 - 2)",
+            "direct4": "ou::conv_direct4_kernel (wide-load split-K: 1x1, phase-GEMM and rate-change convs; 16x16x4 fp32 MFMA, "
+                       "16-byte operand loads, LDS-staged epilogue with 16-byte stores)",
             "lds": "ou::conv_mfma_kernel (LDS-tiled fp32-MFMA implicit-GEMM Conv1d, wide levels / strided convs)",
             "rate": "ou::rate_down_kernel / rate_up_kernel (outermost rate-change convs with the anti-alias FIR fused, K = 64)",
             "chain": "ou::conv_chain_kernel (fused ConvBlock body, C = 32 / 64 levels)",
@@ -392,8 +627,10 @@ def main():
                   "lds": summarise([r for r in recs if r[3] < 40]),
                   "rate": summarise([r for r in recs if 40 <= r[3] < 50]),
                   "chain": summarise([r for r in recs if 100 <= r[3] < 200]),
-                  "direct3": summarise([r for r in recs if r[3] >= 200])}
+                  "direct3": summarise([r for r in recs if 200 <= r[3] < 300]),
+                  "direct4": summarise([r for r in recs if 300 <= r[3] < 400])}
         groups = {k: v for k, v in groups.items() if v}
+        fam = summarise([r for r in recs if (50 <= r[3] < 100 and r[3] not in (66, 76)) or 300 <= r[3] < 400 or 260 <= r[3] < 270])
         dom = max(groups, key=lambda k: groups[k]["ms_per_enhance"])  # the dominant kernel = most time per enhance
         gen = groups[dom]
         allconv = summarise(list(recs))
@@ -462,6 +699,12 @@ def main():
             "all_conv_kernels": {"achieved": allconv["tflops"], "frac": allconv["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                                  "launches": allconv["launches"], "ms_per_enhance": allconv["ms_per_enhance"],
                                  "algorithmic_gflop_per_enhance": allconv["algorithmic_gflop_per_enhance"]},
+            "pointwise_family": None if not fam else {
+                "what": "the 1x1 / phase-GEMM / rate-change convs, whichever kernel took them (conv_direct_kernel, "
+                        "conv_direct_strided_kernel, conv_direct3s_kernel, conv_direct4_kernel)",
+                "achieved": fam["tflops"], "frac": fam["tflops"] / FP32_MFMA_PEAK_TFLOPS, "launches": fam["launches"],
+                "avg_launch_us": fam["avg_launch_us"], "ms_per_enhance": fam["ms_per_enhance"]},
+            "gru": gru_roofline(gru_recs, args, 1e3 * dt / args.steps),
             "score_forward": score_forward,
             "method": f"device-side per-launch timing (first block start .. last block end on the 100 MHz s_memrealtime clock) of every conv launch, profiled pass of {args.profile_steps} "
                       "enhance calls right after the timed region, in the SAME mode as the timed calls (side streams inside the call: the "
@@ -509,6 +752,8 @@ def main():
             "free_running": {"value": audio_s / dt_async, "ms_per_step": 1e3 * dt_async / args.steps,
                              "note": "model.check_status = False: no host sync inside the timed loop, status checked after it"},
             "host_enqueue": host_enqueue,
+            "sustained": sustained,
+            "in_flight": in_flight,
             "gru_exchange": dict(model.gru_exchange_stats(),
                                  note="hand-offs the GRU clusters had to repeat / waves that finished a pass with "
                                       "system-scope publishes (DESIGN.md 4.4), whole process; both 0 on a healthy device"),

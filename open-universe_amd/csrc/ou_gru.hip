@@ -318,7 +318,13 @@ __device__ __attribute__((noinline)) void gru_stale_probe(const unsigned long lo
     // status word 33: events where the granule HAD arrived for a system-scope load or an atomic but not for the agent-scope
     // load the gather uses -- the cheap publish form really failed (what the host switches the publish mode on).  Everything
     // else counted in word 20 is a member that was late (descheduled / starved by the kernels of other streams).
-    if (b.y == want || c.y == want) atomicAdd(err + 33, 1u);
+    // (the granule may simply ARRIVE between the first load and the other two: only if an agent-scope load issued after them
+    // still misses it was it invisible to the gather)
+    if (b.y == want || c.y == want) {
+      u32x2 a2;
+      asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(a2) : "v"(g) : "memory");
+      if (a2.y != want) atomicAdd(err + 33, 1u);
+    }
     if (atomicAdd(err + 21, 1u) == 0u) {
       unsigned now;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(now));

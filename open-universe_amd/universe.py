@@ -268,7 +268,7 @@ class Universe:
         system-scope publishes after such a recovery (slower steps, no more recoveries).  Both 0 on a healthy device."""
         if self._ws is None:
             return {"recoveries": 0, "lost": 0, "system_scope": 0}
-        d = self._ws[:128].view(torch.int32).cpu().tolist()
+        d = self._ws[:256].view(torch.int32).cpu().tolist()
         # recoveries: waits cut short by the safety net (late members included); lost: publishes that really were invisible
         out = {"recoveries": int(d[20]), "lost": int(d[33]), "system_scope": int(d[31])}
         out["agent_scope_publishes"] = bool(self.gru_agent_scope)

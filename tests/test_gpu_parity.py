@@ -558,7 +558,7 @@ def _d4_launches(model):
 
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 1, 64000), ("PP16", 2, 23517), ("PP24", 1, 30011), ("OR16", 3, 9000),
-                                      ("PP16m", 2, 3000), ("PP16", 1, 777)])
+                                      ("PP16m", 2, 3000), ("PP16", 4, 777)])
 def test_wide_load_1x1_kernel_matches_the_first_generation(name, B, T, monkeypatch):
     """conv_direct4_kernel (16-byte operand loads, 16x16x4 MFMA, split-K over the waves where a layer has few tiles, one
     LDS-staged epilogue with 16-byte stores for every `up`) takes the 1x1 convs, the phase GEMMs of the transposed convs and
