@@ -23,6 +23,11 @@ int ou_bench_conv(ou_handle* h, const char* layer, int32_t B, int32_t Tin, int32
                   int32_t iters, void* ws, size_t ws_bytes, ou_stream_t stream, float* ms_per_iter, int32_t* cfg_used);
 int ou_profile_read(ou_handle* h, int32_t max_records, float* ms, double* flops, double* bytes, int32_t* cfg,
                     int32_t* n_records);
+/* The raw stamps of the same records (first block start / last block end, 10 ns ticks of the device's constant clock -- one
+ * clock for every handle of the process: the launches of several lanes lie on one timeline) and the variant code
+ * (>= 1000: one GRU pass of cfg - 1000 steps). */
+int ou_profile_read_ticks(ou_handle* h, int32_t max_records, uint64_t* t_start, uint64_t* t_end, int32_t* cfg,
+                          int32_t* n_records);
 
 #ifdef __cplusplus
 }

@@ -110,6 +110,7 @@ def load():
         "ou_profile_enable": (i32, [vp, i32]),
         "ou_bench_conv": (i32, [vp, c_char_p, i32, i32, i32, i32, i32, i32, vp, sz, vp, POINTER(c_float), POINTER(i32)]),
         "ou_profile_read": (i32, [vp, i32, POINTER(c_float), POINTER(c_double), POINTER(c_double), POINTER(i32), POINTER(i32)]),
+        "ou_profile_read_ticks": (i32, [vp, i32, POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64), POINTER(i32), POINTER(i32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -127,7 +128,7 @@ EXPORTED_SYMBOLS = [
     "ou_set_gru_publish_mode", "ou_get_gru_publish_mode", "ou_set_lanes",
     "ou_transform_frames", "ou_transform_forward", "ou_transform_inverse",
 ]
-TUNING_SYMBOLS = ["ou_profile_enable", "ou_profile_read", "ou_bench_conv",
+TUNING_SYMBOLS = ["ou_profile_enable", "ou_profile_read", "ou_profile_read_ticks", "ou_bench_conv",
 ]
 
 _EXC = {OU_EINVAL: ValueError, OU_ENOTIMPL: NotImplementedError, OU_EMISSING: KeyError, OU_ESHAPE: ValueError,

@@ -781,7 +781,13 @@ int finish(ou_handle* h, Runner& r) {
 // ======================================================================================================
 extern "C" {
 
-const char* ou_version(void) { return "libouniverse 0.1 (gfx950, fp32 MFMA)"; }
+const char* ou_version(void) {
+#ifdef OU_EXPERIMENTS
+  return "libouniverse 0.2 (gfx950, fp32 MFMA) +experiments";
+#else
+  return "libouniverse 0.2 (gfx950, fp32 MFMA)";
+#endif
+}
 const char* ou_last_error(const ou_handle* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
 const char* ou_packer_last_error(const ou_packer* p) { return p ? p->err.c_str() : g_last_error.c_str(); }
 
@@ -1284,6 +1290,35 @@ int ou_profile_enable(ou_handle* h, int32_t on) {
       return fail(h, OU_EHIP, "hipMalloc(profile buffer) failed");
     if (hipMemset(h->prof_dev, 0xFF, kProfSlots * 256) != hipSuccess) return fail(h, OU_EHIP, "hipMemset failed");
   }
+  return OU_OK;
+}
+
+// ... and the raw stamps of the same records: first block start / last block end of every launch on the device's 100 MHz
+// constant clock (10 ns ticks; one clock for all handles of a process, so that the launches of several lanes can be laid on
+// one timeline), plus the variant code
+int ou_profile_read_ticks(ou_handle* h, int32_t max_records, uint64_t* t_start, uint64_t* t_end, int32_t* cfg,
+                          int32_t* n_records) {
+  if (!h || !n_records || !t_start || !t_end) return OU_EINVAL;
+  int n = (int)h->prof_used;
+  if (n > max_records) n = max_records;
+  std::vector<unsigned long long> host((size_t)32 * (n > 0 ? n : 1));
+  if (n > 0) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(host.data(), h->prof_dev, (size_t)n * 256, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(h, OU_EHIP, hipGetErrorString(e));
+  }
+  for (int i = 0; i < n; i++) {
+    unsigned long long t0 = ~0ull, t1 = 0ull;
+    for (int w = 0; w < 16; w++) {
+      const unsigned long long a = host[32 * i + w], b = ~host[32 * i + 16 + w];
+      if (a < t0) t0 = a;
+      if (b > t1) t1 = b;
+    }
+    t_start[i] = t0;
+    t_end[i] = t1 >= t0 ? t1 : t0;
+    if (cfg) cfg[i] = h->prof[i].cfg;
+  }
+  *n_records = n;
   return OU_OK;
 }
 

@@ -293,9 +293,14 @@ struct Direct4Cfg {
 };
 #define OU_D4(R, TM, WN, WK, D) {R, TM, WN, WK, D, conv_direct4_kernel<R, TM, WN, WK, D>}
 // ring depth: 4 slots of 2 R loads while that fits the 6-bit vmcnt and the register file (R <= 2), else 2
+// (64-row tiles -- TM = 4 -- are never the rule's choice, see direct4_pick: in `make EXPERIMENTS=1` builds only, for the sweep tool)
+#ifdef OU_EXPERIMENTS
 #define OU_D4_SHAPES(R, D)                                                                                    \
   OU_D4(R, 4, 4, 1, D), OU_D4(R, 2, 4, 1, D), OU_D4(R, 4, 1, 2, D), OU_D4(R, 2, 1, 2, D), OU_D4(R, 4, 1, 4, D), \
   OU_D4(R, 2, 1, 4, D), OU_D4(R, 4, 1, 8, D), OU_D4(R, 2, 1, 8, D)
+#else
+#define OU_D4_SHAPES(R, D) OU_D4(R, 2, 4, 1, D), OU_D4(R, 2, 1, 2, D), OU_D4(R, 2, 1, 4, D), OU_D4(R, 2, 1, 8, D)
+#endif
 static const Direct4Cfg kDirect4Cfgs[] = {
     OU_D4_SHAPES(1, 4), OU_D4_SHAPES(2, 4), OU_D4_SHAPES(3, 2), OU_D4_SHAPES(4, 2), OU_D4_SHAPES(5, 2), OU_D4_SHAPES(8, 2),
 };

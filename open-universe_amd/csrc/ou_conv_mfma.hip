@@ -425,18 +425,29 @@ struct ConvCfg {
   {BM, BN, WK, MAXW, NT, (WK == 8 && TM * TN == 4) ? CONV_XCAP_BIG : CONV_XCAP,                       \
    conv_mfma_kernel<TM, TN, WM, WN, WK, MAXW, 4, true>,                          \
    conv_mfma_kernel<TM, TN, WM, WN, WK, MAXW, 2, true>, conv_mfma_kernel<TM, TN, WM, WN, WK, MAXW, 2, false>}
+// a table slot whose kernels are not in this build (the slot keeps its index: profile records and tools name configs by it)
+#define OU_CONV_CFG_OFF(BM, BN, WK, MAXW, NT) {BM, BN, WK, MAXW, NT, CONV_XCAP, nullptr, nullptr, nullptr}
 static const ConvCfg kConvCfgs[] = {
     OU_CONV_CFG(64, 128, 1, 6, 256, 1, 2, 2, 2),
     OU_CONV_CFG(32, 128, 1, 6, 256, 1, 1, 1, 4),
     OU_CONV_CFG(64, 64, 1, 6, 256, 1, 1, 2, 2),
-    // small-T levels: reduction split over the waves, up to 4 packed chunks per pipeline stage
+    // small-T levels: reduction split over 4 waves, up to 4 packed chunks per pipeline stage -- never chosen by launch_conv
+    // (superseded by the 8-wave variants below; tools/conv_sweep.py can still force them in an EXPERIMENTS build)
+#ifdef OU_EXPERIMENTS
     OU_CONV_CFG(32, 64, 4, 12, 256, 1, 2, 1, 1),
     OU_CONV_CFG(32, 32, 4, 12, 256, 1, 1, 1, 1),
+#else
+    OU_CONV_CFG_OFF(32, 64, 4, 12, 256), OU_CONV_CFG_OFF(32, 32, 4, 12, 256),
+#endif
     // 8 waves (two per SIMD), reduction split 8 ways
     OU_CONV_CFG(32, 64, 8, 6, 512, 1, 2, 1, 1),
     OU_CONV_CFG(32, 32, 8, 6, 512, 1, 1, 1, 1),
-    // 64x64, reduction split 8 ways, 2x2 accumulator tiles per wave: one LDS read per MFMA
+    // 64x64, reduction split 8 ways, 2x2 accumulator tiles per wave: one LDS read per MFMA (tuning only: needs a cross-CU split-K)
+#ifdef OU_EXPERIMENTS
     OU_CONV_CFG(64, 64, 8, 12, 512, 2, 2, 1, 1),
+#else
+    OU_CONV_CFG_OFF(64, 64, 8, 12, 512),
+#endif
 };
 constexpr int kNumConvCfgs = sizeof(kConvCfgs) / sizeof(kConvCfgs[0]);
 
@@ -452,6 +463,7 @@ static size_t conv_smem_bytes(const ConvCfg& c, const ConvArgs& a) {
 hipError_t init_conv_kernels() {
   hipError_t e_d3 = hipSuccess;
   for (int i = 0; i < kNumConvCfgs; i++) {
+    if (!kConvCfgs[i].kern4) continue;  // not in this build
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kConvCfgs[i].kern4),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -514,6 +526,7 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   for (int i = 0; i < kNumConvCfgs; i++) {
     const ConvCfg& c = kConvCfgs[i];
     if (a.force_cfg >= 0 && i != a.force_cfg) continue;
+    if (!c.kern4) continue;  // (an EXPERIMENTS-only config)
     if (c.BM == 64 && a.M <= 32) continue;
     int span = (c.BN - 1) * a.stride + a.KW;
     if ((long)a.CK * span > c.XCAP) continue;

@@ -51,6 +51,7 @@ __device__ __forceinline__ float tanhf_(float x) {
 }
 constexpr unsigned GRU_SPIN_LIMIT = 4000000u;
 
+#ifdef OU_EXPERIMENTS  // round 1's polling-wave kernel (OU_GRU_V=1): built with `make EXPERIMENTS=1` only
 // Thread mapping: a direction's H hidden units are split over NWG = H/UPW workgroups of NT threads;
 // LPU = NT/UPW lanes share one unit: thread (u, cg) = (tid/LPU, tid%LPU) holds, for unit UPW*g + u, the three gate
 // rows (r, z, n) x columns {4cg + 4*LPU*i + 0..3, i < NI = H/(4*LPU)} in registers (gathered from the canonical
@@ -258,6 +259,8 @@ __global__ __launch_bounds__(NT) void gru_cluster_kernel(GruArgs p, int ncluster
   }
 }
 
+#endif  // OU_EXPERIMENTS
+
 // ---------------------------------------------------------------------------------------------------------
 // GRU recurrence, second generation ("ring"): same cluster decomposition, different exchange.
 //   * every WAVE gathers the h columns its lanes need straight from L2 into registers (volatile agent-scope 16-byte
@@ -407,8 +410,6 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
   unsigned c_rounds = 0;
   long long c_ack = 0;
   if (ts_on) r_start = (long long)__builtin_amdgcn_s_memrealtime();
-  if (p.prof && tid == 0 && cluster < nclusters)
-    atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
   if (cluster < nclusters) {
     const int dir = cluster & 1, b = cluster >> 1;
     const int ul = tid / LPU, cg = tid % LPU;
@@ -776,8 +777,6 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
   }
   // ---- epoch hand-over: the last block to finish advances the epoch for the next launch on this exchange area
   __syncthreads();
-  if (p.prof && tid == 0 && cluster < nclusters)
-    atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
   if (tid == 0) {
     __threadfence();
     const unsigned done = atomicAdd(p.epoch + 1, 1u);
@@ -884,6 +883,7 @@ static hipError_t launch_gru_ring(const GruArgs& c, int upw, int nclusters, hipS
   return hipGetLastError();
 }
 
+#ifdef OU_EXPERIMENTS
 template <int HB>
 static hipError_t launch_gru_variant(const GruArgs& c, int upw, int nclusters, hipStream_t st) {
   constexpr int H = 64 * HB;
@@ -895,7 +895,23 @@ static hipError_t launch_gru_variant(const GruArgs& c, int upw, int nclusters, h
   return hipGetLastError();
 }
 
+#endif  // OU_EXPERIMENTS
+
+// Measurement only (GruArgs.prof): the pass is timed by two one-thread kernels on the same stream, right before and right
+// behind it -- the recurrence kernel itself carries no stamps (its step loop has no SGPR to spare: `make check` fails the
+// build on a spill there).  What is read back is the pass plus the two dispatch gaps around it (~2 us of ~240).
+__global__ void gru_stamp_kernel(unsigned long long* slot, int end) {
+  const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+  if (end) atomicMin(slot + 16, ~t);
+  else atomicMin(slot, t);
+}
+
 hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
+  if (a.prof) hipLaunchKernelGGL(gru_stamp_kernel, dim3(1), dim3(1), 0, st, a.prof, 0);
+  struct EndStamp {
+    const GruArgs& a; hipStream_t st;
+    ~EndStamp() { if (a.prof) hipLaunchKernelGGL(gru_stamp_kernel, dim3(1), dim3(1), 0, st, a.prof, 1); }
+  } end_stamp{a, st};
   if (a.H % 64) return hipErrorInvalidValue;
   const int HB = a.H / 64;
   // Every workgroup of a cluster has to be resident at once; clusters are dealt to XCDs in groups of 8 and a launch
@@ -910,6 +926,7 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
   // the ring kernel runs 256-thread workgroups of 16 units (32 on request, H <= 256)
   if (a.version == 2) upw = gru_ring_upw(a.H, a.force_upw, a.B, num_cu, a.lanes, a.share);
   const int nwg = a.H / upw;
+  (void)nwg;  // (used by the EXPERIMENTS-only polling-wave path)
   int bmax = batch_cap(upw);
   // residency of the ring kernel: every member of a cluster spins on the others, so a launch is sized to what can be on
   // the machine at once (half of it when a second GRU layer may run beside this one: conditioner / first score pass);
@@ -938,6 +955,9 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
       if (e != hipSuccess) return e;
       continue;
     }
+#ifndef OU_EXPERIMENTS
+    return hipErrorInvalidConfiguration;  // OU_GRU_V=1 needs a library built with `make EXPERIMENTS=1`
+#else
     if (nwg > 1) {
       hipError_t e = hipMemsetAsync(c.xchg, 0, (size_t)c.B * 4 * a.H * sizeof(unsigned long long), st);
       if (e != hipSuccess) return e;
@@ -951,6 +971,7 @@ hipError_t launch_gru(const GruArgs& a, int num_cu, hipStream_t st) {
       default: return hipErrorInvalidConfiguration;
     }
     if (e != hipSuccess) return e;
+#endif  // OU_EXPERIMENTS
   }
   return hipSuccess;
 }

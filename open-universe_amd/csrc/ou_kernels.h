@@ -192,7 +192,7 @@ struct GruArgs {
                        // side stream; more: other lanes of the process, ou_set_lanes): a launch takes 1 / share of an XCD
   int lanes = 1;       // enhance calls in flight side by side in this process
   int xcd_rot = 0;     // cluster c of the launch is dealt to XCD (c + xcd_rot) % 8
-  unsigned long long* prof = nullptr;  // measurement: 16 x min block start, 16 x ~max block end (10 ns ticks), like ConvArgs
+  unsigned long long* prof = nullptr;  // measurement: slot [0] <- ticks before the pass, [16] <- ~ticks behind it (stamp kernels)
   int force_bmax = 0;  // testing: cap the utterances per launch (forces the chunked path at small batches)
   int force_upw = 0;  // tuning: 16 / 32 / 64 hidden units per workgroup (0: chosen from the batch size)
 };

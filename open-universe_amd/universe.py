@@ -308,6 +308,15 @@ class Universe:
         _lib.check(self._L.ou_profile_read(self._handle, max_records, ms, fl, by, cf, byref(n)), self._handle)
         return [(ms[i], fl[i], by[i], cf[i]) for i in range(n.value)]
 
+    def profile_read_ticks(self, max_records=32768):
+        """-> list of (start, end, variant) per profiled launch: 10 ns ticks of the device's constant clock."""
+        t0 = (ctypes.c_uint64 * max_records)()
+        t1 = (ctypes.c_uint64 * max_records)()
+        cf = (c_int32 * max_records)()
+        n = c_int32()
+        _lib.check(self._L.ou_profile_read_ticks(self._handle, max_records, t0, t1, cf, byref(n)), self._handle)
+        return [(t0[i], t1[i], cf[i]) for i in range(n.value)]
+
     def bench_conv(self, layer, B, Tin, cfg=-1, sc=-1, with_res=False, iters=20):
         """Tuning aid: ms per launch of one packed conv layer (see ou_bench_conv)."""
         ws = torch.empty(max(1 << 28, 64 * B * Tin * 4 * 64), dtype=torch.uint8, device=self.device)

@@ -166,3 +166,11 @@ def emulate_conv(blob, L, x, act=True):
 
 def plan_convs(plan_json):
     return {c["name"]: c for c in json.loads(plan_json)["convs"]}
+
+
+def experiments_built():
+    """True when libouniverse.so was built with `make EXPERIMENTS=1` (conv_block3_kernel, round 1's gru_cluster_kernel and
+    the never-selected conv_mfma_kernel configs are in the library only then)."""
+    from open_universe_amd import _lib
+
+    return b"+experiments" in _lib.load().ou_version()

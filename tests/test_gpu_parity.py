@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import restatement as O
-from helpers import get_spec, record, synth_mix
+from helpers import experiments_built, get_spec, record, synth_mix
 from open_universe_amd import state_dict as S
 
 pytestmark = pytest.mark.gpu
@@ -511,6 +511,7 @@ def test_throughput_conv_kernel_matches_split_k_kernels(name, B, T, monkeypatch)
     assert n_conv > 0
 
 
+@pytest.mark.skipif(not experiments_built(), reason="conv_block3_kernel is in `make EXPERIMENTS=1` builds only")
 @pytest.mark.parametrize("T", [64000, 7213])
 def test_fused_deep_convblock_is_bit_identical(T, monkeypatch):
     """OU_BLOCK3=1: the three body convs (k5, k3, k3) of the 256- / 512-channel ConvBlocks of UNIVERSE++ at batch 1 in ONE
@@ -592,6 +593,8 @@ def test_every_tile_shape_of_the_wide_load_1x1_kernel(name, B, T, shape, monkeyp
     """OU_D4_FORCE = 10 TM + log2(WK): that tile shape on every layer that admits it (channel groups divisible by WK x ring
     depth), the launcher's own choice elsewhere -- all eight shapes (32 / 64 rows; reduction split over 1 / 2 / 4 / 8 waves)
     against the first-generation kernels on the same inputs."""
+    if shape >= 40 and not experiments_built():
+        pytest.skip("64-row tiles are in `make EXPERIMENTS=1` builds only (the launcher's rule never picks them)")
     model, spec, sd = get_model(name)
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)

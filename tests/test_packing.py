@@ -110,3 +110,21 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert tuning == set(_lib.TUNING_SYMBOLS) and not (tuning & declared)  # measurement entry points kept apart
     for s in declared | tuning:
         assert hasattr(built_lib, s), s
+
+
+def test_default_build_carries_no_experiment_kernels(built_lib):
+    """`make` (what __graft_entry__.build() runs) leaves the kernels no default dispatch rule can select out of the library:
+    conv_block3_kernel (one launch per deep ConvBlock: measured slower end to end), round 1's gru_cluster_kernel and the
+    4-wave / 64x64 split-K configs of conv_mfma_kernel are in `make EXPERIMENTS=1` builds only.  The device code objects
+    inside the .so name their kernels in clear text."""
+    import os
+
+    so = os.path.join(os.path.dirname(__file__), "..", "open-universe_amd", "lib", "libouniverse.so")
+    blob = open(so, "rb").read()
+    assert b"conv_direct2_kernel" in blob and b"gru_ring_kernel" in blob and b"conv_direct4_kernel" in blob
+    if b"+experiments" in built_lib.ou_version():
+        pytest.skip("an EXPERIMENTS build")
+    for name in (b"conv_block3_kernel", b"gru_cluster_kernel"):
+        assert name not in blob, name
+    # conv_mfma_kernel<TM, TN, WM, WN, WK, ...>: no instantiation with a 4-way split of the reduction (WK = 4)
+    assert b"conv_mfma_kernelILi1ELi2ELi1ELi1ELi4E" not in blob and b"conv_mfma_kernelILi1ELi1ELi1ELi1ELi4E" not in blob
