@@ -510,9 +510,10 @@ __global__ __launch_bounds__(512) void conv_direct2_kernel(ConvArgs p) {
 // that are valid there (conv1: the whole window -- it depends on the block input alone; conv2: own range +- 1; conv3: own
 // range); overlapping stores of neighbouring windows carry bit-identical values.  Same tile body, same K order, same
 // epilogues as three conv_direct2_kernel launches: bit-identical results.
-// The placement is checked, not assumed: every workgroup adds its XCC id to its group's mask, a group that spans XCDs
-// raises status bit 32 (the host falls back to separate launches for good); the barrier itself uses agent-scope atomics and
-// is correct under any placement; spins are bounded (status bit 16).
+// The placement is checked, not assumed: every workgroup adds its XCC id to its group's mask; a group that spans XCDs is
+// counted in status word 34 (diagnostics; never observed) and hands over with the agent-scope release / acquire form, which is
+// correct under any placement; spins are bounded (status bit 16).  In `make EXPERIMENTS=1` builds only, behind OU_BLOCK3=1: no
+// per-layer tensors names / profile records for the three convs of a fused launch.
 // ---------------------------------------------------------------------------------------------------------
 struct Block3Args {
   ConvArgs cv[3];

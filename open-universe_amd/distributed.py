@@ -84,9 +84,11 @@ def shard_utterances(lengths, world_size):
     return shards
 
 
-def broadcast_packed_weights(spec, state_dict, device, src=0):
-    """Rank `src` folds + packs the checkpoint; everybody receives the blob with ONE broadcast
-    (PP16: 185 MB, one xGMI hop).  Returns the device tensor to hand to Universe(packed_weights=...)."""
+def broadcast_packed_weights(spec, state_dict, device, src=0, packed=None):
+    """Rank `src` folds + packs the checkpoint (or hands in the blob it has already packed: `packed`); everybody receives
+    the blob with ONE broadcast (PP16: 185 MB, one xGMI hop).  Returns the device tensor to hand to
+    Universe(packed_weights=...).  Packing can fail (missing / mis-shaped tensors): a caller whose other ranks are already
+    waiting in the collective should pack first, tell them, and pass `packed` (inference_utils.load_model_sharded)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     device = torch.device(device)
@@ -95,7 +97,7 @@ def broadcast_packed_weights(spec, state_dict, device, src=0):
     on_host = world > 1 and dist.get_backend() == "gloo"
     xdev = torch.device("cpu") if on_host else device
     if rank == src:
-        blob, _ = _lib.pack_weights(spec, state_dict)
+        blob = packed if packed is not None else _lib.pack_weights(spec, state_dict)[0]
         blob = blob.to(xdev)
     else:
         blob = torch.empty(nfloats, dtype=torch.float32, device=xdev)

@@ -168,11 +168,15 @@ def load_model_sharded(ckpt_path, device=None, strict=True, return_config=False,
     config = load_config(config_path)
     spec = spec_from_config(config)
     rank = dist.get_rank() if dist.is_initialized() else 0
-    sd, err = None, None
+    sd, err, packed = None, None, None
     if rank == 0:
-        try:
+        try:  # everything that can fail on rank 0 -- reading the checkpoint AND folding / packing it -- happens before the
+            # other ranks are told to enter the collective
             sd = _inference_weights(spec, ckpt_path, strict)
-        except Exception as e:  # the other ranks are about to enter a collective: tell them before raising
+            from .. import _lib
+
+            packed = _lib.pack_weights(spec, sd)[0]
+        except Exception as e:
             err = e
     if dist.is_initialized() and dist.get_world_size() > 1:
         flag = [repr(err) if err is not None else None]
@@ -181,7 +185,7 @@ def load_model_sharded(ckpt_path, device=None, strict=True, return_config=False,
             raise err if err is not None else RuntimeError(f"rank 0 could not load the checkpoint: {flag[0]}")
     elif err is not None:
         raise err
-    blob = broadcast_packed_weights(spec, sd, device)
+    blob = broadcast_packed_weights(spec, sd, device, packed=packed)
     cls = UniverseGAN if spec.kind == "universe_gan" else Universe
     model = cls(spec, packed_weights=blob, device=device)
     model.eval()

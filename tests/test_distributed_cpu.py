@@ -142,3 +142,52 @@ def test_pick_backend_uses_the_local_world_size(monkeypatch):
     assert D.pick_backend(16) == "gloo"  # 16 ranks sharing 8 GPUs of one node
     monkeypatch.delenv("LOCAL_WORLD_SIZE")
     assert D.pick_backend(2) == "nccl" and D.pick_backend(9) == "gloo"
+
+
+def _bad_ckpt_worker(rank, world, port, q, path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import open_universe_amd  # noqa: F401
+    from open_universe_amd import distributed as D
+    from open_universe_amd import inference_utils
+
+    D.init(backend="gloo")
+    try:
+        inference_utils.load_model_sharded(path, device="cuda:0", strict=False)
+        q.put((rank, "no error"))
+    except Exception as e:
+        q.put((rank, type(e).__name__ + ": " + str(e)[:120]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_load_model_sharded_reports_a_packing_failure_on_every_rank(built_lib, tmp_path):
+    """Only rank 0 reads and packs the checkpoint.  A tensor of the wrong shape passes the checkpoint reader and fails in the
+    packer: the other ranks must hear about it BEFORE they enter the weight broadcast -- every rank raises, nobody hangs in
+    the collective (round 3: the packing ran after the error-flag exchange)."""
+    import yaml
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import get_spec
+    from open_universe_amd import config as C
+    from open_universe_amd import state_dict as S
+
+    spec = get_spec("PP16s")
+    sd = S.synthetic_state_dict(spec, seed=0)
+    sd["condition_model.input_conv.bias"] = torch.zeros(3)  # wrong shape: the packer refuses it
+    d = tmp_path / "m"
+    d.mkdir()
+    yaml.safe_dump(C.builtin_config("PP16", **{"score_model.n_channels": 8}), open(d / "config.yaml", "w"))
+    torch.save(S.checkpoint_from_state_dict(spec, sd), d / "weights.ckpt")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bad_ckpt_worker, args=(r, 2, port, q, str(d / "weights.ckpt"))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0].startswith("ValueError") and "rank 0 could not load the checkpoint" in res[1], res

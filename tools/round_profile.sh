@@ -8,29 +8,37 @@
 set -u
 export TMPDIR=/tmp
 O=gpurun_out/final
+rm -rf $O
 mkdir -p $O
 timeout 120 python tools/box_health.py 2>&1 | grep "box health" | tee $O/box_health.txt
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -c 400 $O/bench_default.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- \
-  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_under_rocprof.json 2> $O/rocprof.err
+  python bench.py --sustained-s 0 --in-flight "" --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_under_rocprof.json 2> $O/rocprof.err
 python tools/kstats.py $O/prof/bench_kernel_trace.csv | head -16 | tee $O/kstats_PP16_B1.txt
 # the same command as ONE serial chain (OU_NO_OVERLAP=1: no side streams inside the call) -- every kernel alone on the device;
 # the default run above times the first score-encoder pass beside the conditioner, like bench.py's own per-launch pass does
 OU_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -o bench -- \
-  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_under_rocprof_serial.json 2>> $O/rocprof.err
+  python bench.py --sustained-s 0 --in-flight "" --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_under_rocprof_serial.json 2>> $O/rocprof.err
 python tools/kstats.py $O/prof_serial/bench_kernel_trace.csv | head -16 | tee $O/kstats_PP16_B1_serial.txt
 rm -rf $O/prof_serial
 # the other BASELINE configurations (per-GPU shapes): C3 PP16 64 steps B=4, C4 OR16 32 steps B=16, C5 PP24 varlen B=8
-timeout 900 python bench.py --batch 4 --n_steps 64 --steps 5 --warmup 1 --batch-sweep "" > $O/bench_C3_PP16_n64_b4.json 2>> $O/bench_default.err
-timeout 900 python bench.py --model OR16 --batch 16 --n_steps 32 --steps 5 --warmup 1 --batch-sweep "" > $O/bench_C4_OR16_n32_b16.json 2>> $O/bench_default.err
-timeout 900 python bench.py --model PP24 --batch 8 --varlen --steps 5 --warmup 1 > $O/bench_C5_PP24_varlen_b8.json 2>> $O/bench_default.err
-timeout 900 python bench.py --batch 8 --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_PP16_b8.json 2>> $O/bench_default.err
-timeout 900 python bench.py --batch 4 --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_PP16_b4.json 2>> $O/bench_default.err
-for f in C3_PP16_n64_b4 C4_OR16_n32_b16 C5_PP24_varlen_b8 PP16_b8 PP16_b4; do tail -c 200 $O/bench_$f.json | head -c 200; echo; done
+timeout 900 python bench.py --sustained-s 0 --in-flight "" --batch 4 --n_steps 64 --steps 5 --warmup 1 --batch-sweep "" > $O/bench_C3_PP16_n64_b4.json 2>> $O/bench_default.err
+timeout 900 python bench.py --sustained-s 0 --in-flight "" --model OR16 --batch 16 --n_steps 32 --steps 5 --warmup 1 --batch-sweep "" > $O/bench_C4_OR16_n32_b16.json 2>> $O/bench_default.err
+timeout 900 python bench.py --sustained-s 0 --in-flight "" --model PP24 --batch 8 --varlen --steps 5 --warmup 1 > $O/bench_C5_PP24_varlen_b8.json 2>> $O/bench_default.err
+timeout 900 python bench.py --sustained-s 0 --in-flight "" --batch 8 --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_PP16_b8.json 2>> $O/bench_default.err
+timeout 900 python bench.py --sustained-s 0 --in-flight "" --batch 4 --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_PP16_b4.json 2>> $O/bench_default.err
+timeout 900 python bench.py --sustained-s 0 --in-flight "" --batch 16 --steps 6 --warmup 1 --no-cpu-baseline --batch-sweep "" > $O/bench_PP16_b16.json 2>> $O/bench_default.err
+timeout 900 python bench.py --sustained-s 0 --in-flight "" --batch 32 --steps 4 --warmup 1 --no-cpu-baseline --batch-sweep "" > $O/bench_PP16_b32.json 2>> $O/bench_default.err
+for f in C3_PP16_n64_b4 C4_OR16_n32_b16 C5_PP24_varlen_b8 PP16_b8 PP16_b4 PP16_b16 PP16_b32; do python - $O/bench_$f.json $f <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+print(sys.argv[2], "%.2f ms per step, %.1f utt/s, dominant %.1f %% of peak, all conv %.1f %%" % (d["ms_per_step"], d["utterances_per_s"], 100 * d["roofline"]["frac"], 100 * d["roofline"]["all_conv_kernels"]["frac"]))
+PY
+done
 for cfgname in "PP16_B8 --batch 8 --steps 2 --warmup 1" "C3 --batch 4 --n_steps 64 --steps 2 --warmup 1" "C4 --model OR16 --batch 16 --n_steps 32 --steps 2 --warmup 1" "C5 --model PP24 --batch 8 --varlen --steps 2 --warmup 1"; do
   set -- $cfgname; name=$1; shift
-  timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/prof_$name -o k -- python bench.py "$@" --no-cpu-baseline --profile-steps 1 --batch-sweep "" > /dev/null 2>> $O/rocprof.err
+  timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/prof_$name -o k -- python bench.py --sustained-s 0 --in-flight "" "$@" --no-cpu-baseline --profile-steps 1 --batch-sweep "" > /dev/null 2>> $O/rocprof.err
   python tools/kstats.py $O/prof_$name/k_kernel_trace.csv | head -12 > $O/kstats_$name.txt
   rm -rf $O/prof_$name
 done
@@ -39,7 +47,7 @@ for cfgname in "PP16_b1 " "PP16_b8 --batch 8" "PP24_b8_varlen --model PP24 --bat
   set -- $cfgname; tag=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${tag}_$c -o p -- \
-      python bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 --batch-sweep "" > /dev/null 2> $O/pmc_${tag}_$c.err
+      python bench.py --sustained-s 0 --in-flight "" "$@" --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 --batch-sweep "" > /dev/null 2> $O/pmc_${tag}_$c.err
   done
 done
 # SQ counters (4 per pass): the 512-channel k3 latent-level conv at batch 1 (split-K kernel) and the 192-channel k3 conv of
@@ -59,6 +67,14 @@ OU_GRU_AGENT_STORES=1 timeout 300 python tools/gru_ts.py 2>&1 | grep -v amdgpu.i
 timeout 300 python tools/direct_ts.py 2>&1 | grep -v amdgpu.ids > $O/direct_ts.txt; tail -8 $O/direct_ts.txt
 for args in "PP24 8" "PP16 8" "PP16 4" "OR16 16"; do set -- $args; timeout 300 python tools/tile_sweep.py $1 $2 2>&1 | grep -v amdgpu.ids > $O/tile_sweep_$1_B$2.txt; done
 timeout 300 python tools/sharded_rate.py PP16 32 2>&1 | grep -v amdgpu.ids > $O/sharded_rate.txt; cat $O/sharded_rate.txt
+# round 4: the wide-load 1x1 / rate-change kernel against the first generation, per layer and tile shape (the EXPERIMENTS library
+# has the 64-row shapes too); its phase stamps; ragged sets through K lanes; what runs beside what; batch x lanes; free-running
+for b in 1 4 8; do OU_LIBRARY=$PWD/open-universe_amd/lib/libouniverse_experiments.so timeout 600 python tools/d4_sweep.py PP16 $b 2>&1 | grep -v amdgpu.ids | cut -c1-330 > $O/d4_sweep_PP16_B$b.txt; tail -1 $O/d4_sweep_PP16_B$b.txt; done
+OU_LIBRARY=$PWD/open-universe_amd/lib/libouniverse_experiments.so timeout 300 python tools/d4_ts.py 1 2>&1 | grep -v amdgpu.ids > $O/d4_ts_B1.txt
+timeout 900 python tools/lanes_rate.py PP16 32 1,2,3,4,8 2>&1 | grep -v amdgpu.ids | tee $O/lanes_rate.txt
+for K in 1 2 4; do timeout 300 python tools/lanes_timeline.py $K 32 2>&1 | grep -v amdgpu.ids; done > $O/lanes_timeline.txt
+timeout 600 python tools/lanes_batch.py 64 2>&1 | grep -v amdgpu.ids > $O/lanes_batch.txt
+{ timeout 300 python tools/free_run.py; OU_NO_OVERLAP=1 timeout 300 python tools/free_run.py; } 2>&1 | grep -v amdgpu.ids > $O/free_run.txt
 # microbenchmarks behind the design decisions
 for u in xchg_latency launch_overhead vmem_issue; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o /tmp/$u 2>> $O/rocprof.err && timeout 150 /tmp/$u > $O/ubench_$u.txt 2>&1
@@ -70,7 +86,7 @@ for i in 1 2 3; do timeout 120 /tmp/xcc_migrate 300 6 >> $O/xcc_migrate.txt 2>&1
 # two ranks on ONE GPU, repeated (the arrangement that produced the GRU time-outs of round 2)
 ok=0; bad=0
 for i in $(seq 1 30); do
-  if timeout 120 python bench.py --gpus 2 --share-devices --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 1 --batch-sweep "" > $O/st.out 2> $O/st.err; then ok=$((ok+1)); else bad=$((bad+1)); grep -h RuntimeError $O/st.err | head -2 | cut -c1-700 >> $O/stress_two_ranks.txt; fi
+  if timeout 120 python bench.py --sustained-s 0 --in-flight "" --gpus 2 --share-devices --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 1 --batch-sweep "" > $O/st.out 2> $O/st.err; then ok=$((ok+1)); else bad=$((bad+1)); grep -h RuntimeError $O/st.err | head -2 | cut -c1-700 >> $O/stress_two_ranks.txt; fi
 done
 echo "two ranks on one GPU, bench.py --gpus 2 --share-devices --steps 3: ok=$ok failed=$bad of 30" | tee -a $O/stress_two_ranks.txt
 python - >> $O/stress_two_ranks.txt <<PY
