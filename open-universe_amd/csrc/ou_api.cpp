@@ -107,7 +107,7 @@ struct Tensor {
 // Tuning / debug switches, read ONCE per C-ABI call: a forward walks ~400 launches and used to call getenv
 // eight times for each of them (a linear scan of the environment: a third of the host time of an enhance call).
 struct EnvCfg {
-  int dbg = 0, xcd_map = -1, conv_direct = 4, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1, d4_force = 0;
+  int dbg = 0, xcd_map = -1, conv_direct = 4, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1, d4_force = 0, d4_short = 1;
   int gru_v = 2, gru_bmax = 0, gru_ts = 0, gru_upw = 0, gru_backoff = 0, gru_agent = -1, gru_dbg = 0;
   double tile_min = -1.0;  // < 0: the launcher's default
   int tile_prefetch = 1;
@@ -119,6 +119,7 @@ struct EnvCfg {
     fuse_upfir = geti("OU_FUSE_UPFIR", 1);
     d4_fir = geti("OU_D4_FIR", 1);
     d4_force = geti("OU_D4_FORCE", 0);
+    d4_short = geti("OU_D4_SHORT", 1);
     block3 = geti("OU_BLOCK3", 0);
     gru_v = geti("OU_GRU_V", 2); gru_bmax = geti("OU_GRU_BMAX", 0); gru_ts = std::getenv("OU_GRU_TS") ? 1 : 0;
     gru_upw = geti("OU_GRU_UPW", 0); gru_backoff = geti("OU_GRU_BACKOFF", 0); gru_agent = geti("OU_GRU_AGENT_STORES", -1);
@@ -246,7 +247,7 @@ struct Runner {
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
     a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
-    a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct; a.d4_fir_unfused = env.d4_fir; a.d4_force = env.d4_force;
+    a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct; a.d4_fir_unfused = env.d4_fir; a.d4_force = env.d4_force; a.d4_short = env.d4_short;
     a.tile_min = env.tile_min; a.tile_prefetch = env.tile_prefetch;
     a.tstamps = h->tstamps;
     if (collect) { collect->push_back(a); return out; }

@@ -40,10 +40,13 @@ template <int R, int TM, int WN, int WK, int D>
 __global__ __launch_bounds__(64 * WN * WK) void conv_direct4_kernel(ConvArgs p) {
   constexpr int TN = 4, LPS = 2 * R, BM = 16 * TM, NW = WN * WK, EP = 68;
   static_assert(WN == 1 || WK == 1, "a block is either WN column tiles or WK slices of the reduction");
-  static_assert(TM == 2 || TM == 4, "32- or 64-row tiles");
+  static_assert(TM >= 1 && TM <= 4, "16 .. 64-row tiles");
   static_assert(D * LPS <= 60, "loads in flight must fit vmcnt");
   static_assert(D == 2 || D == 4, "ring depth");
-  typedef typename std::conditional<TM == 4, f32x4, f32x2>::type avec;
+  // A fragment of one (tap, 4 channels): TM adjacent rows per lane -- one dword / dwordx2 / dwordx3 / dwordx4 load
+  typedef float f32x3 __attribute__((ext_vector_type(3)));
+  typedef typename std::conditional<TM == 4, f32x4, typename std::conditional<TM == 3, f32x3,
+          typename std::conditional<TM == 2, f32x2, float>::type>::type>::type avec;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,7 +90,9 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_direct4_kernel(ConvArgs p) 
 #pragma unroll
     for (int k = 0; k < R; k++) {
       if constexpr (TM == 4) a4[d0][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      else a4[d0][k] = f32x2{0.f, 0.f};
+      else if constexpr (TM == 3) a4[d0][k] = f32x3{0.f, 0.f, 0.f};
+      else if constexpr (TM == 2) a4[d0][k] = f32x2{0.f, 0.f};
+      else a4[d0][k] = 0.f;
       b4[d0][k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   f32x4acc acc[TM][TN];
@@ -107,8 +112,12 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_direct4_kernel(ConvArgs p) 
     _Pragma("unroll") for (int k = 0; k < R; k++) {                                                                      \
       if constexpr (TM == 4)                                                                                             \
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(a4[d][k]) : "v"(avo), "s"(rw), "s"((wrow + k * CK) * Mp * 4)); \
-      else                                                                                                               \
+      else if constexpr (TM == 3)                                                                                        \
+        asm volatile("buffer_load_dwordx3 %0, %1, %2, %3 offen" : "+v"(a4[d][k]) : "v"(avo), "s"(rw), "s"((wrow + k * CK) * Mp * 4)); \
+      else if constexpr (TM == 2)                                                                                        \
         asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(a4[d][k]) : "v"(avo), "s"(rw), "s"((wrow + k * CK) * Mp * 4)); \
+      else                                                                                                               \
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(a4[d][k]) : "v"(avo), "s"(rw), "s"((wrow + k * CK) * Mp * 4)); \
     }                                                                                                                    \
     _Pragma("unroll") for (int k = 0; k < R; k++)                                                                        \
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "+v"(b4[d][k]) : "v"(bvo), "s"(rx), "s"(xso), "n"(16 * k)); \
@@ -124,7 +133,8 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_direct4_kernel(ConvArgs p) 
     _Pragma("unroll") for (int e = 0; e < 4 * R; e++) X[e] = X[e] >= 0.f ? X[e] : alpha * X[e];                          \
     _Pragma("unroll") for (int k = 0; k < R; k++)                                                                        \
       _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                   \
-        const float av = a4[d][k][i];                                                                                    \
+        float av;                                                                                                        \
+        if constexpr (TM == 1) av = a4[d][k]; else av = a4[d][k][i];                                                     \
         _Pragma("unroll") for (int j = 0; j < TN; j++)                                                                   \
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, X[j * R + k], acc[i][j], 0, 0, 0);                        \
       }                                                                                                                  \
@@ -182,11 +192,11 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_direct4_kernel(ConvArgs p) 
   const int nvalid = p.Nq - n0;  // columns of this tile inside the signal (>= 1)
   if (p.up == 1) {
     // quad e = (row, four adjacent columns): 16 consecutive lanes = 256 contiguous bytes of one output row
-    constexpr int NQ = BM * 16, QPT = NQ / RNT;
-    static_assert(NQ % RNT == 0, "quads per thread");
+    constexpr int NQ = BM * 16, QPT = (NQ + RNT - 1) / RNT;
 #pragma unroll
     for (int u = 0; u < QPT; u++) {
       const int e = rt + u * RNT;
+      if (NQ % RNT != 0 && e >= NQ) break;
       const int row = e >> 4, cq = (e & 15) * 4;
       const int m = m0 + row;
       if (m >= p.M || cq >= nvalid) continue;
@@ -293,13 +303,18 @@ struct Direct4Cfg {
 };
 #define OU_D4(R, TM, WN, WK, D) {R, TM, WN, WK, D, conv_direct4_kernel<R, TM, WN, WK, D>}
 // ring depth: 4 slots of 2 R loads while that fits the 6-bit vmcnt and the register file (R <= 2), else 2
-// (64-row tiles -- TM = 4 -- are never the rule's choice, see direct4_pick: in `make EXPERIMENTS=1` builds only, for the sweep tool)
+// (64-row tiles -- TM = 4 -- are never the rule's choice, see direct4_pick: in `make EXPERIMENTS=1` builds only, for the sweep
+// tool; 16- and 48-row tiles -- TM = 1 / 3 -- exist for the short layers, where the tile height decides how evenly the blocks
+// fill 256 CUs)
 #ifdef OU_EXPERIMENTS
 #define OU_D4_SHAPES(R, D)                                                                                    \
   OU_D4(R, 4, 4, 1, D), OU_D4(R, 2, 4, 1, D), OU_D4(R, 4, 1, 2, D), OU_D4(R, 2, 1, 2, D), OU_D4(R, 4, 1, 4, D), \
-  OU_D4(R, 2, 1, 4, D), OU_D4(R, 4, 1, 8, D), OU_D4(R, 2, 1, 8, D)
+  OU_D4(R, 2, 1, 4, D), OU_D4(R, 4, 1, 8, D), OU_D4(R, 2, 1, 8, D), OU_D4(R, 1, 1, 4, D), OU_D4(R, 1, 1, 8, D), \
+  OU_D4(R, 3, 1, 4, D), OU_D4(R, 3, 1, 8, D)
 #else
-#define OU_D4_SHAPES(R, D) OU_D4(R, 2, 4, 1, D), OU_D4(R, 2, 1, 2, D), OU_D4(R, 2, 1, 4, D), OU_D4(R, 2, 1, 8, D)
+#define OU_D4_SHAPES(R, D)                                                                            \
+  OU_D4(R, 2, 4, 1, D), OU_D4(R, 2, 1, 2, D), OU_D4(R, 2, 1, 4, D), OU_D4(R, 2, 1, 8, D), OU_D4(R, 1, 1, 4, D), \
+  OU_D4(R, 1, 1, 8, D), OU_D4(R, 3, 1, 4, D), OU_D4(R, 3, 1, 8, D)
 #endif
 static const Direct4Cfg kDirect4Cfgs[] = {
     OU_D4_SHAPES(1, 4), OU_D4_SHAPES(2, 4), OU_D4_SHAPES(3, 2), OU_D4_SHAPES(4, 2), OU_D4_SHAPES(5, 2), OU_D4_SHAPES(8, 2),
@@ -321,7 +336,25 @@ hipError_t init_direct4_kernels() {
 // at 55-77 % (operand latency is longer than the ring) -- as long as a wave keeps >= 64 MFMAs of its own and the launch stays
 // under ~12 000 waves.  (An estimate of cycles per launch picked worse shapes than this rule on a third of the layers: block
 // counts just above a multiple of the CU count, LDS-limited residency and the single-wave MFMA rate all enter.)
-static bool direct4_pick(int M, long ct_b, int slots, int R, int D, int* tm_out, int* wk_out) {
+// SHORT layers (a few hundred frames, batch 1 - 2: the 401-frame levels): a few hundred tiles whatever the shape, so the launch
+// lasts as long as its fullest CU -- the tile height (16 / 32 / 48 rows) is chosen for the block count that fills 256 CUs most
+// evenly: cost = ceil(blocks / CUs) x rows; 1536 x 401 (GRU input projection): 48 rows -> 224 blocks, one per CU (32 rows: 336
+// blocks = two on 80 CUs); 512 x 401: 16 rows -> 224 blocks (32 rows: 112).  Widest K split the layer admits.
+static bool direct4_pick(int M, long ct_b, int slots, int R, int D, bool short_layer, int num_cu, int* tm_out, int* wk_out) {
+  if (short_layer) {
+    int wk = 8;
+    while (wk > 4 && slots % (wk * D) != 0) wk >>= 1;
+    if (slots % (wk * D)) return false;
+    int best_tm = 0;
+    long best_cost = 0;
+    for (int tm = 1; tm <= 3; tm++) {
+      const long blocks = (long)((M + 16 * tm - 1) / (16 * tm)) * ct_b;
+      const long cost = (blocks + num_cu - 1) / num_cu * tm;
+      if (!best_tm || cost <= best_cost) { best_tm = tm; best_cost = cost; }  // (ties: the taller tile)
+    }
+    *tm_out = best_tm; *wk_out = wk;
+    return true;
+  }
   const long tiles = (long)((M + 31) / 32) * ct_b;
   int wk = 8;
   while (wk > 1 && (slots % (wk * D) != 0 || (slots / wk) * 8 * R < 64 || tiles * wk > 12000)) wk >>= 1;
@@ -340,10 +373,15 @@ hipError_t launch_conv_direct4(const ConvArgs& a, int num_cu, hipStream_t stream
   if (a.up > 1 && (a.Cout * a.up != a.M || a.Tout != a.Nq * a.up)) return hipErrorInvalidConfiguration;
   const int slots = a.Cin / 4;
   const long ct = (a.Nq + 63) / 64;
-  // The 401-frame levels at batch 1 - 2 (7 column tiles per element, M = 512 .. 1536: a few hundred tiles whatever the shape)
-  // stay with the first-generation kernels: 12.1 vs 12.9 us on the GRU input projection, 6.3 vs 8.0 on the 512-channel 1x1,
-  // 33 vs 49 on the K = 5120 st convs; from batch 4 this kernel is 3-8 % ahead there too.
-  if (a.force_cfg < 300 && a.d4_force == 0 && a.Nq < 1024 && a.B < 4) return hipErrorInvalidConfiguration;
+  // The 401-frame levels (7 column tiles per element, M = 512 .. 1536: a few hundred tiles whatever the shape).  At batch 1
+  // the tile height is picked for an even fill of the CUs (direct4_pick): 10.3 vs 15.6 us on the k = s = 5 rate-change conv
+  // (224 blocks of 16 rows instead of 112 of 32), 11.0 vs 11.9 on the GRU input projection (224 of 48 rows), the rest equal to
+  // the first generation (profiles/r04_final_d4_sweep_PP16_B1.txt).  A transposed conv whose FIR the first generation fuses
+  // stays there (conv + FIR pass: 11.8 + 5.3 vs 17.1 us fused), and so do batch 2 - 3 (12 .. 20 us either way); from batch 4
+  // this kernel is 3-8 % ahead on these levels too.
+  const bool short_layer = a.Nq < 1024 && a.B < 4;
+  if (a.force_cfg < 300 && a.d4_force == 0 && short_layer && (!a.d4_short || a.B > 1 || (probe && a.up > 1)))
+    return hipErrorInvalidConfiguration;
   const Direct4Cfg* best = nullptr;
   auto code = [](const Direct4Cfg& c) { return 10 * c.TM + (c.WK == 1 ? 0 : c.WK == 2 ? 1 : c.WK == 4 ? 2 : 3); };
   const int D = R <= 2 ? 4 : 2;
@@ -353,7 +391,7 @@ hipError_t launch_conv_direct4(const ConvArgs& a, int num_cu, hipStream_t stream
     if (pass == 1) {
       if (a.force_cfg >= 300) break;
       int tm = 0, wk = 0;
-      if (!direct4_pick(a.M, ct * a.B, slots, R, D, &tm, &wk)) break;
+      if (!direct4_pick(a.M, ct * a.B, slots, R, D, short_layer, num_cu, &tm, &wk)) break;
       want = 10 * tm + (wk == 1 ? 0 : wk == 2 ? 1 : wk == 4 ? 2 : 3);
     } else if (want == 0) {
       continue;

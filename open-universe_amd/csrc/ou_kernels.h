@@ -42,6 +42,7 @@ struct ConvArgs {
                                        // 4 = + the wide-load split-K kernel for 1x1 / phase-GEMM / rate-change layers
                                        //     (conv_direct4_kernel)
   int d4_fir_unfused = 1;              // OU_D4_FIR=0: up convs with a fusable FIR stay on the first-generation fused kernel
+  int d4_short = 1;                    // OU_D4_SHORT=0: the 401-frame levels at batch 1 stay on the first-generation kernels
   int d4_force = 0;                    // OU_D4_FORCE = 10 TM + log2(WK): that tile shape wherever a layer admits it (tests / tuning)
   // Anti-alias FIR of the up path fused into the epilogue (direct kernel, up > 1, KW == 1 only; launch_conv returns
   // hipErrorNotSupported otherwise and the caller runs launch_fir after a plain launch):

@@ -38,8 +38,10 @@ for L in layers:
     mflop = 2.0 * L["M"] * Nq * L["Cin"] * L["KW"] * B * 1e-6
     row = []
     best = None
-    for tm in (2, 4):
+    for tm in (1, 2, 3, 4):
         for lw, wk in enumerate((1, 2, 4, 8)):
+            if tm in (1, 3) and wk < 4:
+                continue
             cfg = 300 + 10 * tm + lw
             try:
                 ms, used = model.bench_conv(L["name"], B, Tin, cfg=cfg, with_res=False, iters=20)
@@ -49,6 +51,9 @@ for L in layers:
             except Exception:
                 row.append(f"t{tm}k{wk}:  n/a")
     auto, used = model.bench_conv(L["name"], B, Tin, with_res=False, iters=20)
+    os.environ["OU_D4_SHORT"] = "1"
+    short, used_s = model.bench_conv(L["name"], B, Tin, with_res=False, iters=20)
+    os.environ.pop("OU_D4_SHORT")
     os.environ["OU_CONV_DIRECT"] = "3"
     old, used_old = model.bench_conv(L["name"], B, Tin, with_res=False, iters=20)
     os.environ.pop("OU_CONV_DIRECT")
@@ -56,5 +61,5 @@ for L in layers:
     tot_old += old
     bs = f"best {best[1]} {best[0] * 1e3:5.1f}" if best else "best n/a"
     print(f"{L['name'][-44:]:44s} M={L['M']:5d} Nq={Nq:6d} K={L['Cin'] * L['KW']:5d} up={L['up']} | auto cfg{used} {auto * 1e3:5.1f}us "
-          f"{mflop / auto / 1e6:5.1f}TF | {bs} | old cfg{used_old} {old * 1e3:5.1f}us {mflop / old / 1e6:5.1f}TF | " + " ".join(row), flush=True)
+          f"{mflop / auto / 1e6:5.1f}TF | short-rule cfg{used_s} {short * 1e3:5.1f}us | {bs} | old cfg{used_old} {old * 1e3:5.1f}us {mflop / old / 1e6:5.1f}TF | " + " ".join(row), flush=True)
 print(f"sum over the layers: auto {tot_auto * 1e3:.1f} us, first generation {tot_old * 1e3:.1f} us")
