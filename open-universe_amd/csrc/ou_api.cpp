@@ -109,6 +109,7 @@ struct Tensor {
 struct EnvCfg {
   int dbg = 0, xcd_map = -1, conv_direct = 4, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1, d4_force = 0, d4_short = 1;
   int gru_v = 2, gru_bmax = 0, gru_ts = 0, gru_upw = 0, gru_backoff = 0, gru_agent = -1, gru_dbg = 0;
+  int dbg_dec0_under_gru = 0;  // OU_DBG_DEC0: measurement only, INVALID results (see run_score)
   double tile_min = -1.0;  // < 0: the launcher's default
   int tile_prefetch = 1;
   std::string chain_ts;
@@ -124,6 +125,7 @@ struct EnvCfg {
     gru_v = geti("OU_GRU_V", 2); gru_bmax = geti("OU_GRU_BMAX", 0); gru_ts = std::getenv("OU_GRU_TS") ? 1 : 0;
     gru_upw = geti("OU_GRU_UPW", 0); gru_backoff = geti("OU_GRU_BACKOFF", 0); gru_agent = geti("OU_GRU_AGENT_STORES", -1);
     gru_dbg = geti("OU_GRU_DBG", 0);
+    dbg_dec0_under_gru = geti("OU_DBG_DEC0", 0);
     { const char* e = std::getenv("OU_TILE_MIN"); if (e) tile_min = std::atof(e); }
     tile_prefetch = geti("OU_TILE_PREFETCH", 1);
     { const char* e = std::getenv("OU_CHAIN_TS"); if (e) chain_ts = e; }
@@ -219,6 +221,8 @@ struct Runner {
   unsigned* status_words = nullptr;        // workspace header (layout_persist)
   unsigned long long* block3_bar = nullptr;
   bool gru_shared = false;  // GRU launches enqueued now may run beside another GRU layer (overlapped conditioner / score pass)
+  hipEvent_t pre_gru = nullptr;  // OU_DBG_DEC0: recorded right before the score net's GRU launch
+  bool want_pre_gru = false;
   // GRU launches that can meet on one XCD: this call's own two layers when they overlap, times the lanes whose clusters are
   // dealt to the same XCDs (lane l deals its 2 B clusters from XCD 2 B l on)
   static int gru_share_of(int lanes, int B, bool overlap) {
@@ -539,6 +543,10 @@ struct Runner {
       h->prof.push_back(rec);
       h->prof_used++;
     }
+    if (want_pre_gru) {
+      pre_gru = next_event();
+      if (pre_gru) chk(hipEventRecord(pre_gru, st), "pre-gru record");
+    }
     chk(launch_gru(a, h->num_cu, st), G.name.c_str());
     return out;
   }
@@ -702,10 +710,11 @@ ScoreEnc run_score_enc(Runner& r, Persist& P, const float* x, const StepCoef* co
   return E;
 }
 void run_score_dec(Runner& r, Persist& P, const ScoreEnc& E, const float* x, const float* noise, float* out, int mode,
-                   const StepCoef* coef, int coef_bs, const float* film_row, int film_bs, int T) {
+                   const StepCoef* coef, int coef_bs, const float* film_row, int film_bs, int T, const Tensor* dec0_done = nullptr) {
   const Model& m = r.h->m;
   Tensor y = E.hg;
   for (int j = 0; j < m.n_blocks; j++) {
+    if (j == 0 && dec0_done) { y = *dec0_done; continue; }
     const float* fr = film_row ? film_row + m.film.dec_off[j] : nullptr;
     const Tensor& res = E.residuals[m.n_blocks - 1 - j];
     const float* resp = (j == 0 && E.fuse_res) ? nullptr : res.p;
@@ -716,9 +725,31 @@ void run_score_dec(Runner& r, Persist& P, const ScoreEnc& E, const float* x, con
     r.chk(launch_out_conv(y.p, r.W(m.s_out.w_off), r.W(m.s_out.b_off), r.W(m.s_out.a_off), x, noise, out, coef,
                           coef_bs, m.cfg.has_edm, mode, r.B, m.C0, T, m.s_out.KW, r.st), "score.out");
 }
+static bool m_blocks_ok(const Runner& r) { return r.h->m.n_blocks >= 1 && r.h->m.s_dec[0].dir == 0; }
 void run_score(Runner& r, Persist& P, const float* x, const float* noise, float* out, int mode,
                const StepCoef* coef, int coef_bs, const float* film_row, int film_bs, int T) {
+  // OU_DBG_DEC0=1 -- MEASUREMENT ONLY, RESULTS INVALID: the first decoder block is launched on a side stream that waits for
+  // what precedes the GRU launch instead of the GRU itself, i.e. its three convs run UNDER the recurrence (on whatever that has
+  // written so far).  The time of a forward in this mode is a lower bound for any scheme that gates those convs on the
+  // recurrence's progress: the gated version can only start later and wait more.
+  const bool dec0_under = r.env.dbg_dec0_under_gru != 0 && !r.dry && r.h->overlap && r.h->lanes <= 1 && m_blocks_ok(r);
+  r.want_pre_gru = dec0_under;
   ScoreEnc E = run_score_enc(r, P, x, coef, coef_bs, film_row, film_bs, T);
+  r.want_pre_gru = false;
+  if (dec0_under && r.pre_gru && r.ok()) {
+    const Model& m = r.h->m;
+    hipStream_t main = r.st;
+    r.chk(hipStreamWaitEvent(r.h->aux[0], r.pre_gru, 0), "dec0 wait");
+    r.st = r.h->aux[0];
+    const float* fr = film_row ? film_row + m.film.dec_off[0] : nullptr;
+    const Tensor& res = E.residuals[m.n_blocks - 1];
+    auto bo = r.block(m.s_dec[0], E.hg, "score.dec0", fr, film_bs, P.sc[0].p, E.fuse_res ? nullptr : res.p);
+    r.st = main;
+    r.join(0, main);
+    Tensor done = bo.v;
+    run_score_dec(r, P, E, x, noise, out, mode, coef, coef_bs, film_row, film_bs, T, &done);
+    return;
+  }
   run_score_dec(r, P, E, x, noise, out, mode, coef, coef_bs, film_row, film_bs, T);
 }
 
