@@ -151,3 +151,37 @@ def test_cli_in_flight_matches_file_by_file(tmp_path):
             a, fa = audio.load(o1 / nme)
             b, fb = audio.load(o2 / nme)
             assert fa == fb and torch.equal(a, b), nme
+
+
+def test_enhance_many_rejects_unknown_keywords():
+    """A typo must not change behaviour on the batched path only (round-3 advisor finding): `enhance_many` used to swallow
+    every keyword it did not know."""
+    model, spec, sd = get_model("PP16m")
+    a = synth_mix(spec, 1, 1500)[0].cuda()
+    with pytest.raises(TypeError, match="nsteps"):
+        model.enhance_many([a, a], None, nsteps=3)
+    with pytest.raises(ValueError, match="rngs"):
+        model.enhance_many([a, a], None, rng=torch.Generator(device="cuda"))
+    out = model.enhance_many([a, a], None, n_steps=2, ensemble_stat="median")  # (harmless: accepted)
+    assert len(out) == 2 and out[0].shape == a.shape
+
+
+def test_workspace_allocation_failure_releases_the_cache(monkeypatch):
+    """Round-3 advisor finding: an out-of-memory on a new workspace left the idle ones cached.  Now the cache is dropped and the
+    allocation retried once."""
+    model, spec, sd = get_model("PP16m")
+    model.reset_workspace()
+    a = synth_mix(spec, 2, 1500).cuda()
+    model.enhance(a, n_steps=2)           # a batch-2 workspace in the cache
+    assert 2 in model._ws_cache
+    real_empty, calls = torch.empty, []
+
+    def flaky_empty(*args, **kw):
+        if kw.get("dtype") is torch.uint8 and not calls:
+            calls.append(1)
+            raise torch.OutOfMemoryError("injected")
+        return real_empty(*args, **kw)
+
+    monkeypatch.setattr(torch, "empty", flaky_empty)
+    y = model.enhance(a[:1], n_steps=2)   # needs a batch-1 workspace: first allocation fails, cache is cleared, retry succeeds
+    assert calls and y.shape == (1, 1500) and list(model._ws_cache) == [1]
