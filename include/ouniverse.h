@@ -194,9 +194,10 @@ int ou_get_gru_publish_mode(const ou_handle* h);
  * every handle `lanes` = K and its own index `lane` (0 .. K - 1) BEFORE its first forward call.  A handle itself stays
  * non-re-entrant.  What the numbers are for: the workgroups of a GRU cluster wait for each other, so every GRU launch that
  * can be on the device at a time has to fit there whole -- the library sizes the launches of a lane to its share of the
- * XCDs and deals the clusters of lane l to XCDs of their own (2 B l, 2 B l + 1, ..).  Results do not depend on the lane
- * (K <= 4 at batch 1: bit-identical to the single-lane call; beyond that the recurrence may pick a different split of the
- * hidden units: equal to fp32 rounding).  1 <= lanes <= 8. */
+ * XCDs and deals the clusters of lane l to XCDs of their own (2 B l, 2 B l + 1, ..).  Results do not depend on the lane:
+ * a call keeps the kernels, tilings and -- as long as every cluster is still resident with it -- the split of the hidden
+ * units of the single-lane call, i.e. bit-identical results (every shipped configuration at 1 .. 8 lanes; if the split does
+ * not fit, the recurrence falls back to 16 units per workgroup: equal to fp32 rounding).  1 <= lanes <= 8. */
 int ou_set_lanes(ou_handle* h, int32_t lanes, int32_t lane);
 
 /* After the stream has been synchronised: OU_OK, or OU_ESYNC if a device-side timeout flag was raised.  The status

@@ -854,8 +854,11 @@ static int gru_ring_upw(int H, int force_upw, int B, int num_cu, int lanes, int 
   if (force_upw == 32 && H <= 256) return 32;
   if (force_upw == 9 && H >= 128 && H <= 256) return 8;
   if (force_upw == 8 && (H / 64) % 2 == 0 && H <= 384) return 8;
-  if (force_upw == 0 && (H / 64) % 2 == 0 && H <= 256 && 2 * (B > 0 ? B : 1) * (lanes > 1 ? lanes : 1) * (H / 8) <= num_cu) {
-    // ... and the clusters that may meet on one XCD must all fit there (every member of a cluster spins on the others)
+  (void)lanes;
+  if (force_upw == 0 && (H / 64) % 2 == 0 && H <= 256 && 2 * (B > 0 ? B : 1) * (H / 8) <= num_cu) {
+    // ... and the clusters that may meet on one XCD must all fit there (every member of a cluster spins on the others).  The
+    // lanes of a process do NOT enter the one-CU-per-workgroup preference above: a lane keeps the split of the single call as
+    // long as everything is resident (two workgroups per CU at worst), so that its results stay bit-identical to that call's.
     const int per_cu = gru_ring_per_cu(H, 8, gru_ring_wide(H, force_upw));
     if (share <= 1 || (num_cu / 8) * per_cu / (H / 8) >= share) return 8;
   }
