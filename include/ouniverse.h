@@ -181,8 +181,9 @@ int ou_transform_inverse(const float* spec, int32_t B, int32_t n_frames, const f
  * recurrence): 0 (default) = plain stores inside a cluster whose workgroups share one XCD (its L2 is their point of
  * coherence; verified by a rendezvous at every launch), agent-scope stores otherwise; 1 = agent-scope (sc1,
  * write-through) stores always (+0.1 ms per 401-frame pass).  Both forms are backed by a bounded-spin safety net that
- * repeats a publish system-scope and counts the event in the workspace header (words 20 / 31); a host wrapper should
- * switch to 1 for good the first time that counter moves. */
+ * repeats a publish system-scope and counts the event in the workspace header (word 20: every wait it cut short, late
+ * members included; word 33: those where the publish was there for a system-scope load but not for the gather's
+ * agent-scope load).  The library switches to 1 for good the first time word 33 moves (ou_check_device_status). */
 int ou_set_gru_publish_mode(ou_handle* h, int32_t agent_scope);
 
 /* ... and what the handle currently uses (1 after ou_set_gru_publish_mode(h, 1) or after ou_check_device_status found

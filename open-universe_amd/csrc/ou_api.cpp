@@ -528,9 +528,9 @@ struct Runner {
     a.poll_backoff = env.gru_backoff;
     // publishes: PLAIN stores by default inside a cluster that shares one XCD (the L2 is that XCD's point of coherence; the
     // rendezvous proves the placement at every launch), agent-scope (sc1) stores otherwise, on request
-    // (ou_set_gru_publish_mode) and -- for good -- from the moment ou_check_device_status sees that the kernel's safety net
-    // had to repeat a publish on this handle (status word 20).  A hipGraph captured before such a switch keeps the publish
-    // form it was captured with: re-capture after a switch.
+    // (ou_set_gru_publish_mode) and -- for good -- from the moment ou_check_device_status sees that a publish really was
+    // invisible to the gather's agent-scope loads on this handle (status word 33; word 20 also counts members that were
+    // merely late).  A hipGraph captured before such a switch keeps the publish form it was captured with: re-capture.
     a.agent_stores = env.gru_agent >= 0 ? (env.gru_agent != 0) : h->gru_agent_stores;
     a.dbg = env.gru_dbg;
     if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {
