@@ -306,6 +306,9 @@ def parse_args(argv=None):
     ap.add_argument("--share-devices", action="store_true",
                     help="allow more ranks than visible GPUs (ranks wrap around the devices, gloo rendezvous): "
                          "exercises the N > 1 path on a 1-GPU box; not a scaling measurement")
+    ap.add_argument("--force-nccl", action="store_true",
+                    help="create the nccl (= RCCL) process group even with ONE rank: communicator set-up, the environment RCCL "
+                         "needs and the device-side weight broadcast then execute on a 1-GPU box exactly as on a node")
     ap.add_argument("--sustained-s", type=float, default=10.0,
                     help="length of the sustained leg (back-to-back free-running enhance calls with the device clock and power "
                          "sampled beside them); 0 = off")
@@ -382,7 +385,8 @@ def main():
     if args.gpus > ndev and not args.share_devices:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} HIP device(s) visible "
                          "(--share-devices runs the ranks on shared GPUs for a functional check)")
-    rank, local_rank, world = D.init()
+    rank, local_rank, world = D.init(backend="nccl" if args.force_nccl else None, force=args.force_nccl)
+    host_threads = D.cap_host_threads()  # one process per GPU: the ranks of a node share its host cores
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU")
     device = D.local_device(local_rank)
@@ -402,7 +406,8 @@ def main():
     torch.cuda.synchronize()
     t_pack_bcast = time.perf_counter() - t_b0
     bcast = None
-    if world > 1:
+    grouped = torch.distributed.is_initialized()
+    if grouped:
         # the collective alone (the first call above also folds / packs on rank 0 and sets the communicator up)
         xb = blob if torch.distributed.get_backend() == "nccl" else blob.cpu()
         torch.distributed.barrier()
@@ -416,7 +421,8 @@ def main():
         torch.distributed.all_gather_object(csum, (float(blob.double().sum().item()), int(blob.numel())))
         bcast = {"bytes": int(blob.numel() * 4), "seconds": t_b, "GBs": blob.numel() * 4 / t_b / 1e9,
                  "pack_plus_first_broadcast_s": t_pack_bcast, "identical_on_all_ranks": len(set(csum)) == 1,
-                 "backend": torch.distributed.get_backend()}
+                 "backend": torch.distributed.get_backend(), "ranks": world}
+    rccl = D.rccl_report(device)  # ranks, distinct physical GPUs (UUIDs), backend -- what a SCALE record has to prove
     cls = UniverseGAN if spec.kind == "universe_gan" else Universe
     model = cls(spec, packed_weights=blob, device=device)
 
@@ -741,10 +747,12 @@ def main():
                 "parallelism": "utterances sharded across GPUs; packed weights broadcast once over RCCL; "
                                "no collective in the sampling loop",
                 "devices": devs,
-                "backend": torch.distributed.get_backend() if world > 1 else None,
+                "backend": torch.distributed.get_backend() if grouped else None,
                 "launches_per_enhance": launches[0],
             },
             "per_rank_ms_per_step": rank_ms,
+            "rccl": rccl,
+            "host_threads_per_rank": host_threads,
             "weight_broadcast": bcast,
             "batch_sweep": dict(batch_sweep, note="utterances/s of the whole job at other per-GPU batch sizes (same model, "
                                                   "length and step count; MAX over ranks like the headline)"),
@@ -762,7 +770,7 @@ def main():
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.model, args.n_steps, args.seconds)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if grouped:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -201,10 +201,21 @@ int ou_get_gru_publish_mode(const ou_handle* h);
  * not fit, the recurrence falls back to 16 units per workgroup: equal to fp32 rounding).  1 <= lanes <= 8. */
 int ou_set_lanes(ou_handle* h, int32_t lanes, int32_t lane);
 
+/* Lanes that run calls of DIFFERENT batch sizes at the same time (distributed.enhance_sharded(batch_size > 1, in_flight > 1)
+ * on a ragged set, the CLI with files of different channel counts): the share of an XCD a lane's GRU launch may take and the
+ * XCDs its clusters are dealt to were functions of that call's own B -- lanes that disagree about B then disagree about the
+ * layout, and more cluster workgroups than an XCD holds wait for members that cannot be scheduled (a spurious device-side
+ * time-out).  Tell EVERY handle of the pool the largest batch size any lane will run (`max_batch` >= 1; 0 = "this call's own
+ * B", the default and the right value when all calls have one size): shares and placement are then computed from that one
+ * number on all lanes.  A call smaller than max_batch may fall back to 16 hidden units per workgroup where the single call
+ * takes 8 -- equal to fp32 rounding (> 100 dB), not bit-identical; calls of size max_batch are unchanged. */
+int ou_set_lane_batch(ou_handle* h, int32_t max_batch);
+
 /* After the stream has been synchronised: OU_OK, or OU_ESYNC if a device-side timeout flag was raised.  The status
  * word (first 4 bytes of the workspace) is sticky: it stays raised until ou_workspace_init() / this call clears it.
- * Also reads the recovery counter of the GRU hand-offs (word 20): once it has moved, the handle publishes with
- * agent-scope stores from the next call on (see ou_set_gru_publish_mode). */
+ * Also reads status word 33 -- GRU publishes that were INVISIBLE to the gather's agent-scope loads (the recovery counter,
+ * word 20, also counts cluster members that were merely late and does not switch anything): once word 33 has moved, the
+ * handle publishes with agent-scope stores from the next call on (see ou_set_gru_publish_mode). */
 int ou_check_device_status(ou_handle* h, void* ws);
 
 /* ---- introspection (tests, profiling) ------------------------------------------------------------------- */

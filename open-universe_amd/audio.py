@@ -82,6 +82,25 @@ def load(path):
     return torch.from_numpy(x[:n].reshape(-1, ch).T.copy()), fs
 
 
+def channels(path):
+    """Number of channels of an audio file from its header alone (no sample is decoded)."""
+    ta = _torchaudio()
+    if ta is not None:
+        return int(ta.info(str(path)).num_channels)
+    with open(path, "rb") as f:
+        head = f.read(12)
+        if head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+            raise RuntimeError(f"{path}: not a RIFF/WAVE file")
+        while True:
+            ck = f.read(8)
+            if len(ck) < 8:
+                raise RuntimeError(f"{path}: missing fmt chunk")
+            cid, size = ck[:4], int.from_bytes(ck[4:], "little")
+            if cid == b"fmt ":
+                return int.from_bytes(f.read(4)[2:4], "little")
+            f.seek(size + (size & 1), 1)
+
+
 def save(path, audio, fs):
     """audio: float tensor (channels, T).  Written as 32-bit float WAV (what torchaudio.save does for float32)."""
     ta = _torchaudio()

@@ -29,7 +29,7 @@ from pathlib import Path
 import torch
 
 from .. import inference_utils
-from ..audio import AUDIO_SUFFIXES, can_decode, load, resample, save
+from ..audio import AUDIO_SUFFIXES, can_decode, channels, load, resample, save
 
 
 def handle_help(argv):
@@ -182,7 +182,11 @@ def main(argv=None, model=None):
             save(output_path, enh.cpu(), fs)
             done.append(output_path)
 
-        with LanePool(model, min(int(args.in_flight), LanePool.MAX_LANES)) as pool:
+        # one call per file, batch size = its channel count: files that differ there put calls of different sizes in flight,
+        # and the lanes then have to agree on how their GRU clusters share the device (headers only are read here)
+        chans = {channels(path) for _, path in todo}
+        with LanePool(model, min(int(args.in_flight), LanePool.MAX_LANES),
+                      max_batch=max(chans) if len(chans) > 1 else 0) as pool:
             pending = []
             for k, path in todo:
                 output_path = out_path(path)

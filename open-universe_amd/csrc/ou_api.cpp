@@ -72,10 +72,10 @@ struct ou_handle {
   struct WsRec { const void* ws; size_t bytes; int B, T; };
   std::vector<WsRec> ws_ready;
   int gru_agent_stores = 0;  // ou_set_gru_publish_mode; also set by ou_check_device_status when the safety net had to act
-  unsigned gru_recoveries_seen = 0;
   // enhance calls in flight side by side in this process, one handle + stream + workspace each (ou_set_lanes): the GRU
   // launches of all lanes have to be resident together
   int lanes = 1, lane = 0;
+  int lane_max_b = 0;  // ou_set_lane_batch: largest batch size any lane of the pool runs (0: every call's own B)
   // A workspace prepared for (B, T0) serves every T of the same batch size that fits into it: everything ou_workspace_init
   // prepares (status words, tag epochs, GRU exchange areas) lies in a header whose layout depends on B alone, and the tag
   // epochs advance monotonically whatever the length of a pass -- a directory of files of different lengths runs on ONE
@@ -125,7 +125,9 @@ struct EnvCfg {
     gru_v = geti("OU_GRU_V", 2); gru_bmax = geti("OU_GRU_BMAX", 0); gru_ts = std::getenv("OU_GRU_TS") ? 1 : 0;
     gru_upw = geti("OU_GRU_UPW", 0); gru_backoff = geti("OU_GRU_BACKOFF", 0); gru_agent = geti("OU_GRU_AGENT_STORES", -1);
     gru_dbg = geti("OU_GRU_DBG", 0);
+#ifdef OU_EXPERIMENTS  // measurement-only switch with INVALID results: `make EXPERIMENTS=1` builds only, never in the shipped library
     dbg_dec0_under_gru = geti("OU_DBG_DEC0", 0);
+#endif
     { const char* e = std::getenv("OU_TILE_MIN"); if (e) tile_min = std::atof(e); }
     tile_prefetch = geti("OU_TILE_PREFETCH", 1);
     { const char* e = std::getenv("OU_CHAIN_TS"); if (e) chain_ts = e; }
@@ -520,8 +522,10 @@ struct Runner {
     // for every batch size; OU_GRU_V=1 selects the polling-wave kernel of round 1.  Its publishes: see below.
     a.version = env.gru_v;
     a.lanes = h->lanes;
-    a.share = gru_share_of(h->lanes, B, gru_shared);
-    a.xcd_rot = h->lanes > 1 ? (2 * B * h->lane) % 8 : 0;
+    // (lanes whose calls differ in batch size must agree on the layout: shares and placement from the pool's largest batch)
+    const int Bl = (h->lanes > 1 && h->lane_max_b > B) ? h->lane_max_b : B;
+    a.share = gru_share_of(h->lanes, Bl, gru_shared);
+    a.xcd_rot = h->lanes > 1 ? (2 * Bl * h->lane) % 8 : 0;
     a.force_bmax = env.gru_bmax;
     if (env.gru_ts) a.tstamps = (long long*)(base + cap - (1u << 20));
     a.force_upw = env.gru_upw;
@@ -1187,7 +1191,6 @@ int ou_check_device_status(ou_handle* h, void* ws) {
   // relied upon on this device / in this process mix: agent-scope publishes from now on (+0.1 ms per GRU pass, no more
   // 0.1 ms recoveries).  Results are unaffected either way.
   if (hdr[33] != 0u && !h->gru_agent_stores) h->gru_agent_stores = 1;
-  h->gru_recoveries_seen = hdr[20];
   if (v) {
     (void)hipMemset(ws, 0, sizeof(v));  // sticky until read
     return fail(h, OU_ESYNC, "device-side timeout in the GRU cluster exchange (status word " + std::to_string(v) + ")");
@@ -1222,6 +1225,12 @@ int ou_set_lanes(ou_handle* h, int32_t lanes, int32_t lane) {
   if (!h || lanes < 1 || lanes > 8 || lane < 0 || lane >= lanes) return fail(h, OU_EINVAL, "ou_set_lanes: 1 <= lanes <= 8, 0 <= lane < lanes");
   h->lanes = lanes;
   h->lane = lane;
+  return OU_OK;
+}
+
+int ou_set_lane_batch(ou_handle* h, int32_t max_batch) {
+  if (!h || max_batch < 0) return fail(h, OU_EINVAL, "ou_set_lane_batch: max_batch >= 0");
+  h->lane_max_b = max_batch;
   return OU_OK;
 }
 

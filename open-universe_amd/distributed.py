@@ -42,16 +42,67 @@ def local_device(local_rank):
     return torch.device("cuda", local_rank % torch.cuda.device_count())
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (nccl == RCCL on ROCm; gloo on CPU / shared GPU)."""
+def init(backend=None, force=False):
+    """Initialise torch.distributed from the torchrun environment (nccl == RCCL on ROCm; gloo on CPU / shared GPU).
+    A single process normally runs without a process group; `force=True` creates one anyway (world size 1, rendezvous on
+    127.0.0.1) so that communicator set-up, the environment RCCL needs and the device-side weight broadcast execute on a
+    1-GPU box exactly as they do on a node (`bench.py --force-nccl`, tests/test_gpu_distributed.py)."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = pick_backend(world)
         if torch.cuda.is_available():
             torch.cuda.set_device(local_device(local_rank))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(free_port())
+        kw = {}
+        if backend == "nccl":  # bind the communicator to this rank's device up front (no lazy guess at the first collective)
+            kw["device_id"] = local_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
+
+
+def cap_host_threads(local_world=None):
+    """One process per GPU: the ranks of a node share its host cores.  Caps torch's intra-op pool of THIS process at
+    min(8, logical CPUs / local ranks) unless OMP_NUM_THREADS says otherwise -- the enhance path needs one enqueueing thread;
+    eight uncapped ranks would start 8 x 256 OpenMP threads for the few host-side tensor ops there are."""
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if "OMP_NUM_THREADS" in os.environ:
+        n = max(1, int(os.environ["OMP_NUM_THREADS"]))
+    else:
+        n = max(1, min(8, (os.cpu_count() or 8) // max(1, local_world)))
+    torch.set_num_threads(n)
+    return n
+
+
+def rccl_report(device):
+    """What a multi-GPU record has to prove: how many ranks there were, that each sat on its OWN physical GPU (distinct
+    device UUIDs, not just distinct ordinals) and which backend carried the collectives.  All ranks must call it."""
+    if not dist.is_initialized():
+        return None
+    device = torch.device(device)
+    me = {"rank": dist.get_rank(), "device": str(device), "uuid": None, "name": None, "pci": None,
+          "host_threads": torch.get_num_threads()}
+    if device.type == "cuda":
+        pr = torch.cuda.get_device_properties(device)
+        me["uuid"] = str(getattr(pr, "uuid", "")) or None
+        me["name"] = pr.name
+        me["pci"] = f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}"
+    every = [None] * dist.get_world_size()
+    dist.all_gather_object(every, me)
+    ids = [e["uuid"] or e["pci"] or e["device"] for e in every]
+    ver = None
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    return {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "distinct_device_uuids": len(set(ids)),
+            "rccl_version": ver, "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+            "per_rank": every}
 
 
 def free_port():
@@ -89,19 +140,20 @@ def broadcast_packed_weights(spec, state_dict, device, src=0, packed=None):
     the blob with ONE broadcast (PP16: 185 MB, one xGMI hop).  Returns the device tensor to hand to
     Universe(packed_weights=...).  Packing can fail (missing / mis-shaped tensors): a caller whose other ranks are already
     waiting in the collective should pack first, tell them, and pass `packed` (inference_utils.load_model_sharded)."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
+    grouped = dist.is_initialized()
+    world = dist.get_world_size() if grouped else 1
+    rank = dist.get_rank() if grouped else 0
     device = torch.device(device)
     nfloats = _lib.packed_bytes(spec) // 4
     # the collective runs where the backend lives: on the GPUs for RCCL, on the host for gloo
-    on_host = world > 1 and dist.get_backend() == "gloo"
+    on_host = grouped and dist.get_backend() == "gloo"
     xdev = torch.device("cpu") if on_host else device
     if rank == src:
         blob = packed if packed is not None else _lib.pack_weights(spec, state_dict)[0]
         blob = blob.to(xdev)
     else:
         blob = torch.empty(nfloats, dtype=torch.float32, device=xdev)
-    if world > 1:
+    if grouped:  # (also with ONE rank when a group exists: the same code path as on a node, cheap)
         dist.broadcast(blob, src=src)
     return blob.to(device)
 
@@ -200,7 +252,9 @@ def enhance_sharded(model, signals, seed=1028282, gather=True, batch_size=1, pad
     if in_flight > 1 and getattr(model, "fork", None) is not None and enhance_kwargs.get("target") is None:
         from .lanes import LanePool
 
-        with LanePool(model, min(in_flight, LanePool.MAX_LANES)) as pool:
+        sizes = {len(g) for g in groups}
+        # (groups of different sizes in flight side by side: the lanes must agree on the GRU cluster layout -- the pool's largest)
+        with LanePool(model, min(in_flight, LanePool.MAX_LANES), max_batch=max(sizes) if len(sizes) > 1 else 0) as pool:
             for group in groups:
                 _, res = pool.submit(lambda m, g=group: run_group(m, g))
                 for i, o in zip(group, res):

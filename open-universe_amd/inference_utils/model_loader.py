@@ -178,7 +178,7 @@ def load_model_sharded(ckpt_path, device=None, strict=True, return_config=False,
             packed = _lib.pack_weights(spec, sd)[0]
         except Exception as e:
             err = e
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         flag = [repr(err) if err is not None else None]
         dist.broadcast_object_list(flag, src=0)
         if flag[0] is not None:

@@ -23,7 +23,10 @@ class LanePool:
 
     MAX_LANES = 8
 
-    def __init__(self, model, lanes):
+    def __init__(self, model, lanes, max_batch=0):
+        """`max_batch`: the largest batch size any call submitted to this pool will have, when the calls differ in size
+        (groups of a ragged set, files of different channel counts) -- all lanes then agree on how the GRU clusters of the
+        pool share the XCDs (include/ouniverse.h, ou_set_lane_batch).  0: all calls have one size."""
         lanes = int(lanes)
         if not 1 <= lanes <= self.MAX_LANES:
             raise ValueError(f"lanes must be in [1, {self.MAX_LANES}]")
@@ -36,7 +39,7 @@ class LanePool:
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(lanes)]
         self._saved_mode = model.check_status
         for k, m in enumerate(self.models):
-            m.set_lanes(lanes, k)
+            m.set_lanes(lanes, k, max_batch)
             m.check_status = False  # free-running: nothing inside a lane waits for the device
         self._next = 0
         self._busy = [False] * lanes
@@ -58,9 +61,9 @@ class LanePool:
         for t in inputs:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(s)
+        self._busy[k] = True  # (before fn: if it raises half-way, what it did enqueue is still waited for at close)
         with torch.cuda.stream(s):
             out = fn(self.models[k])
-        self._busy[k] = True
         return k, out
 
     def wait(self, lane):
@@ -82,9 +85,16 @@ class LanePool:
         try:
             self.synchronize()
         finally:
+            for st in self.streams:  # whatever happened above: nothing of this pool may still run when the models go back
+                st.synchronize()
             for m in self.models:
                 m.set_lanes(1, 0)
                 m.check_status = self._saved_mode
+            for m in self.models[1:]:  # the forks stay (handles are cheap), their workspaces -- grown to the longest call -- go
+                try:
+                    m.reset_workspace()
+                except RuntimeError:
+                    pass  # (a time-out on that lane has been raised by synchronize() above already)
             self.models = self.models[:1]
 
     def __enter__(self):

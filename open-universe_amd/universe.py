@@ -94,12 +94,19 @@ class Universe:
             _lib.check(twin._L.ou_set_gru_publish_mode(twin._handle, 1), twin._handle)
         return twin
 
-    def set_lanes(self, lanes, lane):
+    def set_lanes(self, lanes, lane, max_batch=0):
         """This object is lane `lane` of `lanes` models whose calls are in flight side by side on this device (one stream
         each): the library then sizes and places the GRU clusters of every lane so that all of them fit on the device
-        together (include/ouniverse.h, ou_set_lanes)."""
+        together (include/ouniverse.h, ou_set_lanes).  `max_batch`: the largest batch size ANY lane of the pool will run
+        when the calls differ in size (ou_set_lane_batch; 0 = every call's own size)."""
         _lib.check(self._L.ou_set_lanes(self._handle, int(lanes), int(lane)), self._handle)
+        _lib.check(self._L.ou_set_lane_batch(self._handle, int(max_batch)), self._handle)
         self._lanes = (int(lanes), int(lane))
+
+    def release_lanes(self):
+        """Drop the forks (handles + workspaces) that `LanePool`s of this model created and kept for re-use."""
+        for twin in self.__dict__.pop("_lane_forks", []):
+            twin.reset_workspace()
 
     # ------------------------------------------------------------------------------------------------
     def __del__(self):
@@ -182,6 +189,28 @@ class Universe:
         self._ws_key = key
         self._cond_key = None
         return self._ws
+
+    def _private_workspace(self, B, T):
+        """A workspace of its own for a captured graph: never in the cache, so no eager call -- same batch size, longer
+        signal -- can regrow or evict the buffer the graph's launches point into."""
+        need = self._workspace_bytes(B, T)
+        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ou_workspace_init(self._handle, B, T, c_void_p(ws.data_ptr()), c_size_t(need), self._stream()),
+                       self._handle)
+        return ws
+
+    def _adopt_workspace(self, ws, B, T):
+        """Make `ws` (prepared for at least (B, T)) the current workspace of this object."""
+        if self._ws is ws and self._ws_key == (B, T):
+            return
+        if self._ws is not ws and self._status_event is not None and not self.check_status:
+            # free-running mode: the pending status copy belongs to the workspace that is left now
+            self._status_event.synchronize()
+            self._raise_on_status()
+        self._ws = ws
+        self._ws_key = (B, T)
+        self._cond_key = None
 
     def reset_workspace(self):
         """Drop every cached workspace: the next call allocates and initialises a fresh one (tests; after switching
@@ -575,7 +604,10 @@ class Universe:
         s_noise = torch.zeros(n_steps, B, 1, T, dtype=torch.float32, device=dev)
         s_out = torch.empty(B, 1, mix_len, dtype=torch.float32, device=dev)
         sigma = self.get_std_dev(torch.linspace(0, 1, n_steps).to(torch.float32).flip(dims=[0])).to(torch.float32).contiguous()
-        ws = self._workspace(B, T)
+        # the graph's launches carry this buffer's address: a workspace of the graph's own, outside the per-batch-size cache
+        # (an eager call with the same B and a longer T regrows the cached one)
+        ws = self._private_workspace(B, T)
+        self._adopt_workspace(ws, B, T)
         # serial=True: capture the call as ONE chain on the capture stream.  The eager path forks three side streams inside
         # the call (mel branch, st convs, first score-encoder pass); captured, every fork / join becomes a cross-stream edge
         # of the graph, and such a graph replays SLOWER than the chain (measured, profiles/).
@@ -602,9 +634,7 @@ class Universe:
         def run(mix, rng=None):
             self._poll_deferred_status()
             x = self._prep(mix).reshape(B, 1, mix_len)
-            if self._workspace(B, T) is not ws:  # (eager calls on other shapes in between are fine: workspaces are cached)
-                raise RuntimeError("the workspace this graph was captured on has been released (reset_workspace / cache "
-                                   "eviction): set graphed_enhance() up again")
+            self._adopt_workspace(ws, B, T)  # (eager calls on any shape in between are fine: the graph owns its workspace)
             s_mix.copy_(x)
             for n in range(n_steps):  # draw order of the reference: x0, z_0 .. z_{N-2}
                 s_noise[n].copy_(torch.randn((B, 1, T), dtype=torch.float32, device=dev, generator=rng))

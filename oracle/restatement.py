@@ -571,10 +571,29 @@ def compressed_mag_stft(x, n_fft, hop_length, window, transform_type, abs_expone
     return y.unsqueeze(1)
 
 
+class ParityFigure(float):
+    """SI-SDR in dB (the float itself) that also carries the figures a scale-invariant measure cannot see:
+    `.snr` = plain SNR 10 log10(|ref|^2 / |est - ref|^2) (a common gain error g shows up as -20 log10 |g - 1|) and
+    `.gain` = the least-squares gain of `est` over `ref` that SI-SDR projects away."""
+    snr = float("nan")
+    gain = float("nan")
+
+
+def snr_db(ref, est):
+    """Plain (NOT scale-invariant) SNR in dB of `est` against `ref`."""
+    ref = ref.reshape(-1).double()
+    est = est.reshape(-1).double()
+    return float(10 * torch.log10(ref.square().sum().clamp(min=1e-300) / (est - ref).square().sum().clamp(min=1e-300)))
+
+
 def si_sdr(ref, est):
-    """Scale-invariant SDR in dB of `est` against `ref` (the parity gate: >= 60 dB)."""
+    """Scale-invariant SDR in dB of `est` against `ref` (the parity gate: >= 60 dB).  The returned float carries the plain
+    SNR and the projected gain as attributes (ParityFigure); tests/helpers.record() logs and gates both."""
     ref = ref.reshape(-1).double()
     est = est.reshape(-1).double()
     a = (ref @ est) / (ref @ ref).clamp(min=1e-30)
     err = est - a * ref
-    return float(10 * torch.log10((a * ref).square().sum() / err.square().sum().clamp(min=1e-300)))
+    v = ParityFigure(10 * torch.log10((a * ref).square().sum() / err.square().sum().clamp(min=1e-300)))
+    v.snr = snr_db(ref, est)
+    v.gain = float(a)
+    return v

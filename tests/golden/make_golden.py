@@ -16,7 +16,10 @@ Fixtures are DATA only: inputs are regenerated from seeds, outputs are stored as
     full_PP24_varlen.npz BASELINE configs[4]: UNIVERSE++ 24 kHz, 8 steps, variable-length batch of 8 right-zero-padded
                          to its longest member (datasets/datamodule.py:24-42); rows 0 / 7 (longest / shortest) stored
     transform.npz        CompressedMagSTFT(Padded) forward / inverse of the reference's own classes (4 parameter sets)
-Run:  python tests/golden/make_golden.py [base] [stress] [configs] [transform]      (default: base)
+    loud_<cfg>.npz       inputs loud enough that the peak guard (universe.py:356-357) divides: row 0 at the usual level, row 1
+                         60 x louder; with keep_rms (the RMS restore puts row 1 far above full scale, the guard fires on that row
+                         only) and without (normalize_batch removes the level; the guard's state is asserted, not assumed)
+Run:  python tests/golden/make_golden.py [base] [stress] [configs] [transform] [loud]      (default: base)
 """
 import json
 import os
@@ -119,6 +122,26 @@ def make_configs():
     print("C5", lens, enh.shape, float(enh.std()))
 
 
+LOUD_GAINS = (1.0, 60.0)
+
+
+def make_loud():
+    """Last link of enhance (universe.py:349-357): `x * (mix_rms / x_rms)` then `x / max|x|` where the peak exceeds 1."""
+    for name in ("PP16s", "OR16s", "PP24s"):
+        m, spec, sd = build(name)
+        B, T = 2, spec.tot_ds * 12 + 5
+        mix = synth_mix(spec, B, T) * torch.tensor(LOUD_GAINS)[:, None]
+        Tp = T + (spec.tot_ds - T % spec.tot_ds)
+        out = {"B": B, "T": T}
+        for tag, kw in {"keep_rms": dict(n_steps=3, keep_rms=True), "plain": dict(n_steps=3)}.items():
+            enh = enhance_with_noise(m, mix, noise_list(9, 3, B, Tp), **kw)
+            out["enh_" + tag] = enh.numpy()
+        pk = np.abs(out["enh_keep_rms"]).max(axis=-1)
+        assert pk[0] < 0.9 and abs(pk[1] - 1.0) < 1e-6, pk  # the guard divided row 1 and left row 0 alone
+        np.savez_compressed(os.path.join(HERE, f"loud_{name}.npz"), **out)
+        print("loud", name, "peaks keep_rms", pk, "plain", np.abs(out["enh_plain"]).max(axis=-1))
+
+
 def noise_list(seed, n, B, T):
     g = torch.Generator().manual_seed(seed)
     return [torch.randn(B, 1, T, generator=g) for _ in range(n)]
@@ -173,6 +196,8 @@ def main():
         make_stress()
     if "configs" in what:
         make_configs()
+    if "loud" in what:
+        make_loud()
     if "base" not in what:
         return
     # ---- key schema

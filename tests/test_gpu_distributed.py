@@ -196,6 +196,66 @@ def test_cli_batch_size_matches_file_by_file(tmp_path):
         record(f"cli.batched_vs_serial.f{i}", O.si_sdr(a.reshape(-1), b.reshape(-1)), 90)
 
 
+_NCCL_WS1 = r"""
+import os, sys, json
+import torch, torch.distributed as dist
+import yaml
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from helpers import get_spec, synth_mix
+from open_universe_amd import config as C, distributed as D, state_dict as S
+from open_universe_amd.inference_utils import load_model
+from open_universe_amd.inference_utils.model_loader import load_model_sharded
+tmp = sys.argv[2]
+spec = get_spec("PP16m")
+with open(os.path.join(tmp, "config.yaml"), "w") as f:
+    yaml.safe_dump(C.builtin_config("PP16", **{"score_model.n_channels": 16}), f)
+torch.save(S.checkpoint_from_state_dict(spec, S.synthetic_state_dict(spec, seed=0), ema_jitter=0.01), os.path.join(tmp, "weights.ckpt"))
+rank, local_rank, world = D.init(backend="nccl", force=True)     # ONE rank, RCCL communicator on cuda:0
+assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+device = D.local_device(local_rank)
+model = load_model_sharded(os.path.join(tmp, "weights.ckpt"), device=device)   # pack on rank 0 -> device-side dist.broadcast
+sigs = [synth_mix(spec, 1, L, seed=60 + i)[0] for i, L in enumerate([4100, 2900, 3555])]
+outs = D.enhance_sharded(model, sigs, seed=77, n_steps=3)          # gather_outputs at world 1
+rep = D.rccl_report(device)
+x = torch.ones(1 << 20, device=device)
+dist.all_reduce(x); dist.barrier(); torch.cuda.synchronize()       # the communicator really carries a collective
+assert float(x[0]) == 1.0
+single = load_model(os.path.join(tmp, "weights.ckpt"), device=device)
+ok = all(torch.equal(o.cpu(), single.enhance(s.to(device), n_steps=3, rng=D.utterance_generator(device, 77, i)).cpu())
+         for i, (o, s) in enumerate(zip(outs, sigs)))
+print("WS1_JSON " + json.dumps({"bit_equal": ok, "rccl": rep}))
+dist.destroy_process_group()
+"""
+
+
+def test_world_size_1_nccl_group_end_to_end(tmp_path):
+    """What a 1-GPU box CAN execute of the multi-GPU path: a world-size-1 `nccl` (= RCCL) process group -- communicator
+    set-up with the environment RCCL needs (HSA_ENABLE_IPC_MODE_LEGACY=0), `load_model_sharded` (rank 0 packs, the blob goes
+    through the DEVICE-side `dist.broadcast`), one `enhance_sharded`, an all-reduce and a barrier on the communicator --
+    bit-equal to `load_model` + `enhance` without a group."""
+    r = _run([sys.executable, "-c", _NCCL_WS1, ROOT, str(tmp_path)])
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("WS1_JSON ")][-1][len("WS1_JSON "):])
+    assert res["bit_equal"]
+    rep = res["rccl"]
+    assert rep["ranks"] == 1 and rep["backend"] == "nccl" and rep["distinct_device_uuids"] == 1
+    assert rep["per_rank"][0]["device"] == "cuda:0" and rep["ipc_mode_legacy"] == "0"
+
+
+def test_bench_force_nccl_line_carries_the_rccl_block():
+    """`bench.py --gpus 1 --force-nccl`: the headline loop under an initialised RCCL group of one rank; the JSON line carries
+    `rccl: {ranks, distinct_device_uuids, backend}` (what a SCALE record needs to prove N GPUs were seen) and the
+    explicit host-thread cap per rank."""
+    r = _run([sys.executable, "bench.py", "--gpus", "1", "--force-nccl", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+              "--profile-steps", "1", "--sustained-s", "0", "--in-flight", "", "--batch-sweep", ""])
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["config"]["backend"] == "nccl"
+    assert res["rccl"]["ranks"] == 1 and res["rccl"]["backend"] == "nccl" and res["rccl"]["distinct_device_uuids"] == 1
+    assert res["weight_broadcast"]["backend"] == "nccl" and res["weight_broadcast"]["identical_on_all_ranks"]
+    assert 1 <= res["host_threads_per_rank"] <= 8
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
 def test_bench_two_gpus_over_rccl():
     """The day-one multi-GPU run: `bench.py --gpus 2` on two real devices must take the nccl (= RCCL) branch, put every
@@ -207,6 +267,7 @@ def test_bench_two_gpus_over_rccl():
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert res["n_gpus"] == 2 and res["config"]["backend"] == "nccl"
     assert res["config"]["devices"] == ["rank0:cuda:0", "rank1:cuda:1"]
+    assert res["rccl"]["ranks"] == 2 and res["rccl"]["distinct_device_uuids"] == 2 and res["rccl"]["backend"] == "nccl"
     wb = res["weight_broadcast"]
     assert wb["backend"] == "nccl" and wb["identical_on_all_ranks"] and wb["GBs"] > 1.0
     assert len(res["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in res["per_rank_ms_per_step"])

@@ -214,3 +214,74 @@ def test_set_lanes_argument_checks_and_batched_lanes():
     flying = D.enhance_sharded(model, sigs, seed=4, n_steps=3, batch_size=4, in_flight=4)
     for a, b in zip(serial, flying):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("lanes", [4, 8])
+def test_lanes_with_groups_of_different_batch_sizes_full_size(lanes):
+    """Round-4 advisor finding: `enhance_sharded(batch_size > 1, in_flight > 1)` on a ragged set puts calls of DIFFERENT batch
+    sizes in flight; shares and placement of the GRU clusters used to follow each call's own B, so on the full-size model
+    (H = 256: two 8-unit clusters fill an XCD) lanes at B = 1 / 2 / 4 over-subscribed XCDs and a cluster waited for members
+    that could not be scheduled -- a spurious device-side time-out.  The pool now tells every handle its largest batch size
+    (ou_set_lane_batch).  Groups of 1, 2 and 4 at 4 and 8 lanes: no time-out, nothing lost, every utterance equal to the
+    serial loop's to fp32 rounding (a call smaller than the pool's largest may take 16 hidden units per workgroup where the
+    single call takes 8) and bit-identical from run to run."""
+    from open_universe_amd import distributed as D
+
+    model, spec, sd = get_model("PP16")
+    lens = [32000] * 4 + [24000] * 2 + [28000] + [20000] * 4 + [16000] * 2 + [12000] + [36000] * 4 + [8000] * 2 + [10000]
+    sigs = [synth_mix(spec, 1, n, seed=700 + i)[0] for i, n in enumerate(lens)]
+    groups = D.plan_batches([int(s.shape[-1]) for s in sigs], list(range(len(sigs))), 4)
+    assert sorted({len(g) for g in groups}) == [1, 2, 4]
+    serial = D.enhance_sharded(model, sigs, seed=6, n_steps=2, batch_size=4)
+    flying = D.enhance_sharded(model, sigs, seed=6, n_steps=2, batch_size=4, in_flight=lanes)   # raises on a time-out
+    again = D.enhance_sharded(model, sigs, seed=6, n_steps=2, batch_size=4, in_flight=lanes)
+    st = model.gru_exchange_stats()
+    assert st["lost"] == 0, st
+    from helpers import worst
+
+    record(f"lanes.mixed_batch.PP16.k{lanes}", worst(O.si_sdr(a, b) for a, b in zip(serial, flying)), 100)
+    assert all(torch.equal(b, c) for b, c in zip(flying, again))
+    solo = D.enhance_sharded(model, sigs[:3], seed=6, n_steps=2)  # back in single-lane mode
+    assert len(solo) == 3 and model._lanes == (1, 0)
+
+
+def test_graph_replay_survives_a_longer_eager_call_of_the_same_batch_size():
+    """Round-4 advisor finding: workspaces are cached per batch size and regrown for a longer signal -- which used to release
+    the buffer a captured graph's launches point into.  The graph now owns its workspace."""
+    model, spec, sd = get_model("PP16m")
+    n = 3000
+    run = model.graphed_enhance(1, n, n_steps=2)
+    x = synth_mix(spec, 1, n)[0].cuda()
+    g = lambda: torch.Generator(device="cuda").manual_seed(12)  # noqa: E731
+    y0 = run(x, rng=g())
+    eager0 = model.enhance(x, n_steps=2, rng=g())
+    long = model.enhance(synth_mix(spec, 1, 4 * n)[0].cuda(), n_steps=2, rng=g())  # same B, longer T: the cache regrows
+    y1 = run(x, rng=g())                                                            # ... and the replay is unaffected
+    assert torch.equal(y0, y1) and long.shape == (4 * n,)
+    assert torch.equal(model.enhance(x, n_steps=2, rng=g()), eager0)
+    model.reset_workspace()
+    assert torch.equal(run(x, rng=g()), y0)  # even a cache reset leaves the graph's own buffer alone
+
+
+def test_pool_close_waits_for_work_enqueued_by_a_call_that_raised():
+    """Round-4 advisor finding: a callable that raised after enqueueing work left its lane marked idle, and close() handed the
+    models back while kernels were still running."""
+    from open_universe_amd.lanes import LanePool
+
+    model, spec, sd = get_model("PP16m")
+    x = synth_mix(spec, 1, 4000)[0].cuda()
+    ref = model.enhance(x, n_steps=2, rng=torch.Generator(device="cuda").manual_seed(1))
+    pool = LanePool(model, 2)
+
+    def bad(m):
+        m.enhance(x, n_steps=2, rng=torch.Generator(device="cuda").manual_seed(1))
+        raise KeyError("after the enqueue")
+
+    with pytest.raises(KeyError):
+        pool.submit(bad)
+    assert pool._busy[0]
+    pool.close()
+    assert model._lanes == (1, 0)
+    assert torch.equal(model.enhance(x, n_steps=2, rng=torch.Generator(device="cuda").manual_seed(1)), ref)
+    model.release_lanes()
+    assert "_lane_forks" not in model.__dict__

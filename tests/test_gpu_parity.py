@@ -123,6 +123,28 @@ def test_enhance_vs_reference_goldens(name):
         record(f"gold.{name}.{tag}", O.si_sdr(ref, out))
 
 
+@pytest.mark.parametrize("name", ["PP16s", "OR16s", "PP24s"])
+def test_peak_guard_and_rms_restore_vs_reference_goldens(name):
+    """post_reg_kernel where the peak guard DIVIDES (universe.py:349-357): row 1 of the batch is 60 x louder than row 0, so with
+    keep_rms the restore puts it far above full scale and the guard fires on that row only (asserted on the reference's
+    output).  Per row, against the REAL reference's output, SI-SDR and plain SNR (record() gates both: a gain error in this
+    link is invisible to a scale-invariant figure)."""
+    gold = np.load(os.path.join(G, f"loud_{name}.npz"))
+    model, spec, sd = get_model(name)
+    B, T = int(gold["B"]), int(gold["T"])
+    mix = synth_mix(spec, B, T) * torch.tensor([1.0, 60.0])[:, None]
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    for tag, kw in {"keep_rms": dict(n_steps=3, keep_rms=True), "plain": dict(n_steps=3)}.items():
+        out = run_enhance(model, mix, noise_list(9, 3, B, Tp), **kw)
+        ref = torch.from_numpy(gold["enh_" + tag])
+        assert out.shape == ref.shape
+        for b in range(B):
+            record(f"loud.{name}.{tag}.row{b}", O.si_sdr(ref[b], out[b]))
+    ref = torch.from_numpy(gold["enh_keep_rms"])
+    assert float(ref[1].abs().max()) == pytest.approx(1.0, abs=1e-6) and float(ref[0].abs().max()) < 0.9
+    assert float(out.abs().max()) <= 1.0 + 1e-6
+
+
 def test_full_size_headline_config_vs_reference_golden():
     """UNIVERSE++ 16 kHz, 4 s, 8 steps, B=1 (BASELINE.json configs[1]) against the reference's own output."""
     gold = np.load(os.path.join(G, "full_PP16.npz"))

@@ -175,3 +175,36 @@ def test_checkpoint_reader_executes_nothing(tmp_path):
     assert set(data["state_dict"]) == set(sd) and all(torch.equal(data["state_dict"][k], sd[k]) for k in sd)
     torch.save({"state_dict": sd, "epoch": 3}, tmp_path / "plain.ckpt")
     assert ML.read_checkpoint(tmp_path / "plain.ckpt")["epoch"] == 3
+
+
+@pytest.mark.parametrize("spec_str, repo, revision", [("line-corporation/open-universe:plusplus", "line-corporation/open-universe", "plusplus"),
+                                                       ("line-corporation/open-universe", "line-corporation/open-universe", None)])
+def test_hub_id_is_split_and_both_files_are_fetched(tmp_path, monkeypatch, spec_str, repo, revision):
+    """model_loader.py:81-110 of the reference: a path that is not a local file is a Huggingface id `repo[:revision]`;
+    `weights.ckpt` and `config.yaml` are fetched with the same repo / revision / token.  The hub itself is unreachable here:
+    `hf_hub_download` is replaced by a recorder that serves local files."""
+    import huggingface_hub
+
+    from open_universe_amd.inference_utils import model_loader as ML
+
+    served = {"weights.ckpt": tmp_path / "w.ckpt", "config.yaml": tmp_path / "c.yaml"}
+    served["weights.ckpt"].write_bytes(b"")
+    served["config.yaml"].write_text("model: {}\n")
+    calls = []
+
+    def fake(repo_id, filename, revision=None, token=None, **kw):
+        calls.append(dict(repo_id=repo_id, filename=filename, revision=revision, token=token))
+        return str(served[filename])
+
+    monkeypatch.setattr(huggingface_hub, "hf_hub_download", fake)
+    ckpt, cfg = ML._resolve(spec_str, hf_token="tok")
+    assert (ckpt, cfg) == (str(served["weights.ckpt"]), str(served["config.yaml"]))
+    assert calls == [dict(repo_id=repo, filename="weights.ckpt", revision=revision, token="tok"),
+                     dict(repo_id=repo, filename="config.yaml", revision=revision, token="tok")]
+
+    def down(**kw):
+        raise OSError("no network")
+
+    monkeypatch.setattr(huggingface_hub, "hf_hub_download", down)
+    with pytest.raises(OSError):  # the reference prints a hint and re-raises (model_loader.py:103-107)
+        ML._resolve("nobody/nothing:rev", None)

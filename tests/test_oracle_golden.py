@@ -63,6 +63,38 @@ def test_oracle_networks_and_enhance_vs_reference(name):
         assert O.si_sdr(ref, out) > 90, (tag, O.si_sdr(ref, out))
 
 
+LOUD_GAINS = (1.0, 60.0)  # tests/golden/make_golden.py::make_loud
+
+
+@pytest.mark.parametrize("name", ["PP16s", "OR16s", "PP24s"])
+def test_oracle_peak_guard_and_rms_restore_vs_reference(name):
+    """Last link of enhance (universe.py:349-357) where the peak guard DIVIDES: row 1 is 60 x louder than row 0, so with
+    keep_rms the RMS restore puts it far above full scale.  Held to SI-SDR and to the plain, scale-sensitive SNR -- a gain
+    error in that link is invisible to SI-SDR."""
+    gold = np.load(os.path.join(G, f"loud_{name}.npz"))
+    spec = get_spec(name)
+    sd = S.synthetic_state_dict(spec, seed=0)
+    B, T = int(gold["B"]), int(gold["T"])
+    mix = synth_mix(spec, B, T) * torch.tensor(LOUD_GAINS)[:, None]
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    for tag, kw in {"keep_rms": dict(n_steps=3, keep_rms=True), "plain": dict(n_steps=3)}.items():
+        out = O.enhance(sd, spec.to_dict(), mix, noise=noise_list(9, 3, B, Tp), **kw)
+        ref = torch.from_numpy(gold["enh_" + tag])
+        for b in range(B):
+            f = O.si_sdr(ref[b], out[b])
+            assert f > 90 and f.snr > 90, (tag, b, float(f), f.snr, f.gain)
+    ref = torch.from_numpy(gold["enh_keep_rms"])
+    assert float(ref[1].abs().max()) == pytest.approx(1.0, abs=1e-6) and float(ref[0].abs().max()) < 0.9
+
+
+def test_parity_figure_sees_a_gain_error():
+    """SI-SDR projects a common gain away; the plain SNR carried by the same figure does not."""
+    g = torch.Generator().manual_seed(0)
+    ref = torch.randn(2, 1000, generator=g)
+    f = O.si_sdr(ref, 1.01 * ref)
+    assert f > 120 and 39.9 < f.snr < 40.1 and abs(f.gain - 1.01) < 1e-6
+
+
 def test_gru_explicit_recurrence_matches_aten():
     spec = get_spec("PP16s")
     sd = S.synthetic_state_dict(spec, seed=2)
