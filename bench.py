@@ -598,7 +598,7 @@ def main():
         model.profile(False)
         # records: (ms, algorithmic flops, algorithmic bytes, variant); variant < 40: conv_mfma_kernel tile configs,
         # 40-49: rate_down_kernel,
-        # 66 / 76: conv_direct2_kernel, other 50-99: conv_direct_kernel / conv_direct_strided_kernel variants,
+        # 66 / 76 / 67 / 77: conv_direct2_kernel, 78 / 79: conv_direct2w_kernel, other 50-99: conv_direct_kernel / conv_direct_strided_kernel variants,
         # 100-199: conv_chain_kernel (fused ConvBlock body), 200-299: conv_direct3_kernel (2xx: 200 + 10 TM + KW) /
         # conv_direct3s_kernel (260 + R), 300-399: conv_direct4_kernel (300 + 10 TM + log2 WK), >= 1000: one GRU pass
         # (1000 + steps).
@@ -617,7 +617,8 @@ def main():
                     "tflops": fl_ / (ms_ * 1e-3) / 1e12, "gbs": by_ / (ms_ * 1e-3) / 1e9,
                     "algorithmic_bytes_per_launch": by_ / len(rr)}
         KERNELS = {
-            "direct2": "ou::conv_direct2_kernel (register-direct split-K fp32-MFMA Conv1d, wide operand loads: k3 / k5 layers)",
+            "direct2": "ou::conv_direct2_kernel / conv_direct2w_kernel (register-direct split-K fp32-MFMA Conv1d, wide operand loads: "
+                       "k3 / k5 layers; the w form with minimal filtering F(2, 3) / F(2, 5) on 64-column tiles)",
             "direct": "ou::conv_direct_kernel / conv_direct_strided_kernel (first-generation register-direct split-K, dword "
                       "operand loads: 1x1, phase-GEMM and rate-change convs of the 401-frame levels at batch 1 - 2)",
             "direct4": "ou::conv_direct4_kernel (wide-load split-K: 1x1, phase-GEMM and rate-change convs; 16x16x4 fp32 MFMA, "
@@ -628,15 +629,16 @@ def main():
             "direct3": "ou::conv_direct3_kernel / conv_direct3s_kernel (no-split-K throughput kernels: one (16 TM) x 64 tile per "
                        "wave over the whole reduction, 16x16x4 fp32 MFMA, register-direct operands, stores from the accumulators)",
         }
-        groups = {"direct2": summarise([r for r in recs if r[3] in (66, 76)]),
-                  "direct": summarise([r for r in recs if 50 <= r[3] < 100 and r[3] not in (66, 76)]),
+        D2 = (66, 76, 67, 77, 78, 79)  # conv_direct2_kernel (8 / 4 K slices) and its minimal-filtering form conv_direct2w_kernel
+        groups = {"direct2": summarise([r for r in recs if r[3] in D2]),
+                  "direct": summarise([r for r in recs if 50 <= r[3] < 100 and r[3] not in D2]),
                   "lds": summarise([r for r in recs if r[3] < 40]),
                   "rate": summarise([r for r in recs if 40 <= r[3] < 50]),
                   "chain": summarise([r for r in recs if 100 <= r[3] < 200]),
                   "direct3": summarise([r for r in recs if 200 <= r[3] < 300]),
                   "direct4": summarise([r for r in recs if 300 <= r[3] < 400])}
         groups = {k: v for k, v in groups.items() if v}
-        fam = summarise([r for r in recs if (50 <= r[3] < 100 and r[3] not in (66, 76)) or 300 <= r[3] < 400 or 260 <= r[3] < 270])
+        fam = summarise([r for r in recs if (50 <= r[3] < 100 and r[3] not in D2) or 300 <= r[3] < 400 or 260 <= r[3] < 270])
         dom = max(groups, key=lambda k: groups[k]["ms_per_enhance"])  # the dominant kernel = most time per enhance
         gen = groups[dom]
         allconv = summarise(list(recs))

@@ -107,7 +107,7 @@ struct Tensor {
 // Tuning / debug switches, read ONCE per C-ABI call: a forward walks ~400 launches and used to call getenv
 // eight times for each of them (a linear scan of the environment: a third of the host time of an enhance call).
 struct EnvCfg {
-  int dbg = 0, xcd_map = -1, conv_direct = 4, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1, d4_force = 0, d4_short = 1;
+  int dbg = 0, xcd_map = -1, conv_direct = 5, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1, d4_force = 0, d4_short = 1, d2_wk = 0, wino = 1, d2_map = -1;
   int gru_v = 2, gru_bmax = 0, gru_ts = 0, gru_upw = 0, gru_backoff = 0, gru_agent = -1, gru_dbg = 0;
   int dbg_dec0_under_gru = 0;  // OU_DBG_DEC0: measurement only, INVALID results (see run_score)
   double tile_min = -1.0;  // < 0: the launcher's default
@@ -115,12 +115,15 @@ struct EnvCfg {
   std::string chain_ts;
   static int geti(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
   EnvCfg() {
-    dbg = geti("OU_DBG", 0); xcd_map = geti("OU_XCD_MAP", -1); conv_direct = geti("OU_CONV_DIRECT", 4);
+    dbg = geti("OU_DBG", 0); xcd_map = geti("OU_XCD_MAP", -1); conv_direct = geti("OU_CONV_DIRECT", 5);
     fuse = geti("OU_FUSE", -1); fuse_nc = geti("OU_FUSE_NC", 0); rate_small = geti("OU_RATE_SMALL", 1);
     fuse_upfir = geti("OU_FUSE_UPFIR", 1);
     d4_fir = geti("OU_D4_FIR", 1);
     d4_force = geti("OU_D4_FORCE", 0);
     d4_short = geti("OU_D4_SHORT", 1);
+    d2_wk = geti("OU_D2_WK", 0);
+    wino = geti("OU_WINO", 1);
+    d2_map = geti("OU_D2_MAP", -1);
     block3 = geti("OU_BLOCK3", 0);
     gru_v = geti("OU_GRU_V", 2); gru_bmax = geti("OU_GRU_BMAX", 0); gru_ts = std::getenv("OU_GRU_TS") ? 1 : 0;
     gru_upw = geti("OU_GRU_UPW", 0); gru_backoff = geti("OU_GRU_BACKOFF", 0); gru_agent = geti("OU_GRU_AGENT_STORES", -1);
@@ -241,7 +244,7 @@ struct Runner {
     if (dry || !ok()) return out;
     ConvArgs a;
     a.x = in.p; a.w = W(L.w_off); a.bias = W(L.b_off); a.y = out.p;
-    if (L.KWP) a.wd = W(L.wd_off);
+    if (L.KWP) { a.wd = W(L.wd_off); a.wu = W(L.wu_off); }
     a.in_scale = e.in_scale;
     a.act = (L.act && e.act) ? 1 : 0;
     a.alpha_val = a.act ? h->alphas[L.a_off] : 0.f;
@@ -253,7 +256,7 @@ struct Runner {
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
     a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
-    a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct; a.d4_fir_unfused = env.d4_fir; a.d4_force = env.d4_force; a.d4_short = env.d4_short;
+    a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct; a.d4_fir_unfused = env.d4_fir; a.d4_force = env.d4_force; a.d4_short = env.d4_short; a.d2_wk = env.d2_wk; a.wino = env.wino; a.d2_map = env.d2_map;
     a.tile_min = env.tile_min; a.tile_prefetch = env.tile_prefetch;
     a.tstamps = h->tstamps;
     if (collect) { collect->push_back(a); return out; }

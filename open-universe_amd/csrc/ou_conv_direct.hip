@@ -346,6 +346,105 @@ __global__ __launch_bounds__(512) void conv_direct_kernel(ConvArgs p) {
   if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
+// Epilogue of conv_direct2_kernel (stride 1, up == 1, no fused FIR): the accumulators of the WK K-slice waves -> LDS -> reduced
+// on read -> bias, cond add, FiLM, residual -> 16-byte stores.  Each thread owns QPT quads of four consecutive samples of one
+// output row.  Its global operands (cond add, residual, bias, FiLM row) are fetched by `issue()` BEFORE THE DRAIN of the
+// operand ring -- the last D slots of MFMAs, about one memory latency long, during which no ring load is issued any more --
+// with inline-asm buffer loads that join the ring's in-order vmcnt accounting (NLOAD more loads outstanding behind every ring
+// slot still in flight).  The first generation fetched them after the main loop and paid one exposed L2 / Infinity-Cache
+// round trip per launch; fetching them before the main loop kept 11-36 registers live across it and cost occupancy (see
+// DirectEpilogue).  Here their registers are live across the drain only: the allocator takes them from what the main loop's
+// address arithmetic has freed.  Absent operands use a zero-length descriptor (reads as 0, no memory access); quads that cross
+// the end of a row read the neighbouring row's samples into elements that are never used.
+template <int TN, int WK>
+struct Direct2Epilogue {
+  static constexpr int NT = 64 * WK, BM = 32, BN = 32 * TN, EP = BN + 4, C4 = BN / 4, NQ = BM * C4;
+  static constexpr int QPT = (NQ + NT - 1) / NT;  // quads per thread: 1 (half the threads idle at TN = 1, WK = 8) or 2
+  static constexpr int NLOAD = 5 * QPT;           // buffer loads issue() puts in flight
+  struct Pre {
+    f32x4 ad[QPT], rs[QPT];
+    float bi[QPT], ga[QPT], be[QPT];
+  };
+  static __device__ __forceinline__ void issue(const ConvArgs& p, Pre& q, int tid, int b, int m0, int n0) {
+    const unsigned ybytes = (unsigned)p.Cout * (unsigned)p.Tout * 4u;
+    const size_t ybase = (size_t)b * p.Cout * p.Tout;
+    const u32x4 ra = direct_desc(p.add ? p.add + ybase : p.y, p.add ? ybytes : 0u);
+    const u32x4 rr = direct_desc(p.res ? p.res + ybase : p.y, p.res ? ybytes : 0u);
+    const u32x4 rb = direct_desc(p.bias, (unsigned)p.Cout * 4u);
+    const u32x4 rf = direct_desc(p.film ? p.film + (size_t)b * p.film_bstride : p.bias, p.film ? 2u * (unsigned)p.Cout * 4u : 0u);
+#pragma unroll
+    for (int j = 0; j < QPT; j++) {
+      const int i = tid + j * NT, er = i / C4, eq = (i % C4) * 4, m = m0 + er;
+      const bool on = i < NQ && m < p.M && n0 + eq < p.Nq;
+      const int vo = on ? (m * p.Tout + n0 + eq) * 4 : (int)0x80000000;
+      const int vb = on ? m * 4 : (int)0x80000000;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(q.ad[j]) : "v"(vo), "s"(ra));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(q.rs[j]) : "v"(vo), "s"(rr));
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(q.bi[j]) : "v"(vb), "s"(rb));
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(q.ga[j]) : "v"(vb), "s"(rf));
+      asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(q.be[j]) : "v"(vb), "s"(rf), "s"(p.Cout * 4));
+    }
+  }
+  // [c_lo, c_hi): output columns this tile may STORE (the fused ConvBlock kernel computes halo columns that belong to a
+  // neighbouring tile group)
+  static __device__ __forceinline__ void run(const ConvArgs& p, const floatx16 (&acc)[TN], Pre& q, float* Es, int tid, int kw,
+                                             int b, int m0, int n0, int c_lo, int c_hi) {
+    const int lane = tid & 63, lhalf = lane >> 5, l31 = lane & 31;
+    if constexpr (TN == 2) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+        *reinterpret_cast<f32x2*>(&Es[(kw * BM + row) * EP + 2 * l31]) = f32x2{acc[0][r], acc[1][r]};
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+        Es[(kw * BM + row) * EP + l31] = acc[0][r];
+      }
+    }
+    // the prefetched operands have landed long ago (they were issued before the drain); the registers are valid only past
+    // this wait and the empty asm statements that follow it
+    asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+    for (int j = 0; j < QPT; j++) {
+      asm volatile("" : "+v"(q.ad[j]));
+      asm volatile("" : "+v"(q.rs[j]));
+      asm volatile("" : "+v"(q.bi[j]));
+      asm volatile("" : "+v"(q.ga[j]));
+      asm volatile("" : "+v"(q.be[j]));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const size_t ybase = (size_t)b * p.Cout * p.Tout;
+    const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < QPT; j++) {
+      const int i = tid + j * NT, er = i / C4, eq = (i % C4) * 4, m = m0 + er;
+      if (!(i < NQ && m < p.M && n0 + eq < p.Nq && n0 + eq + 4 > c_lo && n0 + eq < c_hi)) continue;
+      const size_t eidx = ybase + (size_t)m * p.Tout + n0 + eq;
+      int e_n = p.Nq - (n0 + eq);
+      if (e_n > 4) e_n = 4;
+      if (e_n > c_hi - (n0 + eq)) e_n = c_hi - (n0 + eq);
+      const int e_0 = c_lo - (n0 + eq) > 0 ? c_lo - (n0 + eq) : 0;  // first element of the quad inside the store range
+      f32x4 v = *reinterpret_cast<const f32x4*>(&Es[er * EP + eq]);
+#pragma unroll
+      for (int kk = 1; kk < WK; kk++) v += *reinterpret_cast<const f32x4*>(&Es[(kk * BM + er) * EP + eq]);
+      if (p.in_scale) v *= insc;
+      v += q.bi[j];
+      if (p.add) v = (v + q.ad[j]) * p.add_scale;
+      if (p.film) v = q.ga[j] * v + q.be[j];
+      if (p.res) v = (v + q.rs[j]) * p.res_scale;
+      if (e_0 == 0 && e_n == 4) {  // 16-byte store at dword alignment (the 401- / 2005-frame levels too)
+        *reinterpret_cast<f32x4u*>(p.y + eidx) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (e >= e_0 && e < e_n) p.y[eidx + e] = v[e];
+      }
+    }
+  }
+};
+
 // One ring slot of conv_direct2_kernel after its wait: window -> (edge fix-up) -> PReLU -> KW x TN MFMAs.
 template <int KW, int TN>
 __device__ __forceinline__ void direct2_mma(const f32x4& a4, float a1, const f32x4& b4, float b1, const f32x2& b2,
@@ -374,6 +473,53 @@ __device__ __forceinline__ void direct2_mma(const f32x4& a4, float a1, const f32
     for (int q = 0; q < TN; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k], X[q + k], acc[q], 0, 0, 0);
 }
 
+// One ring slot of conv_direct2w_kernel after its wait: window -> (edge fix-up) -> PReLU -> B^T -> KW + 1 MFMAs on independent
+// accumulators.  B^T of F(2, 3): points 0, 1, -1, inf; of F(2, 5): points 0, 1, -1, 1/2, -2, inf, rows scaled to small integers
+// (the scale is in G, ou_model.cpp; tests/test_packing.py holds U, B^T and A^T against the convolution they must reproduce).
+template <int KW>
+__device__ __forceinline__ void direct2w_mma(const f32x4& a4, const f32x2& a2, const f32x4& b4, const f32x2& b2,
+                                             floatx16 (&acc)[KW + 1], float alpha, bool edge, int sh, unsigned vmask) {
+  constexpr int W = KW + 1, PAD = (KW - 1) / 2;
+  const float L[6] = {b4.x, b4.y, b4.z, b4.w, b2.x, b2.y};
+  float X[W];
+  if (edge) {  // block-uniform: first / last column tiles only
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+      float v = L[i];  // sh == 0
+#pragma unroll
+      for (int s = 1; s <= PAD; s++) v = sh == s ? (i - s >= 0 ? L[i - s >= 0 ? i - s : 0] : 0.f) : v;
+      X[i] = ((vmask >> i) & 1u) ? v : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < W; i++) X[i] = L[i];
+  }
+#pragma unroll
+  for (int i = 0; i < W; i++) X[i] = X[i] >= 0.f ? X[i] : alpha * X[i];
+  float V[W];
+  if constexpr (KW == 3) {
+    V[0] = X[0] - X[2];
+    V[1] = X[1] + X[2];
+    V[2] = X[2] - X[1];
+    V[3] = X[1] - X[3];
+  } else {
+    // rows of B^T: [2 -3 -4 3 2 0] [0 -2 1 5 2 0] [0 -2 5 -1 -2 0] [0 2 1 -2 -1 0] [0 1 -2 -1 2 0] [0 2 -3 -4 3 2]
+    const float p13 = X[1] - X[3], p24 = X[2] - X[4];
+    V[3] = fmaf(2.f, p13, p24);
+    V[4] = fmaf(-2.f, p24, p13);
+    const float q = X[4] - X[1];                       // V1 = 2 q + X2 + 5 X3 ; V2 = -2 q + 5 X2 - X3 - 4 X4 ... keep it plain:
+    V[1] = fmaf(5.f, X[3], fmaf(2.f, q, X[2]));
+    V[2] = fmaf(5.f, X[2], fmaf(-2.f, X[1] + X[4], -X[3]));
+    const float s04 = X[0] + X[4], d31 = X[3] - X[1];  // V0 = 2 (X0 + X4) + 3 (X3 - X1) - 4 X2
+    V[0] = fmaf(-4.f, X[2], fmaf(3.f, d31, 2.f * s04));
+    const float s15 = X[1] + X[5], d42 = X[4] - X[2];  // V5 = 2 (X1 + X5) + 3 (X4 - X2) - 4 X3
+    V[5] = fmaf(-4.f, X[3], fmaf(3.f, d42, 2.f * s15));
+  }
+  const float A[6] = {a4.x, a4.y, a4.z, a4.w, a2.x, a2.y};
+#pragma unroll
+  for (int x = 0; x < W; x++) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[x], V[x], acc[x], 0, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // conv_direct2_kernel: the stride-1 k3 / k5 direct kernel with WIDE operand loads.
 // The first direct kernel is bound by vector-memory instruction issue, not by MFMA or bytes: a CU retires one
@@ -395,14 +541,16 @@ __device__ __forceinline__ void direct2_mma(const f32x4& a4, float a1, const f32
 // ---------------------------------------------------------------------------------------------------------
 // (the tile body is a device function: conv_direct2_kernel runs it once per block, conv_block3_kernel three times with a
 // group barrier in between; [c_lo, c_hi) = columns the tile may store)
-template <int KW, int TN>
+template <int KW, int TN, int WK = 8>
 __device__ __forceinline__ void direct2_tile(const ConvArgs& p, float* smem, int b, int m0, int n0, int c_lo, int c_hi) {
   constexpr int D = 4, W = KW + TN - 1, KWP = KW == 3 ? 4 : 8, PAD = (KW - 1) / 2;
   constexpr int B2 = W - 4;                    // elements in the second B load: 0 (none), 1 (dword), 2 (dwordx2)
   constexpr int A2 = KW - 4 > 0 ? KW - 4 : 0;  // elements in the second A load: 0 / 1
   constexpr int LPS = 1 + (A2 ? 1 : 0) + 1 + (B2 > 0 ? 1 : 0);  // load instructions per ring slot (= channel pair)
+  using Epi = Direct2Epilogue<TN, WK>;
+  constexpr int NE = Epi::NLOAD;               // epilogue operand loads that join the queue before the drain
   static_assert(KW == 3 || KW == 5, "k3 / k5");
-  static_assert(B2 >= -1 && B2 <= 2 && D * LPS <= 60, "window / vmcnt");
+  static_assert(B2 >= -1 && B2 <= 2 && D * LPS + NE <= 60, "window / vmcnt");
   constexpr int BN = 32 * TN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int kw = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -421,7 +569,7 @@ __device__ __forceinline__ void direct2_tile(const ConvArgs& p, float* smem, int
 #pragma unroll
   for (int i = 0; i < W; i++) vmask |= (t0 + i >= 0 && t0 + i < Tin) ? (1u << i) : 0u;
 
-  const int NG = p.Cin >> 4;  // channel pairs per wave (launcher: a multiple of D)
+  const int NG = p.Cin / (2 * WK);  // channel pairs per wave (launcher: a multiple of D)
   f32x4 a4[D], b4[D];
   float a1[D];   // k5: tap 4
   float b1[D];   // window element 4 (5-element windows)
@@ -439,7 +587,7 @@ __device__ __forceinline__ void direct2_tile(const ConvArgs& p, float* smem, int
 
 #define OU_ISSUE(g_, d)                                                                                              \
   {                                                                                                                  \
-    const int ci = 2 * (kw + 8 * (g_));                                                                              \
+    const int ci = 2 * (kw + WK * (g_));                                                                             \
     const int aso = ci * Mp * KWP * 4, xso = ci * Tin * 4;                                                           \
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(a4[d]) : "v"(avo), "s"(rw), "s"(aso));            \
     if constexpr (A2 == 1)                                                                                           \
@@ -450,9 +598,10 @@ __device__ __forceinline__ void direct2_tile(const ConvArgs& p, float* smem, int
     if constexpr (B2 == 2)                                                                                           \
       asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:16" : "+v"(b2[d]) : "v"(bvo), "s"(rx), "s"(xso)); \
   }
+// `out`: loads issued after this slot's that may still be in flight (whole ring slots x LPS, plus the epilogue operands)
 #define OU_MMA(d, out)                                                                                               \
   {                                                                                                                  \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS));                                                          \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(out));                                                                  \
     asm volatile("" : "+v"(a4[d]));                                                                                  \
     asm volatile("" : "+v"(b4[d]));                                                                                  \
     if constexpr (A2 == 1) asm volatile("" : "+v"(a1[d]));                                                           \
@@ -468,19 +617,21 @@ __device__ __forceinline__ void direct2_tile(const ConvArgs& p, float* smem, int
   const int NR = NG / D;
   for (int r = 0; r + 1 < NR; r++) {
     const int g = r * D;
-    OU_MMA(0, 3);
+    OU_MMA(0, 3 * LPS);
     if (ts_on && r == 0) c2 = __builtin_readcyclecounter();
     OU_ISSUE(g + 4, 0);
-    OU_MMA(1, 3); OU_ISSUE(g + 5, 1);
-    OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
-    OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
+    OU_MMA(1, 3 * LPS); OU_ISSUE(g + 5, 1);
+    OU_MMA(2, 3 * LPS); OU_ISSUE(g + 6, 2);
+    OU_MMA(3, 3 * LPS); OU_ISSUE(g + 7, 3);
   }
   if (ts_on) c3 = __builtin_readcyclecounter();
-  OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
+  typename Epi::Pre pre;
+  Epi::issue(p, pre, tid, b, m0, n0);  // the epilogue's global operands travel under the drain
+  OU_MMA(0, 3 * LPS + NE); OU_MMA(1, 2 * LPS + NE); OU_MMA(2, LPS + NE); OU_MMA(3, NE);
   if (ts_on) c4 = __builtin_readcyclecounter();
 #undef OU_ISSUE
 #undef OU_MMA
-  DirectEpilogue<TN, true>::run(p, acc, smem, tid, kw, b, m0, n0, c_lo, c_hi);
+  Epi::run(p, acc, pre, smem, tid, kw, b, m0, n0, c_lo, c_hi);
   if (ts_on && lane == 0) {
     const long long c5 = __builtin_readcyclecounter();
     long long* o = p.tstamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + kw) * 8;
@@ -488,13 +639,132 @@ __device__ __forceinline__ void direct2_tile(const ConvArgs& p, float* smem, int
     o[6] = 0; o[7] = (long long)__builtin_amdgcn_s_memrealtime();
   }
 }
-template <int KW, int TN>
-__global__ __launch_bounds__(512) void conv_direct2_kernel(ConvArgs p) {
+// WK = 8: 512 threads, the reduction split over eight waves (round 2).  WK = 4 (round 5): 256 threads, four K slices -- twice
+// the K loop per wave for the same prologue and drain, half the LDS read traffic of the cross-wave reduction, one wave per
+// SIMD and block (the waves of a block advance together: no barrier skew between two waves that share a matrix pipe), and
+// twice as many blocks on a CU whose epilogues and prologues no longer coincide.
+template <int KW, int TN, int WK>
+__global__ __launch_bounds__(64 * WK) void conv_direct2_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int tile_m, tile_n;
   if (!direct_tile(p, tile_m, tile_n)) return;
   if (p.prof && threadIdx.x == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
-  direct2_tile<KW, TN>(p, smem, blockIdx.z, tile_m * 32, tile_n * 32 * TN, 0, 0x7fffffff);
+  direct2_tile<KW, TN, WK>(p, smem, blockIdx.z, tile_m * 32, tile_n * 32 * TN, 0, 0x7fffffff);
+  if (p.prof && threadIdx.x == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_direct2w_kernel: conv_direct2_kernel with MINIMAL FILTERING (Winograd / Cook-Toom F(2, KW)) -- round 5.
+// The split-K direct kernels are bound by the fp32 matrix pipe wherever their loop runs (85-93 % of its rate), and exact
+// fp32 has no faster MFMA: what is left is to issue fewer of them.  F(2, KW) computes the two adjacent outputs of a tile
+// position from KW + 1 products instead of 2 KW:
+//     y[2p + j] = sum_x AT[j][x] * ( sum_ci U_x[co][ci] * V_x[ci][p] ),   U = G w (packer, in double),  V = B^T d (here)
+// i.e. KW + 1 GEMMs [M x Cin] x [Cin x T/2] instead of KW of [M x Cin] x [Cin x T]: 4 instead of 6 MFMAs per channel pair and
+// 32 x 64 output tile for k3, 6 instead of 10 for k5.  Everything else is conv_direct2_kernel's: lane (n, half) already
+// loads the KW + 1 consecutive samples d[2 n - PAD ..] of row 2 I + half that its two adjacent output columns need (ONE
+// 16-byte load [+ 8 bytes]), lane (m, half) the KW + 1 values U_x of (row m, channel 2 I + half) with one 16-byte load [+ 8]
+// from the third weight copy -- k3: the same bytes as before (the fourth float of the slot is no longer padding), k5: 24
+// instead of 20 -- the ring, the counted waits, the prefetched epilogue operands.  PReLU is applied to the samples, then
+// B^T (4 VALU operations for k3, ~20 for k5: small integers only), KW + 1 independent accumulators (no dependent MFMA chain);
+// A^T is applied to the accumulators once per wave before the cross-wave reduction, which then sees two accumulators as ever.
+// Numerics: fp32 throughout; against a double evaluation F(2, 3) loses 2 dB to the plain summation (129-132 vs 131-133 dB per
+// layer), F(2, 5) with the points 0, +-1, 1/2, -2 about 9 (122-125 dB) -- two and a half orders of magnitude inside the 60 dB
+// tolerance of the path, see DESIGN.md 5.  64-column tiles only (32 tile positions = one MFMA's columns): the 401-frame
+// levels at batch 1 (32-column tiles) stay on conv_direct2_kernel.  OU_WINO=0 switches the variant off.
+// ---------------------------------------------------------------------------------------------------------
+template <int KW, int WK>
+__device__ __forceinline__ void direct2w_tile(const ConvArgs& p, float* smem, int b, int m0, int n0) {
+  constexpr int D = 4, TN = 2, NX = KW + 1, W = NX, KWP = KW == 3 ? 4 : 8, PAD = (KW - 1) / 2;
+  constexpr int X2 = NX - 4;                  // elements in the second load of either operand: 0 (k3) / 2 (k5)
+  constexpr int LPS = X2 ? 4 : 2;             // load instructions per ring slot (= channel pair)
+  using Epi = Direct2Epilogue<TN, WK>;
+  constexpr int NE = Epi::NLOAD;
+  static_assert(KW == 3 || KW == 5, "k3 / k5");
+  static_assert(D * LPS + NE <= 60, "vmcnt");
+  constexpr int BN = 32 * TN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lhalf = lane >> 5, l31 = lane & 31;
+  const int Tin = p.Tin, Mp = p.Mp;
+  const float alpha = p.act ? p.alpha_val : 1.0f;
+  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  const u32x4 rw = direct_desc(p.wu, (unsigned)p.Cin * (unsigned)Mp * (unsigned)KWP * 4u);
+  const int avo = ((lhalf * Mp) + m0 + l31) * KWP * 4;
+  // this lane's window: samples t0 .. t0 + W - 1 of row 2I + half; `sh` = samples cut off in front of the row
+  const int t0 = n0 + TN * l31 - PAD;
+  const int sh = t0 < 0 ? -t0 : 0;
+  const int bvo = (t0 + sh < Tin) ? (lhalf * Tin + t0 + sh) * 4 : (int)0x80000000;
+  const bool edge = __builtin_amdgcn_readfirstlane((n0 < PAD || n0 + BN + KW - 1 - PAD > Tin) ? 1 : 0) != 0;
+  unsigned vmask = 0;  // bit i: window element i is inside the row
+#pragma unroll
+  for (int i = 0; i < W; i++) vmask |= (t0 + i >= 0 && t0 + i < Tin) ? (1u << i) : 0u;
+
+  const int NG = p.Cin / (2 * WK);  // channel pairs per wave (launcher: a multiple of D)
+  f32x4 a4[D], b4[D];
+  f32x2 a2[D], b2[D];  // k5: U_4, U_5 / window elements 4, 5
+#pragma unroll
+  for (int d0 = 0; d0 < D; d0++) {
+    a4[d0] = f32x4{0.f, 0.f, 0.f, 0.f}; b4[d0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    a2[d0] = f32x2{0.f, 0.f}; b2[d0] = f32x2{0.f, 0.f};
+  }
+  floatx16 acc[NX];
+#pragma unroll
+  for (int j = 0; j < NX; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+#define OU_ISSUE(g_, d)                                                                                              \
+  {                                                                                                                  \
+    const int ci = 2 * (kw + WK * (g_));                                                                             \
+    const int aso = ci * Mp * KWP * 4, xso = ci * Tin * 4;                                                           \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(a4[d]) : "v"(avo), "s"(rw), "s"(aso));            \
+    if constexpr (X2 == 2)                                                                                           \
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:16" : "+v"(a2[d]) : "v"(avo), "s"(rw), "s"(aso)); \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(b4[d]) : "v"(bvo), "s"(rx), "s"(xso));            \
+    if constexpr (X2 == 2)                                                                                           \
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:16" : "+v"(b2[d]) : "v"(bvo), "s"(rx), "s"(xso)); \
+  }
+#define OU_MMA(d, out)                                                                                               \
+  {                                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(out));                                                                  \
+    asm volatile("" : "+v"(a4[d]));                                                                                  \
+    asm volatile("" : "+v"(b4[d]));                                                                                  \
+    if constexpr (X2 == 2) asm volatile("" : "+v"(a2[d]));                                                           \
+    if constexpr (X2 == 2) asm volatile("" : "+v"(b2[d]));                                                           \
+    direct2w_mma<KW>(a4[d], a2[d], b4[d], b2[d], acc, alpha, edge, sh, vmask);                                       \
+  }
+  OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
+  const int NR = NG / D;
+  for (int r = 0; r + 1 < NR; r++) {
+    const int g = r * D;
+    OU_MMA(0, 3 * LPS); OU_ISSUE(g + 4, 0);
+    OU_MMA(1, 3 * LPS); OU_ISSUE(g + 5, 1);
+    OU_MMA(2, 3 * LPS); OU_ISSUE(g + 6, 2);
+    OU_MMA(3, 3 * LPS); OU_ISSUE(g + 7, 3);
+  }
+  typename Epi::Pre pre;
+  Epi::issue(p, pre, tid, b, m0, n0);  // the epilogue's global operands travel under the drain
+  OU_MMA(0, 3 * LPS + NE); OU_MMA(1, 2 * LPS + NE); OU_MMA(2, LPS + NE); OU_MMA(3, NE);
+#undef OU_ISSUE
+#undef OU_MMA
+  // A^T: the wave's KW + 1 partial GEMM results -> its two output accumulators (even / odd columns of the tile)
+  floatx16 out[TN];
+  if constexpr (KW == 3) {
+    out[0] = acc[0] + acc[1] + acc[2];
+    out[1] = acc[1] - acc[2] - acc[3];
+  } else {
+    out[0] = acc[0] + acc[1] + acc[2] + acc[3] + acc[4];
+    out[1] = acc[1] - acc[2] + 0.5f * acc[3] - 2.0f * acc[4] + acc[5];
+  }
+  Epi::run(p, out, pre, smem, tid, kw, b, m0, n0, 0, 0x7fffffff);
+}
+template <int KW, int WK>
+__global__ __launch_bounds__(64 * WK) void conv_direct2w_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int tile_m, tile_n;
+  if (!direct_tile(p, tile_m, tile_n)) return;
+  if (p.prof && threadIdx.x == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  direct2w_tile<KW, WK>(p, smem, blockIdx.z, tile_m * 32, tile_n * 64);
   if (p.prof && threadIdx.x == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
@@ -796,6 +1066,29 @@ static const StridedCfg kStridedCfgs[] = {
     OU_STRIDED(2, 1), OU_STRIDED(3, 1), OU_STRIDED(4, 1), OU_STRIDED(5, 1), OU_STRIDED(8, 1),
 };
 
+// Tile width, K split and arithmetic of the wide-load kernel for one layer.  force_cfg 105 / 106: eight slices, 64 / 32
+// columns (round 2); 107 / 108: four slices; 109 / 110: minimal filtering (conv_direct2w_kernel), eight / four slices.
+static void direct2_pick(const ConvArgs& a, int num_cu, int& tn, int& wk, bool& wino) {
+  const long gm = (a.M + 31) / 32;
+  const long b64 = gm * ((a.Nq + 63) / 64) * a.B;
+  wk = 8;  // tn: the caller's block-round rule
+  const bool wk4_ok = (a.Cin / 8) % 4 == 0;  // channel pairs per wave with four slices: whole rounds of the ring
+  if (a.d2_wk == 4 && wk4_ok) wk = 4;
+  // Minimal filtering wherever the block-round rule takes 64-column tiles.  Residency: the k5 form holds six accumulators
+  // (~170 VGPRs: two waves per SIMD), so a launch that needs two 8-wave blocks per CU to run in one round splits the
+  // reduction over four waves instead (two 4-wave blocks per CU: the same two waves per SIMD).
+  wino = a.wino && a.direct >= 5 && a.wu && tn == 2;
+  if (wino && a.KW == 5 && b64 > num_cu && a.d2_wk != 8) {
+    if (wk4_ok) wk = 4; else wino = false;
+  }
+  if (a.force_cfg == 105) { tn = 2; wk = 8; wino = false; }
+  if (a.force_cfg == 106) { tn = 1; wk = 8; wino = false; }
+  if (a.force_cfg == 107 && wk4_ok) { tn = 2; wk = 4; wino = false; }
+  if (a.force_cfg == 108 && wk4_ok) { tn = 1; wk = 4; wino = false; }
+  if (a.force_cfg == 109 && a.wu) { tn = 2; wk = 8; wino = true; }
+  if (a.force_cfg == 110 && a.wu && wk4_ok) { tn = 2; wk = 4; wino = true; }
+}
+
 // Launches a direct kernel when the layer fits one; hipErrorInvalidConfiguration = "use conv_mfma_kernel".
 hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
   if (a.Cin % 16 || (a.in_scale != nullptr && a.act)) return hipErrorInvalidConfiguration;
@@ -833,12 +1126,25 @@ hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream,
     const long plain = gm * ((a.Nq + 32 * tn - 1) / (32 * tn)) * a.B;
     if (a.force_cfg < 0 && (fused + slots - 1) / slots > (plain + slots - 1) / slots) return hipErrorNotSupported;
   }
+  int wk = 8;
   if (a.stride == 1 && a.wd && a.direct >= 2 && !a.fir && a.up == 1 && (a.KW == 3 || a.KW == 5) && npw % 4 == 0 &&
-      a.pad == (a.KW - 1) / 2 && (long)a.Cin * a.Mp * 8 * 4 < (1L << 31)) {
-    // wide-load variant (taps-innermost weight copy)
-    kern = a.KW == 3 ? (tn == 2 ? conv_direct2_kernel<3, 2> : conv_direct2_kernel<3, 1>)
-                     : (tn == 2 ? conv_direct2_kernel<5, 2> : conv_direct2_kernel<5, 1>);
-    variant = 56 + 10 * tn;  // 66 / 76
+      a.pad == (a.KW - 1) / 2 && (long)a.Cin * a.Mp * 8 * 4 < (1L << 31) && (long)a.Cout * a.Tout * 4 < (1L << 31)) {
+    // wide-load variant (taps-innermost weight copy); the reduction split over 8 or 4 waves (direct2_pick)
+    bool wino = false;
+    direct2_pick(a, num_cu, tn, wk, wino);
+    if (wino) {
+      if (wk == 8) kern = a.KW == 3 ? conv_direct2w_kernel<3, 8> : conv_direct2w_kernel<5, 8>;
+      else kern = a.KW == 3 ? conv_direct2w_kernel<3, 4> : conv_direct2w_kernel<5, 4>;
+      variant = wk == 8 ? 78 : 79;  // minimal-filtering variants (64-column tiles)
+    } else {
+      if (wk == 8)
+        kern = a.KW == 3 ? (tn == 2 ? conv_direct2_kernel<3, 2, 8> : conv_direct2_kernel<3, 1, 8>)
+                         : (tn == 2 ? conv_direct2_kernel<5, 2, 8> : conv_direct2_kernel<5, 1, 8>);
+      else
+        kern = a.KW == 3 ? (tn == 2 ? conv_direct2_kernel<3, 2, 4> : conv_direct2_kernel<3, 1, 4>)
+                         : (tn == 2 ? conv_direct2_kernel<5, 2, 4> : conv_direct2_kernel<5, 1, 4>);
+      variant = (wk == 8 ? 56 : 57) + 10 * tn;  // 66 / 76 (eight K slices), 67 / 77 (four)
+    }
   } else if (a.stride == 1) {
     if (a.KW != 1 && a.KW != 3 && a.KW != 5) return hipErrorInvalidConfiguration;
     for (const DirectCfg& c : kDirectCfgs) {
@@ -868,18 +1174,30 @@ hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream,
   aa.tile_bm = bm_step; aa.tile_bn = BN - 2 * halo; aa.tile_halo = halo;
   aa.grid_n = (a.Nq + aa.tile_bn - 1) / aa.tile_bn;
   aa.grid_m = (int)gm_fir;
+  const bool is_d2 = variant == 66 || variant == 76 || variant == 67 || variant == 77 || variant == 78 || variant == 79;
   {
     const double xb = (double)a.Cin * a.Nq * a.stride, wb = (double)a.M * a.Cin * a.KW;
     aa.xcd_map = 0;
     if (aa.grid_m % 8 == 0 && wb >= xb) aa.xcd_map = 1;
     else if (aa.grid_n >= 8) aa.xcd_map = 2;
+    if (is_d2 && aa.xcd_map == 2 && aa.grid_m % 2 == 0) {
+      // 2-D ownership instead of "column tiles x mod 8 per XCD": an XCD then owns a CONTIGUOUS quarter of the time axis and
+      // half of the rows.  Measured (tools/d2_sweep.py, PP16 B = 1): 19.3 -> 18.3 us (64 channels, T = 32 080), 16.5 -> 15.5 /
+      // 11.2 -> 10.9 us (128 channels), no difference at 256 channels; (4 x 2) the same where it fits and a disaster where the
+      // row groups do not divide (two row tiles: half the blocks are padding).  A per-XCD byte count (W/2 + X/4 against
+      // W + X/8) predicts the opposite for the 128-channel level: with interleaved ownership every XCD also pulls the halo
+      // lines of its neighbours' tiles, and the weights are the smaller operand there anyway.
+      if (direct_grid_blocks(3, aa.grid_m, aa.grid_n) * 16 <= (long)aa.grid_m * ((aa.grid_n + 7) / 8 * 8) * 17) aa.xcd_map = 3;
+    }
+    if (is_d2 && a.d2_map >= 0) aa.xcd_map = a.d2_map;
     if (a.force_xcd_map >= 0) aa.xcd_map = a.force_xcd_map;
     if (aa.xcd_map == 1 && aa.grid_m % 8) aa.xcd_map = 0;
+    if ((aa.xcd_map == 3 || aa.xcd_map == 4) && !is_d2) aa.xcd_map = 0;
   }
-  const int gn_pad = aa.xcd_map == 2 ? (aa.grid_n + 7) / 8 * 8 : aa.grid_n;
-  const size_t smem = (size_t)8 * 32 * (BN + 4) * 4;
+  const int nblocks = direct_grid_blocks(aa.xcd_map, aa.grid_m, aa.grid_n);
+  const size_t smem = (size_t)wk * 32 * (BN + 4) * 4;
   if (cfg_out) *cfg_out = variant;
-  hipLaunchKernelGGL(kern, dim3(gn_pad * aa.grid_m, 1, a.B), dim3(512), smem, stream, aa);
+  hipLaunchKernelGGL(kern, dim3(nblocks, 1, a.B), dim3(64 * wk), smem, stream, aa);
   return hipGetLastError();
 }
 

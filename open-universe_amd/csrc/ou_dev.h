@@ -59,11 +59,32 @@ __device__ __forceinline__ bool direct_tile(const ConvArgs& p, int& tile_m, int&
     tile_m = q - ng * gy;
     tile_n = ng * 8 + (L & 7);
     if (tile_n >= gx) return false;
+  } else if (p.xcd_map == 3 || p.xcd_map == 4) {
+    // 2-D ownership (round 5): the eight XCDs as a (2 x 4) or (4 x 2) grid of (row groups x column groups) -- an XCD's L2
+    // then fetches 1/2 (1/4) of the weights and 1/4 (1/2) of the activations instead of all of one and an eighth of the
+    // other: less memory-side traffic where the two operands are of similar size (the 256-channel level: 1.0 instead of
+    // 1.3 MB per XCD for k3, 1.6 instead of 2.3 MB for k5)
+    const int rg = p.xcd_map == 3 ? 2 : 4, cg = 8 / rg;
+    const int x = L & 7, q = L >> 3, xr = x % rg, xc = x / rg;
+    const int gmh = (gy + rg - 1) / rg, gnq = (gx + cg - 1) / cg;
+    const int nn = q / gmh, mm = q - nn * gmh;
+    tile_m = xr * gmh + mm;
+    tile_n = xc * gnq + nn;
+    if (nn >= gnq || tile_m >= gy || tile_n >= gx) return false;
   } else {
     tile_m = L / gx;
     tile_n = L - tile_m * gx;
   }
   return true;
+}
+// blocks a launch needs under mapping `xcd_map` (padding blocks of the XCD-aware mappings included)
+inline int direct_grid_blocks(int xcd_map, int grid_m, int grid_n) {
+  if (xcd_map == 2) return (grid_n + 7) / 8 * 8 * grid_m;
+  if (xcd_map == 3 || xcd_map == 4) {
+    const int rg = xcd_map == 3 ? 2 : 4, cg = 8 / rg;
+    return 8 * ((grid_m + rg - 1) / rg) * ((grid_n + cg - 1) / cg);
+  }
+  return grid_m * grid_n;
 }
 __device__ __forceinline__ u32x4 direct_desc(const void* base, unsigned bytes) {
   // buffer descriptor as a plain SGPR quad (base, bounds, raw-dword format) for the inline-asm loads

@@ -14,6 +14,7 @@ struct ConvArgs {
   const float* x = nullptr;       // (B, Cin, Tin)
   const float* w = nullptr;       // packed [Cin/CK][KW][CK][Mp]
   const float* wd = nullptr;      // second copy, taps innermost: [Cin][Mp][4 (k3) / 8 (k5)] (conv_direct2_kernel) or null
+  const float* wu = nullptr;      // third copy, Winograd domain U = G w: [Cin][Mp][4 (F(2,3)) / 8 (F(2,5): 6 used)] or null
   const float* bias = nullptr;    // [Cout]
   float* y = nullptr;             // (B, Cout, Tout)
   const float* in_scale = nullptr;  // [B] or null
@@ -36,11 +37,16 @@ struct ConvArgs {
   int force_xcd_map = -1;              // tuning: 0 / 1 / 2
   double tile_min = -1.0;              // OU_TILE_MIN (< 0: the launcher's default of 1.2 wave tiles per SIMD)
   int tile_prefetch = 1;               // OU_TILE_PREFETCH: LDS prefetch of the epilogue operand in conv_direct3_kernel
-  int direct = 4;                      // OU_CONV_DIRECT: 0 = never use the register-direct kernels, 1 = only the first
+  int direct = 5;                      // OU_CONV_DIRECT: 0 = never use the register-direct kernels, 1 = only the first
                                        // generation (dword loads), 2 = + wide-load split-K variant where a layer has `wd`,
                                        // 3 = + the no-split-K throughput kernel (conv_direct3_kernel) for many-column launches,
                                        // 4 = + the wide-load split-K kernel for 1x1 / phase-GEMM / rate-change layers
-                                       //     (conv_direct4_kernel)
+                                       //     (conv_direct4_kernel),
+                                       // 5 = + minimal filtering F(2, 3) / F(2, 5) for the k3 / k5 layers on 64-column tiles
+                                       //     (conv_direct2w_kernel; default)
+  int d2_map = -1;                     // OU_D2_MAP: block -> tile mapping of the wide-load split-K kernels only (tuning)
+  int wino = 1;                        // OU_WINO=0: never use the minimal-filtering variants (conv_direct2w_kernel, ...)
+  int d2_wk = 0;                       // OU_D2_WK = 4 / 8: K slices (waves per block) of conv_direct2_kernel (0: the launcher's rule)
   int d4_fir_unfused = 1;              // OU_D4_FIR=0: up convs with a fusable FIR stay on the first-generation fused kernel
   int d4_short = 1;                    // OU_D4_SHORT=0: the 401-frame levels at batch 1 stay on the first-generation kernels
   int d4_force = 0;                    // OU_D4_FORCE = 10 TM + log2(WK): that tile shape wherever a layer admits it (tests / tuning)

@@ -44,6 +44,7 @@ std::string finish_conv(ConvL& L, Alloc& a) {
   if (L.stride == 1 && L.up == 1 && (L.KW == 3 || L.KW == 5) && L.Cin % 16 == 0 && L.pad == (L.KW - 1) / 2) {
     L.KWP = L.KW == 3 ? 4 : 8;
     L.wd_off = a.take((size_t)L.Cin * L.Mp * L.KWP);
+    L.wu_off = a.take((size_t)L.Cin * L.Mp * L.KWP);
   }
   return "";
 }
@@ -131,7 +132,7 @@ void json_conv(std::ostringstream& os, const ConvL& L, bool& first) {
      << ",\"M\":" << L.M << ",\"Mp\":" << L.Mp << ",\"CK\":" << L.CK << ",\"rate\":" << L.rate << ",\"act\":" << L.act
      << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"a_off\":" << L.a_off
      << ",\"fir_mode\":" << L.fir_mode << ",\"fir_len\":" << L.fir_len << ",\"fir_off\":" << L.fir_off
-     << ",\"fbias_off\":" << L.fbias_off << ",\"wd_off\":" << L.wd_off << ",\"KWP\":" << L.KWP << "}";
+     << ",\"fbias_off\":" << L.fbias_off << ",\"wd_off\":" << L.wd_off << ",\"wu_off\":" << L.wu_off << ",\"KWP\":" << L.KWP << "}";
 }
 void json_block(std::ostringstream& os, const BlockL& B, bool& first) {
   if (B.dir) json_conv(os, B.rc, first);
@@ -384,6 +385,29 @@ struct Packer {
         for (int mm = 0; mm < L.M; mm++)
           for (int k = 0; k < KW; k++)
             blob[L.wd_off + ((size_t)ci * Mp + mm) * L.KWP + k] = (float)W[((size_t)mm * L.Cin + ci) * KW + k];
+    if (L.KWP) {
+      // Winograd / Cook-Toom minimal filtering F(2, KW): two outputs from KW + 1 products instead of 2 KW.  U = G w in double,
+      // rounded once.  F(2, 3): points 0, 1, -1, inf (Lavin & Gray's matrices).  F(2, 5): points 0, 1, -1, 1/2, -2, inf -- the
+      // mixed pair 1/2, -2 loses 2 dB less than +-2 in fp32 (measured against a double evaluation: 123-125 dB per layer, plain
+      // fp32 summation 131-133 dB); rows scaled so that the kernel's input transform B^T has small integer entries.
+      static const double G3[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+      static const double G5[6][5] = {{1. / 2, 0, 0, 0, 0},
+                                      {1. / 6, 1. / 6, 1. / 6, 1. / 6, 1. / 6},
+                                      {1. / 6, -1. / 6, 1. / 6, -1. / 6, 1. / 6},
+                                      {16. / 15, 8. / 15, 4. / 15, 2. / 15, 1. / 15},
+                                      {1. / 30, -1. / 15, 2. / 15, -4. / 15, 8. / 15},
+                                      {0, 0, 0, 0, 1. / 2}};
+      const int NU = KW + 1;
+      for (int ci = 0; ci < L.Cin; ci++)
+        for (int mm = 0; mm < L.M; mm++) {
+          const double* w = &W[((size_t)mm * L.Cin + ci) * KW];
+          for (int x = 0; x < NU; x++) {
+            double u = 0;
+            for (int k = 0; k < KW; k++) u += (KW == 3 ? G3[x][k] : G5[x][k]) * w[k];
+            blob[L.wu_off + ((size_t)ci * Mp + mm) * L.KWP + x] = (float)u;
+          }
+        }
+    }
   }
 
   void pack_conv(const ConvL& L) {

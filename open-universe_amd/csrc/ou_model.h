@@ -25,6 +25,8 @@ struct ConvL {
   int act = 0;            // PReLU prologue
   size_t wd_off = 0;      // stride-1 k3 / k5 layers: second copy of the weights with the taps innermost, [Cin][Mp][KWP]
   int KWP = 0;            // ... 4 (k3) / 8 (k5); 0 = no such copy
+  size_t wu_off = 0;      // ... and a third copy in the Winograd / Cook-Toom domain, U = G w: F(2, 3) -> 4 floats, F(2, 5) -> 6 (of
+                          // 8) floats per (row, channel), same [Cin][Mp][KWP] slots (conv_direct2w_kernel); valid when KWP != 0
   size_t w_off = 0;       // float offsets into the blob
   size_t b_off = 0;       // bias[Cout]
   size_t a_off = 0;       // prelu slope (1 float) when act

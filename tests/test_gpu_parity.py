@@ -450,6 +450,55 @@ def test_wide_load_direct_kernel_at_the_headline_size(monkeypatch):
     record("direct2_vs_direct1.PP16.64000", O.si_sdr(ref[0], out[0]), 100)
 
 
+@pytest.mark.parametrize("name,B,T", [("PP16", 1, 64000), ("PP16", 2, 23517), ("PP16", 3, 777), ("OR16", 2, 9000)])
+def test_four_slice_wide_load_kernel_vs_eight_slices(name, B, T, monkeypatch):
+    """conv_direct2_kernel with the reduction split over FOUR waves (256-thread blocks, round 5) against the eight-slice form:
+    the same per-wave order over twice as long a K slice, four partial sums instead of eight -- fp32 rounding apart; and the
+    2-D XCD ownerships (OU_XCD_MAP 3 / 4: the same tiles dealt to other blocks) are bit-identical to the default mapping."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(53, 2, B, Tp)
+    monkeypatch.setenv("OU_D2_WK", "8")
+    ref = run_enhance(model, mix, nz, n_steps=2)
+    for mp in ("3", "4"):
+        monkeypatch.setenv("OU_XCD_MAP", mp)
+        assert torch.equal(run_enhance(model, mix, nz, n_steps=2), ref), mp
+    monkeypatch.delenv("OU_XCD_MAP")
+    monkeypatch.setenv("OU_D2_WK", "4")
+    out = run_enhance(model, mix, nz, n_steps=2)
+    for b in range(B):
+        record(f"direct2_wk4_vs_wk8.{name}.T{T}.{b}", O.si_sdr(ref[b], out[b]), 100)
+    monkeypatch.setenv("OU_XCD_MAP", "3")
+    assert torch.equal(run_enhance(model, mix, nz, n_steps=2), out)
+
+
+@pytest.mark.parametrize("name,B,T", [("PP16", 1, 64000), ("PP16", 2, 23517), ("PP16", 3, 777), ("OR16", 2, 9000), ("PP24", 1, 30011),
+                                      ("PP16", 1, 4001)])
+def test_minimal_filtering_kernels_vs_plain_summation(name, B, T, monkeypatch):
+    """conv_direct2w_kernel (Winograd / Cook-Toom F(2, 3) and F(2, 5): KW + 1 instead of 2 KW products per pair of adjacent
+    outputs, weights transformed by the packer, samples transformed on the fly) against the plain wide-load kernel
+    (OU_CONV_DIRECT=4) through a whole enhance, and against the oracle.  Different arithmetic by construction (fp32 rounding
+    of the transforms: -2 dB per k3 layer, -9 dB per k5 layer against a double evaluation); ragged / tiny lengths put the shifted and
+    masked windows of the first and last column tiles under the input transform."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(59, 2, B, Tp)
+    monkeypatch.setenv("OU_CONV_DIRECT", "4")
+    ref = run_enhance(model, mix, nz, n_steps=2)
+    n_ref = model.launch_stats()
+    monkeypatch.delenv("OU_CONV_DIRECT")
+    out = run_enhance(model, mix, nz, n_steps=2)
+    assert model.launch_stats() == n_ref
+    for b in range(B):
+        record(f"wino_vs_plain.{name}.T{T}.{b}", O.si_sdr(ref[b], out[b]), 85)
+    e_ref = O.enhance(sd, spec.to_dict(), mix, n_steps=2, noise=nz)
+    record(f"wino_vs_oracle.{name}.T{T}", O.si_sdr(e_ref, out), 80)
+    monkeypatch.setenv("OU_WINO", "0")
+    assert torch.equal(run_enhance(model, mix, nz, n_steps=2), ref)  # the switch: exactly the plain kernels
+
+
 @pytest.mark.parametrize("name,B,T", [("PP16", 2, 23517), ("PP24", 1, 30011), ("PP16", 1, 64000)])
 def test_fused_up_fir_epilogue_is_bit_identical_to_the_fir_pass(name, B, T, monkeypatch):
     """Up path: FIR + bias + residual fused into the transposed conv's epilogue (overlapping tiles, one halo frame) vs

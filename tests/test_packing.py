@@ -88,6 +88,37 @@ def test_taps_innermost_weight_copy_equals_the_tap_major_one(built_lib):
     assert n >= 20
 
 
+def test_winograd_domain_weight_copy_reproduces_the_convolution(built_lib):
+    """The third copy U = G w (F(2, 3): 4 values, F(2, 5): 6 values per (row, channel), ou_model.cpp) together with the
+    kernel's B^T / A^T must BE the convolution: y[2p + j] = sum_k w[k] d[2p + j + k].  Checked in double on the packed fp32
+    values: an error in any of the three matrices -- they live in two source files -- shows here, without a GPU."""
+    BT = {3: [[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]],
+          5: [[2, -3, -4, 3, 2, 0], [0, -2, 1, 5, 2, 0], [0, -2, 5, -1, -2, 0], [0, 2, 1, -2, -1, 0], [0, 1, -2, -1, 2, 0],
+              [0, 2, -3, -4, 3, 2]]}
+    AT = {3: [[1, 1, 1, 0], [0, 1, -1, -1]], 5: [[1, 1, 1, 1, 1, 0], [0, 1, -1, 0.5, -2, 1]]}
+    spec = get_spec("PP16m")
+    sd = S.synthetic_state_dict(spec, seed=5)
+    blob, plan = _lib.pack_weights(spec, sd)
+    g = torch.Generator().manual_seed(3)
+    n = 0
+    for nm, L in plan_convs(plan).items():
+        if not L["KWP"]:
+            continue
+        Cin, KW, KWP, Mp, M = L["Cin"], L["KW"], L["KWP"], L["Mp"], L["M"]
+        W, _, _ = unpack_conv(blob, L)                                     # [M][Cin][KW]
+        wu = blob[L["wu_off"]: L["wu_off"] + Cin * Mp * KWP].view(Cin, Mp, KWP)
+        assert not wu[:, :, KW + 1:].any() and not wu[:, M:, :].any(), nm
+        U = wu[:, :M, :KW + 1].permute(1, 0, 2).double()                   # [M][Cin][KW + 1]
+        d = torch.randn(Cin, KW + 1, generator=g).double()                 # one tile: KW + 1 input samples per channel
+        V = d @ torch.tensor(BT[KW], dtype=torch.float64).T                # [Cin][KW + 1]
+        Mx = (U * V[None]).sum(dim=1)                                      # [M][KW + 1]: reduction over the channels
+        y = Mx @ torch.tensor(AT[KW], dtype=torch.float64).T               # [M][2]
+        ref = torch.stack([(W.double() * d[None, :, j:j + KW]).sum(dim=(1, 2)) for j in range(2)], dim=1)
+        assert torch.allclose(y, ref, rtol=0, atol=2e-5 * float(ref.abs().max())), (nm, float((y - ref).abs().max()))
+        n += 1
+    assert n >= 20
+
+
 def test_pack_errors(built_lib):
     spec = get_spec("PP16s")
     sd = S.synthetic_state_dict(spec, seed=0)
