@@ -146,7 +146,8 @@ def test_lora_and_weight_norm_removed_checkpoints():
             wn_blob, _ = _lib.pack_weights(spec, sd)
             _, plain = lora_style_state_dict(sd, rank=10 ** 6)  # no adapter fits: plain == folded sd
             pb, _ = _lib.pack_weights(spec, S.inference_state_dict(spec, plain))
-            assert torch.allclose(pb, wn_blob, rtol=3e-7, atol=1e-9)
+            # (the Winograd-domain copies U = G w hold differences of taps: absolute, not relative, agreement there)
+            assert torch.allclose(pb, wn_blob, rtol=3e-7, atol=5e-7)
         with pytest.raises(NotImplementedError):
             S.inference_state_dict(spec, {"state_dict": lora_sd, "ema": {"shadow_params": []}})
     # alpha != rank scales the adapter
