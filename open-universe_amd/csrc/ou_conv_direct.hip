@@ -497,24 +497,7 @@ __device__ __forceinline__ void direct2w_mma(const f32x4& a4, const f32x2& a2, c
 #pragma unroll
   for (int i = 0; i < W; i++) X[i] = X[i] >= 0.f ? X[i] : alpha * X[i];
   float V[W];
-  if constexpr (KW == 3) {
-    V[0] = X[0] - X[2];
-    V[1] = X[1] + X[2];
-    V[2] = X[2] - X[1];
-    V[3] = X[1] - X[3];
-  } else {
-    // rows of B^T: [2 -3 -4 3 2 0] [0 -2 1 5 2 0] [0 -2 5 -1 -2 0] [0 2 1 -2 -1 0] [0 1 -2 -1 2 0] [0 2 -3 -4 3 2]
-    const float p13 = X[1] - X[3], p24 = X[2] - X[4];
-    V[3] = fmaf(2.f, p13, p24);
-    V[4] = fmaf(-2.f, p24, p13);
-    const float q = X[4] - X[1];                       // V1 = 2 q + X2 + 5 X3 ; V2 = -2 q + 5 X2 - X3 - 4 X4 ... keep it plain:
-    V[1] = fmaf(5.f, X[3], fmaf(2.f, q, X[2]));
-    V[2] = fmaf(5.f, X[2], fmaf(-2.f, X[1] + X[4], -X[3]));
-    const float s04 = X[0] + X[4], d31 = X[3] - X[1];  // V0 = 2 (X0 + X4) + 3 (X3 - X1) - 4 X2
-    V[0] = fmaf(-4.f, X[2], fmaf(3.f, d31, 2.f * s04));
-    const float s15 = X[1] + X[5], d42 = X[4] - X[2];  // V5 = 2 (X1 + X5) + 3 (X4 - X2) - 4 X3
-    V[5] = fmaf(-4.f, X[3], fmaf(3.f, d42, 2.f * s15));
-  }
+  wino_bt<KW>(X, V);
   const float A[6] = {a4.x, a4.y, a4.z, a4.w, a2.x, a2.y};
 #pragma unroll
   for (int x = 0; x < W; x++) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[x], V[x], acc[x], 0, 0, 0);

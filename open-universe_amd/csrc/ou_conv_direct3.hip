@@ -230,6 +230,214 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// conv_direct3w_kernel: conv_direct3_kernel with MINIMAL FILTERING F(2, KW) (round 5; see conv_direct2w_kernel for the scheme
+// and its numerics).  A lane's four adjacent output columns are two tile positions p = 0, 1; its window of KW + 3 samples --
+// the very loads of conv_direct3_kernel -- holds both input tiles d_p = window[2 p .. 2 p + KW]; A lane (m, kk) loads the KW + 1
+// Winograd-domain values U_x of (row m0 + 16 i + m, channel 4 J + kk) from the third weight copy (16 bytes for k3 -- what the
+// taps took --, 16 + 8 for k5).  Per ring slot and 32 x 64 wave tile: 2 x 2 x (KW + 1) MFMAs instead of 2 x 4 x KW (16 / 24, was
+// 24 / 40) on 2 x 2 x (KW + 1) independent 16 x 16 accumulators; A^T is applied in the epilogue, which then finishes quads of
+// four adjacent samples exactly as before.  32-row tiles only (TM = 2): the accumulators of a 64-row tile would not leave room
+// for the ring (k3: 64 + 56 ring registers at TM = 2, 128 + 88 at TM = 4).
+// ---------------------------------------------------------------------------------------------------------
+template <int KW, bool PRE>
+__global__ __launch_bounds__(256, 2) void conv_direct3w_kernel(ConvArgs p) {
+  constexpr int D = 4, TM = 2, TN = 4, NX = KW + 1, W = KW + TN - 1, KWP = KW == 3 ? 4 : 8, PAD = (KW - 1) / 2;
+  constexpr int A2 = KW == 5 ? 1 : 0;       // second A load per row tile (U_4, U_5)
+  constexpr int LPS = TM * (1 + A2) + 2;    // load instructions per ring slot
+  static_assert(KW == 3 || KW == 5, "k3 / k5");
+  static_assert(D * LPS <= 60, "loads in flight must fit vmcnt");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = blockIdx.x, q8 = L >> 3, rg = q8 % p.grid_m, cidx = (q8 / p.grid_m) * 8 + (L & 7);
+  const int b = cidx / p.grid_n, chunk = cidx - b * p.grid_n;
+  const int n0 = (chunk * 4 + wv) * 64, m0 = rg * (16 * TM);
+  if (b >= p.B || n0 >= p.Nq) return;  // (whole waves: nothing in this kernel synchronises)
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const int l15 = lane & 15, kk = lane >> 4;
+  const int Tin = p.Tin, Mp = p.Mp;
+  const float alpha = p.act ? p.alpha_val : 1.0f;
+  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  const u32x4 rw = direct_desc(p.wu, (unsigned)p.Cin * (unsigned)Mp * (unsigned)KWP * 4u);
+  const int avo = (kk * Mp + m0 + l15) * KWP * 4;
+  const int t0 = n0 + TN * l15 - PAD;
+  const int sh = t0 < 0 ? -t0 : 0;
+  const int bvo = (t0 + sh < Tin) ? (kk * Tin + t0 + sh) * 4 : (int)0x80000000;
+  const bool edge = __builtin_amdgcn_readfirstlane((n0 < PAD || n0 + 64 + KW - 1 - PAD > Tin) ? 1 : 0) != 0;
+  unsigned vmask = 0;  // bit i: window element i is inside the row
+#pragma unroll
+  for (int i = 0; i < W; i++) vmask |= (t0 + i >= 0 && t0 + i < Tin) ? (1u << i) : 0u;
+
+  const int NG = p.Cin >> 2;  // ring slots (launcher: a multiple of D)
+  f32x4 a4[D][TM], b4[D], b4b[D];
+  f32x2 a2[D][TM], b2[D];
+#pragma unroll
+  for (int d0 = 0; d0 < D; d0++) {
+#pragma unroll
+    for (int i = 0; i < TM; i++) { a4[d0][i] = f32x4{0.f, 0.f, 0.f, 0.f}; a2[d0][i] = f32x2{0.f, 0.f}; }
+    b4[d0] = f32x4{0.f, 0.f, 0.f, 0.f}; b4b[d0] = f32x4{0.f, 0.f, 0.f, 0.f}; b2[d0] = f32x2{0.f, 0.f};
+  }
+  f32x4acc acc[TM][2][NX];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int x = 0; x < NX; x++) acc[i][q][x] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+
+#define OU_ISSUE(g_, d)                                                                                               \
+  {                                                                                                                   \
+    const int aso = (g_) * 4 * Mp * KWP * 4, xso = (g_) * 4 * Tin * 4;                                                \
+    _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                  \
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"                                               \
+                   : "+v"(a4[d][i]) : "v"(avo), "s"(rw), "s"(aso), "n"(i * 16 * KWP * 4));                            \
+      if constexpr (A2 == 1)                                                                                          \
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4"                                             \
+                     : "+v"(a2[d][i]) : "v"(avo), "s"(rw), "s"(aso), "n"(i * 16 * KWP * 4 + 16));                     \
+    }                                                                                                                 \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(b4[d]) : "v"(bvo), "s"(rx), "s"(xso));             \
+    if constexpr (KW == 3)                                                                                            \
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:16" : "+v"(b2[d]) : "v"(bvo), "s"(rx), "s"(xso)); \
+    else                                                                                                              \
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "+v"(b4b[d]) : "v"(bvo), "s"(rx), "s"(xso)); \
+  }
+#define OU_MMA(d, out) OU_MMAX(d, out, 0)
+#define OU_MMAX(d, out, extra)                                                                                        \
+  {                                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS + (extra)));                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                  \
+      asm volatile("" : "+v"(a4[d][i]));                                                                              \
+      if constexpr (A2 == 1) asm volatile("" : "+v"(a2[d][i]));                                                       \
+    }                                                                                                                 \
+    asm volatile("" : "+v"(b4[d]));                                                                                   \
+    if constexpr (KW == 3) asm volatile("" : "+v"(b2[d]));                                                            \
+    else asm volatile("" : "+v"(b4b[d]));                                                                             \
+    const float Lw[8] = {b4[d].x, b4[d].y, b4[d].z, b4[d].w, KW == 3 ? b2[d].x : b4b[d].x, KW == 3 ? b2[d].y : b4b[d].y, \
+                         b4b[d].z, b4b[d].w};                                                                         \
+    float X[W];                                                                                                       \
+    if (edge) {                                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < W; i++) {                                                                 \
+        float v = Lw[i];                                                                                              \
+        _Pragma("unroll") for (int s2 = 1; s2 <= PAD; s2++) v = sh == s2 ? (i - s2 >= 0 ? Lw[i - s2 >= 0 ? i - s2 : 0] : 0.f) : v; \
+        X[i] = ((vmask >> i) & 1u) ? v : 0.f;                                                                         \
+      }                                                                                                               \
+    } else {                                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < W; i++) X[i] = Lw[i];                                                     \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < W; i++) X[i] = X[i] >= 0.f ? X[i] : alpha * X[i];                           \
+    _Pragma("unroll") for (int q = 0; q < 2; q++) {                                                                   \
+      float V[NX];                                                                                                    \
+      wino_bt<KW>(X + 2 * q, V);                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < TM; i++)                                                                  \
+        _Pragma("unroll") for (int x = 0; x < NX; x++) {                                                              \
+          const float av = x == 0 ? a4[d][i].x : (x == 1 ? a4[d][i].y : (x == 2 ? a4[d][i].z : (x == 3 ? a4[d][i].w : (x == 4 ? a2[d][i].x : a2[d][i].y)))); \
+          acc[i][q][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, V[x], acc[i][q][x], 0, 0, 0);                       \
+        }                                                                                                             \
+    }                                                                                                                 \
+  }
+  extern __shared__ __attribute__((aligned(16))) float smem3[];
+  constexpr int NDMA = 4 * TM;
+  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+  const size_t ybase = (size_t)b * p.Cout * p.Tout;
+  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+  const int c0 = n0 + TN * l15;
+  int ncol = p.Nq - c0;
+  if (ncol > 4) ncol = 4;
+  const bool vec4 = ncol == 4;
+  const float* pre = p.res ? p.res : p.add;  // the operand that is prefetched (PRE: see conv_direct3_kernel)
+  constexpr bool pre_on = PRE;
+  float* const slab = smem3 + wv * (NDMA * 256);
+  {
+    OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
+    const int NR = NG / 4;
+    for (int r = 0; r + 1 < NR; r++) {
+      const int g = r * 4;
+      OU_MMA(0, 3); OU_ISSUE(g + 4, 0);
+      OU_MMA(1, 3); OU_ISSUE(g + 5, 1);
+      OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
+      OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
+    }
+    if constexpr (PRE) {
+      const __amdgpu_buffer_rsrc_t rp = make_rsrc(pre + ybase, (unsigned)p.Cout * (unsigned)p.Tout * 4u);
+      const int pvo = ncol > 0 ? ((m0 + 4 * kk) * p.Tout + c0) * 4 : (int)0x80000000;
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          dma_b128(rp, slab + (4 * i + r) * 256, pvo, (16 * i + r) * p.Tout * 4);
+      asm volatile("" ::: "memory");
+      OU_MMAX(0, 3, NDMA); OU_MMAX(1, 2, NDMA); OU_MMAX(2, 1, NDMA); OU_MMAX(3, 0, NDMA);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
+    }
+  }
+#undef OU_ISSUE
+#undef OU_MMA
+#undef OU_MMAX
+
+  // ---- epilogue: A^T, then bias, cond add, FiLM, residual -- straight from the accumulators, 16 bytes per lane and row
+  if (ncol > 0) {
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+      f32x4 ad[4], rs[4];
+      float bi[4], ga[4], be[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + 16 * i + 4 * kk + r;
+        const bool on = row < p.M;
+        const size_t idx = ybase + (size_t)(on ? row : 0) * p.Tout + c0;
+        ad[r] = f32x4{0.f, 0.f, 0.f, 0.f}; rs[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bi[r] = on ? p.bias[row] : 0.f;
+        ga[r] = 1.f; be[r] = 0.f;
+        if (on && filmb) { ga[r] = filmb[row]; be[r] = filmb[p.Cout + row]; }
+        if (on && vec4) {
+          const f32x4 pq = pre_on ? *reinterpret_cast<const f32x4*>(slab + (4 * i + r) * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.add) ad[r] = (pre_on && !p.res) ? pq : f32x4(*reinterpret_cast<const f32x4u*>(p.add + idx));
+          if (p.res) rs[r] = pre_on ? pq : f32x4(*reinterpret_cast<const f32x4u*>(p.res + idx));
+        } else if (on) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (p.add && j < ncol) ad[r][j] = p.add[idx + j];
+            if (p.res && j < ncol) rs[r][j] = p.res[idx + j];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + 16 * i + 4 * kk + r;
+        if (row >= p.M) continue;
+        const size_t idx = ybase + (size_t)row * p.Tout + c0;
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          if constexpr (KW == 3) {
+            v[2 * q] = acc[i][q][0][r] + acc[i][q][1][r] + acc[i][q][2][r];
+            v[2 * q + 1] = acc[i][q][1][r] - acc[i][q][2][r] - acc[i][q][3][r];
+          } else {
+            v[2 * q] = acc[i][q][0][r] + acc[i][q][1][r] + acc[i][q][2][r] + acc[i][q][3][r] + acc[i][q][4][r];
+            v[2 * q + 1] = acc[i][q][1][r] - acc[i][q][2][r] + 0.5f * acc[i][q][3][r] - 2.0f * acc[i][q][4][r] + acc[i][q][5][r];
+          }
+        }
+        if (p.in_scale) v *= insc;
+        v += bi[r];
+        if (p.add) v = (v + ad[r]) * p.add_scale;
+        if (filmb) v = ga[r] * v + be[r];
+        if (p.res) v = (v + rs[r]) * p.res_scale;
+        if (vec4) {
+          *reinterpret_cast<f32x4u*>(p.y + idx) = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (j < ncol) p.y[idx + j] = v[j];
+        }
+      }
+    }
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // conv_direct3s_kernel<R>: the same per-wave scheme for the layers WITHOUT a taps-innermost weight copy, many columns:
 //   R = 1: 1x1 convs and transposed convs as `up` phase GEMMs (row m = co * up + phase);
 //   R > 1: rate-change (down) convs, k = s = R, whole frames (Tin = Nq * R).
@@ -436,7 +644,9 @@ hipError_t init_direct3_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern_pre), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
   }
-  return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct3w_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct3w_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
 // rows per wave tile (in units of 16) for a layer with M output channels: exact tiling where 16-row granularity allows it
 static int direct3_tm(int M) {
@@ -520,7 +730,11 @@ hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t stream
   // PP24 C = 384 at B = 8 (2.4 -> 4.8 tiles per SIMD) 355 / 222 -> 305 / 190 us, PP16 C = 64 at B = 8 (3.9 -> 7.8) 109 / 68 -> 104 / 64;
   // even at 5.9 tiles per SIMD (PP24 C = 192) the two are equal.
   if (tm > 2 && a.M % 32 == 0 && (double)((a.M + 16 * tm - 1) / (16 * tm)) * ct * a.B / (4.0 * num_cu) < 3.0) tm = 2;
-  if (a.force_cfg >= 200) tm = (a.force_cfg / 10) % 10;
+  // minimal filtering (conv_direct3w_kernel: 32-row tiles) wherever the rows tile by 32: 2/3 (k3) / 3/5 (k5) of the MFMAs
+  bool wino = a.wino && a.direct >= 5 && a.wu && a.M % 32 == 0;
+  if (a.force_cfg >= 200) { tm = (a.force_cfg / 10) % 10; wino = false; }
+  if (a.force_cfg >= 280 && a.force_cfg < 290 && a.wu) { tm = 2; wino = true; }  // 28x: the minimal-filtering form (tests / sweeps)
+  if (wino) tm = 2;
   if (tm < 2 || tm > 4) return hipErrorInvalidConfiguration;
   const long gy = (a.M + 16 * tm - 1) / (16 * tm);
   const double per_simd = (double)gy * ct * a.B / (4.0 * num_cu);
@@ -528,14 +742,18 @@ hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t stream
   // 4 waves x 4 TM KB of LDS for the prefetched epilogue operand (OU_TILE_PREFETCH=0 switches it off)
   const bool prefetch = (a.res || a.add) && (a.Tout & 3) == 0 && a.tile_prefetch != 0;
   void (*kern)(ConvArgs) = nullptr;
-  for (const Direct3Cfg& c : kDirect3Cfgs)
-    if (c.KW == a.KW && c.TM == tm) { kern = prefetch ? c.kern_pre : c.kern; break; }
+  if (wino)
+    kern = a.KW == 3 ? (prefetch ? conv_direct3w_kernel<3, true> : conv_direct3w_kernel<3, false>)
+                     : (prefetch ? conv_direct3w_kernel<5, true> : conv_direct3w_kernel<5, false>);
+  else
+    for (const Direct3Cfg& c : kDirect3Cfgs)
+      if (c.KW == a.KW && c.TM == tm) { kern = prefetch ? c.kern_pre : c.kern; break; }
   if (!kern) return hipErrorInvalidConfiguration;
   ConvArgs aa = a;
   aa.grid_m = (int)gy;
   const long chunks = (ct + 3) / 4, total8 = (chunks * a.B + 7) / 8 * 8;
   aa.grid_n = (int)chunks;
-  if (cfg_out) *cfg_out = 200 + 10 * tm + a.KW;
+  if (cfg_out) *cfg_out = wino ? 280 + a.KW : 200 + 10 * tm + a.KW;
   const size_t smem = prefetch ? (size_t)4 * 4 * tm * 1024 : 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)(total8 * gy)), dim3(256), smem, stream, aa);
   return hipGetLastError();

@@ -99,4 +99,30 @@ __device__ __forceinline__ u32x4 direct_desc(const void* base, unsigned bytes) {
 
 __device__ __forceinline__ float prelu(float v, float a) { return v >= 0.f ? v : a * v; }
 
+// Input transform V = B^T d of the minimal-filtering kernels (conv_direct2w_kernel, conv_direct3w_kernel): d = KW + 1 consecutive
+// samples of one channel, V = the KW + 1 values that meet U = G w (ou_model.cpp) in the element-wise products.
+//   F(2, 3), points 0, 1, -1, inf:        rows [1 0 -1 0] [0 1 1 0] [0 -1 1 0] [0 1 0 -1]
+//   F(2, 5), points 0, 1, -1, 1/2, -2, inf, rows scaled to small integers (the scale is in G):
+//            [2 -3 -4 3 2 0] [0 -2 1 5 2 0] [0 -2 5 -1 -2 0] [0 2 1 -2 -1 0] [0 1 -2 -1 2 0] [0 2 -3 -4 3 2]
+// A^T (applied to the accumulators): F(2, 3): y0 = M0 + M1 + M2, y1 = M1 - M2 - M3;
+//   F(2, 5): y0 = M0 + M1 + M2 + M3 + M4, y1 = M1 - M2 + M3 / 2 - 2 M4 + M5.   tests/test_packing.py holds the three against
+// the convolution they must reproduce.
+template <int KW>
+__device__ __forceinline__ void wino_bt(const float* X, float (&V)[KW + 1]) {
+  if constexpr (KW == 3) {
+    V[0] = X[0] - X[2];
+    V[1] = X[1] + X[2];
+    V[2] = X[2] - X[1];
+    V[3] = X[1] - X[3];
+  } else {
+    const float p13 = X[1] - X[3], p24 = X[2] - X[4];
+    V[3] = fmaf(2.f, p13, p24);
+    V[4] = fmaf(-2.f, p24, p13);
+    V[1] = fmaf(5.f, X[3], fmaf(2.f, X[4] - X[1], X[2]));
+    V[2] = fmaf(5.f, X[2], fmaf(-2.f, X[1] + X[4], -X[3]));
+    V[0] = fmaf(-4.f, X[2], fmaf(3.f, X[3] - X[1], 2.f * (X[0] + X[4])));
+    V[5] = fmaf(-4.f, X[3], fmaf(3.f, X[4] - X[2], 2.f * (X[1] + X[5])));
+  }
+}
+
 }  // namespace ou

@@ -582,6 +582,29 @@ def test_throughput_conv_kernel_matches_split_k_kernels(name, B, T, monkeypatch)
     assert n_conv > 0
 
 
+@pytest.mark.parametrize("name,B,T", [("PP16m", 3, 3000), ("PP16", 2, 8000), ("PP24", 1, 9000), ("OR16", 2, 5000), ("PP16", 4, 2077)])
+def test_minimal_filtering_throughput_kernel_matches_the_plain_one(name, B, T, monkeypatch):
+    """conv_direct3w_kernel (no split-K, F(2, 3) / F(2, 5): a lane's four adjacent columns are two tile positions, 2 x 2 x (KW + 1)
+    MFMAs per ring slot instead of 2 x 4 x KW) forced onto every layer it fits (OU_TILE_MIN=0, unfused ConvBlock bodies) against
+    conv_direct3_kernel on the same layers (OU_CONV_DIRECT=4) and against the oracle.  Ragged lengths: partial column tiles,
+    shifted / masked windows under the input transform, rows that are not 16-byte multiples (no prefetched operand)."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(67, 3, B, Tp)
+    monkeypatch.setenv("OU_TILE_MIN", "0")
+    monkeypatch.setenv("OU_FUSE", "0")
+    monkeypatch.setenv("OU_CONV_DIRECT", "4")
+    ref = run_enhance(model, mix, nz, n_steps=3)
+    monkeypatch.delenv("OU_CONV_DIRECT")
+    out = run_enhance(model, mix, nz, n_steps=3)
+    assert torch.equal(out, run_enhance(model, mix, nz, n_steps=3))
+    assert not torch.equal(out, ref), "the minimal-filtering kernels did not run"
+    record(f"direct3w_vs_direct3.{name}.b{B}", O.si_sdr(ref, out), 85)
+    e_ref = O.enhance(sd, spec.to_dict(), mix, n_steps=3, noise=nz)
+    record(f"direct3w_vs_oracle.{name}.b{B}", O.si_sdr(e_ref, out.cpu()), 80)
+
+
 @pytest.mark.skipif(not experiments_built(), reason="conv_block3_kernel is in `make EXPERIMENTS=1` builds only")
 @pytest.mark.parametrize("T", [64000, 7213])
 def test_fused_deep_convblock_is_bit_identical(T, monkeypatch):

@@ -49,6 +49,8 @@ for lname, Tin in layers:
     variants = [("auto", -1, None), ("direct3", forced, None), ("r2", -1, "2")]
     if KW in (3, 5) and stride == 1 and tm == 4:
         variants += [("tm2", 200 + 20 + KW, None), ("tm3", 200 + 30 + KW, None)]
+    if KW in (3, 5) and stride == 1:
+        variants += [("wino", 280 + KW, None), ("plain", -1, "4")]
     for tag, cfg, env in variants:
         if env is not None:
             os.environ["OU_CONV_DIRECT"] = env
