@@ -600,7 +600,7 @@ def main():
         # 40-49: rate_down_kernel,
         # 66 / 76 / 67 / 77: conv_direct2_kernel, 78 / 79: conv_direct2w_kernel, other 50-99: conv_direct_kernel / conv_direct_strided_kernel variants,
         # 100-199: conv_chain_kernel (fused ConvBlock body), 200-299: conv_direct3_kernel (2xx: 200 + 10 TM + KW) /
-        # conv_direct3s_kernel (260 + R), 300-399: conv_direct4_kernel (300 + 10 TM + log2 WK), >= 1000: one GRU pass
+        # conv_direct3s_kernel (260 + R), 500-599: conv_direct3w_kernel (500 + 10 TM + KW), 300-399: conv_direct4_kernel (300 + 10 TM + log2 WK), >= 1000: one GRU pass
         # (1000 + steps).
         gru_recs = [r for r in recs if r[3] >= 1000]
         recs = [r for r in recs if r[3] < 1000]
@@ -618,7 +618,8 @@ def main():
                     "algorithmic_bytes_per_launch": by_ / len(rr)}
         KERNELS = {
             "direct2": "ou::conv_direct2_kernel / conv_direct2w_kernel (register-direct split-K fp32-MFMA Conv1d, wide operand loads: "
-                       "k3 / k5 layers; the w form with minimal filtering F(2, 3) / F(2, 5) on 64-column tiles)",
+                       "k3 / k5 layers; the w forms with minimal filtering F(2, 3) / F(2, 5): conv_direct2w_kernel on 64-column tiles, "
+                       "conv_direct4w_kernel on 16 / 32-row tiles for the 401-frame levels)",
             "direct": "ou::conv_direct_kernel / conv_direct_strided_kernel (first-generation register-direct split-K, dword "
                       "operand loads: 1x1, phase-GEMM and rate-change convs of the 401-frame levels at batch 1 - 2)",
             "direct4": "ou::conv_direct4_kernel (wide-load split-K: 1x1, phase-GEMM and rate-change convs; 16x16x4 fp32 MFMA, "
@@ -626,16 +627,19 @@ def main():
             "lds": "ou::conv_mfma_kernel (LDS-tiled fp32-MFMA implicit-GEMM Conv1d, wide levels / strided convs)",
             "rate": "ou::rate_down_kernel / rate_up_kernel (outermost rate-change convs with the anti-alias FIR fused, K = 64)",
             "chain": "ou::conv_chain_kernel (fused ConvBlock body, C = 32 / 64 levels)",
-            "direct3": "ou::conv_direct3_kernel / conv_direct3s_kernel (no-split-K throughput kernels: one (16 TM) x 64 tile per "
-                       "wave over the whole reduction, 16x16x4 fp32 MFMA, register-direct operands, stores from the accumulators)",
+            "direct3": "ou::conv_direct3_kernel / conv_direct3w_kernel / conv_direct3s_kernel (no-split-K throughput kernels: one "
+                       "(16 TM) x 64 tile per wave over the whole reduction, 16x16x4 fp32 MFMA, register-direct operands, stores from "
+                       "the accumulators; the w form with minimal filtering F(2, 3) / F(2, 5))",
         }
-        D2 = (66, 76, 67, 77, 78, 79)  # conv_direct2_kernel (8 / 4 K slices) and its minimal-filtering form conv_direct2w_kernel
+        # conv_direct2_kernel (8 / 4 K slices), its minimal-filtering form conv_direct2w_kernel, and conv_direct4w_kernel
+        # (6xx / 7xx: the same layers on 16 / 32-row tiles where there are few columns)
+        D2 = (66, 76, 67, 77, 78, 79) + tuple(range(600, 800))
         groups = {"direct2": summarise([r for r in recs if r[3] in D2]),
                   "direct": summarise([r for r in recs if 50 <= r[3] < 100 and r[3] not in D2]),
                   "lds": summarise([r for r in recs if r[3] < 40]),
                   "rate": summarise([r for r in recs if 40 <= r[3] < 50]),
                   "chain": summarise([r for r in recs if 100 <= r[3] < 200]),
-                  "direct3": summarise([r for r in recs if 200 <= r[3] < 300]),
+                  "direct3": summarise([r for r in recs if 200 <= r[3] < 300 or 500 <= r[3] < 600]),
                   "direct4": summarise([r for r in recs if 300 <= r[3] < 400])}
         groups = {k: v for k, v in groups.items() if v}
         fam = summarise([r for r in recs if (50 <= r[3] < 100 and r[3] not in D2) or 300 <= r[3] < 400 or 260 <= r[3] < 270])

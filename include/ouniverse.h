@@ -211,6 +211,12 @@ int ou_set_lanes(ou_handle* h, int32_t lanes, int32_t lane);
  * takes 8 -- equal to fp32 rounding (> 100 dB), not bit-identical; calls of size max_batch are unchanged. */
 int ou_set_lane_batch(ou_handle* h, int32_t max_batch);
 
+/* How many lanes this device can carry when every lane may run a call of `max_batch` utterances: the GRU launches of all
+ * lanes must be resident together (1 .. 8; e.g. UNIVERSE++ 16 kHz, H = 256: 8 lanes up to batch 2, 4 lanes at batch 4, 2 at
+ * batch 8).  A pool larger than this makes the forward calls fail with OU_EHIP ("invalid configuration") -- the Python pool
+ * (lanes.LanePool) clamps itself to this number. */
+int ou_lane_capacity(const ou_handle* h, int32_t max_batch);
+
 /* After the stream has been synchronised: OU_OK, or OU_ESYNC if a device-side timeout flag was raised.  The status
  * word (first 4 bytes of the workspace) is sticky: it stays raised until ou_workspace_init() / this call clears it.
  * Also reads status word 33 -- GRU publishes that were INVISIBLE to the gather's agent-scope loads (the recovery counter,

@@ -105,6 +105,7 @@ def load():
         "ou_get_gru_publish_mode": (i32, [vp]),
         "ou_set_lanes": (i32, [vp, i32, i32]),
         "ou_set_lane_batch": (i32, [vp, i32]),
+        "ou_lane_capacity": (i32, [vp, i32]),
         "ou_transform_frames": (i32, [i32, i32, i32]),
         "ou_transform_forward": (i32, [vp, i32, i32, vp, i32, i32, i32, c_float, c_float, vp, vp]),
         "ou_transform_inverse": (i32, [vp, i32, i32, vp, i32, i32, i32, c_float, c_float, i32, vp, vp, vp]),
@@ -126,7 +127,7 @@ EXPORTED_SYMBOLS = [
     "ou_packer_destroy", "ou_packed_bytes", "ou_create", "ou_destroy", "ou_workspace_bytes", "ou_schedule",
     "ou_condition", "ou_score", "ou_aux_to_wav", "ou_enhance", "ou_check_device_status", "ou_plan_json",
     "ou_packer_plan_json", "ou_tensor", "ou_launch_stats", "ou_workspace_init", "ou_sampler_step",
-    "ou_set_gru_publish_mode", "ou_get_gru_publish_mode", "ou_set_lanes", "ou_set_lane_batch",
+    "ou_set_gru_publish_mode", "ou_get_gru_publish_mode", "ou_set_lanes", "ou_set_lane_batch", "ou_lane_capacity",
     "ou_transform_frames", "ou_transform_forward", "ou_transform_inverse",
 ]
 TUNING_SYMBOLS = ["ou_profile_enable", "ou_profile_read", "ou_profile_read_ticks", "ou_bench_conv",

@@ -107,7 +107,7 @@ struct Tensor {
 // Tuning / debug switches, read ONCE per C-ABI call: a forward walks ~400 launches and used to call getenv
 // eight times for each of them (a linear scan of the environment: a third of the host time of an enhance call).
 struct EnvCfg {
-  int dbg = 0, xcd_map = -1, conv_direct = 5, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1, d4_force = 0, d4_short = 1, d2_wk = 0, wino = 1, d2_map = -1;
+  int dbg = 0, xcd_map = -1, conv_direct = 5, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1, d4_force = 0, d4_short = 1, d2_wk = 0, wino = 1, d2_map = -1, unfuse64 = 0;
   int gru_v = 2, gru_bmax = 0, gru_ts = 0, gru_upw = 0, gru_backoff = 0, gru_agent = -1, gru_dbg = 0;
   int dbg_dec0_under_gru = 0;  // OU_DBG_DEC0: measurement only, INVALID results (see run_score)
   double tile_min = -1.0;  // < 0: the launcher's default
@@ -124,6 +124,7 @@ struct EnvCfg {
     d2_wk = geti("OU_D2_WK", 0);
     wino = geti("OU_WINO", 1);
     d2_map = geti("OU_D2_MAP", -1);
+    unfuse64 = geti("OU_UNFUSE64", 0);
     block3 = geti("OU_BLOCK3", 0);
     gru_v = geti("OU_GRU_V", 2); gru_bmax = geti("OU_GRU_BMAX", 0); gru_ts = std::getenv("OU_GRU_TS") ? 1 : 0;
     gru_upw = geti("OU_GRU_UPW", 0); gru_backoff = geti("OU_GRU_BACKOFF", 0); gru_agent = geti("OU_GRU_AGENT_STORES", -1);
@@ -309,6 +310,10 @@ struct Runner {
     // even); below that the fused launch wins (B = 1: 24 us for all three convs).
     if (h->fuse_mode < 0 && Bk.C % 16 == 0 && Bk.c1.KWP && Bk.c2.KWP && Bk.c3.KWP) {
       if (env.conv_direct >= 3 && direct3_tiles_per_simd(Bk.C, T, B, h->num_cu) >= 1.9 && T >= 1024) return 0;
+      // Round 5, measured and left off: with minimal filtering the three split-K launches of a 64-channel body (17.0 + 11.7 +
+      // 11.7 us at B = 1, back to back) look level with conv1 + the fused pair (17.0 + 24.8) -- end to end the unfused form is
+      // 0.04-0.07 ms per enhance SLOWER (6.88-6.91 vs 6.83-6.85 ms, three alternating runs).  OU_UNFUSE64=1 selects it.
+      if (env.unfuse64 && env.conv_direct >= 5 && env.wino && Bk.C % 64 == 0 && T >= 1024) return 0;
     }
     auto shape = [&](int depth) {
       ChainArgs ca;
@@ -1229,6 +1234,20 @@ int ou_set_lanes(ou_handle* h, int32_t lanes, int32_t lane) {
   h->lanes = lanes;
   h->lane = lane;
   return OU_OK;
+}
+
+int ou_lane_capacity(const ou_handle* h, int32_t max_batch) {
+  if (!h || max_batch < 1) return 0;
+  // the largest number of lanes whose GRU launches -- every lane at `max_batch` -- can all be resident at the same time
+  const Model& m = h->m;
+  for (int lanes = 8; lanes >= 1; lanes--) {
+    const int share = Runner::gru_share_of(lanes, max_batch, false);
+    bool ok = true;
+    for (int H : {m.s_gru.H, m.c_gru0.H, m.c_gru1.H})
+      if (H > 0 && gru_ring_batch_cap(H, h->num_cu, share, 0, max_batch, lanes) < 1) ok = false;
+    if (ok) return lanes;
+  }
+  return 1;
 }
 
 int ou_set_lane_batch(ou_handle* h, int32_t max_batch) {

@@ -239,9 +239,9 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
 // four adjacent samples exactly as before.  32-row tiles only (TM = 2): the accumulators of a 64-row tile would not leave room
 // for the ring (k3: 64 + 56 ring registers at TM = 2, 128 + 88 at TM = 4).
 // ---------------------------------------------------------------------------------------------------------
-template <int KW, bool PRE>
+template <int KW, int TM, bool PRE>
 __global__ __launch_bounds__(256, 2) void conv_direct3w_kernel(ConvArgs p) {
-  constexpr int D = 4, TM = 2, TN = 4, NX = KW + 1, W = KW + TN - 1, KWP = KW == 3 ? 4 : 8, PAD = (KW - 1) / 2;
+  constexpr int D = 4, TN = 4, NX = KW + 1, W = KW + TN - 1, KWP = KW == 3 ? 4 : 8, PAD = (KW - 1) / 2;
   constexpr int A2 = KW == 5 ? 1 : 0;       // second A load per row tile (U_4, U_5)
   constexpr int LPS = TM * (1 + A2) + 2;    // load instructions per ring slot
   static_assert(KW == 3 || KW == 5, "k3 / k5");
@@ -639,14 +639,24 @@ static const Direct3Cfg kDirect3Cfgs[] = {
     // ring depth 4 only: the depth-2 instantiations come out of the compiler with MORE registers (240-256, spills)
     OU_D3(3, 2, 4), OU_D3(3, 3, 4), OU_D3(3, 4, 4), OU_D3(5, 2, 4), OU_D3(5, 3, 4), OU_D3(5, 4, 4),
 };
+struct Direct3wCfg {
+  int KW, TM;
+  void (*kern)(ConvArgs);
+  void (*kern_pre)(ConvArgs);
+};
+#define OU_D3W(KW, TM) {KW, TM, conv_direct3w_kernel<KW, TM, false>, conv_direct3w_kernel<KW, TM, true>}
+// (k3 at 64 rows and k5 at 48 rows do not fit the register file: 256 VGPRs + scratch)
+static const Direct3wCfg kDirect3wCfgs[] = {OU_D3W(3, 1), OU_D3W(3, 2), OU_D3W(3, 3), OU_D3W(5, 1), OU_D3W(5, 2)};
 hipError_t init_direct3_kernels() {
   for (const Direct3Cfg& c : kDirect3Cfgs) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern_pre), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct3w_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct3w_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  for (const Direct3wCfg& c : kDirect3wCfgs) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern_pre), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 // rows per wave tile (in units of 16) for a layer with M output channels: exact tiling where 16-row granularity allows it
 static int direct3_tm(int M) {
@@ -721,8 +731,13 @@ hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t stream
   // ~1 tile per SIMD, +8 .. +60 % from 1.5 up, 2-3x slower at 0.25; OU_TILE_MIN: tuning / tests, 0 = wherever it fits)
   const double tile_min = a.tile_min >= 0 ? a.tile_min : 1.2;
   // short signals (the T / 160 level: 401 frames = 6.3 column tiles per element) waste the last tile and supply few
-  // chunks; the split-K kernels keep them whatever the batch (B = 8: 54 vs 107 us on the latent k3 convs)
-  if (tile_min > 0 && a.Nq < 1024 && a.force_cfg < 200) return hipErrorInvalidConfiguration;
+  // chunks; the split-K kernels keep them whatever the batch (B = 8: 54 vs 107 us on the latent k3 convs) -- except the k5
+  // layers in their minimal-filtering form from ~0.85 wave tiles per SIMD (PP16 B = 8: 76.5 vs 89.1 us; k3 50.5 vs 54.4 there
+  // but 116 vs 109 us on PP24's 768 channels: k5 only)
+  const bool wino_ok = a.wino && a.direct >= 5 && a.wu && a.M % 16 == 0;
+  const bool short_k5 = wino_ok && a.KW == 5 && a.M % 32 == 0 &&
+                        (double)(a.M / 32) * ((a.Nq + 63) / 64) * a.B / (4.0 * num_cu) >= 0.85;
+  if (tile_min > 0 && a.Nq < 1024 && a.force_cfg < 200 && !short_k5) return hipErrorInvalidConfiguration;
   int tm = direct3_tm(a.M);
   const long ct = (a.Nq + 63) / 64;
   // 32-row tiles where the preferred ones leave fewer than ~3 wave tiles per SIMD (and M tiles by 32): twice the waves, half the
@@ -731,29 +746,31 @@ hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t stream
   // even at 5.9 tiles per SIMD (PP24 C = 192) the two are equal.
   if (tm > 2 && a.M % 32 == 0 && (double)((a.M + 16 * tm - 1) / (16 * tm)) * ct * a.B / (4.0 * num_cu) < 3.0) tm = 2;
   // minimal filtering (conv_direct3w_kernel: 32-row tiles) wherever the rows tile by 32: 2/3 (k3) / 3/5 (k5) of the MFMAs
-  bool wino = a.wino && a.direct >= 5 && a.wu && a.M % 32 == 0;
+  // minimal filtering: 32-row tiles (16-row tiles where the rows only tile by 16: PP24's 48 channels, 165 vs 184 us)
+  bool wino = wino_ok;
+  if (wino) tm = a.M % 32 == 0 ? 2 : 1;
   if (a.force_cfg >= 200) { tm = (a.force_cfg / 10) % 10; wino = false; }
-  if (a.force_cfg >= 280 && a.force_cfg < 290 && a.wu) { tm = 2; wino = true; }  // 28x: the minimal-filtering form (tests / sweeps)
-  if (wino) tm = 2;
-  if (tm < 2 || tm > 4) return hipErrorInvalidConfiguration;
+  if (a.force_cfg >= 500 && a.force_cfg < 600 && a.wu) wino = true;  // 500 + 10 TM + KW: the minimal-filtering form (tests / sweeps)
+  if (tm < (wino ? 1 : 2) || tm > 4) return hipErrorInvalidConfiguration;
   const long gy = (a.M + 16 * tm - 1) / (16 * tm);
   const double per_simd = (double)gy * ct * a.B / (4.0 * num_cu);
-  if (a.force_cfg < 200 && per_simd < tile_min) return hipErrorInvalidConfiguration;
+  if (a.force_cfg < 200 && per_simd < (short_k5 && a.Nq < 1024 ? 0.85 : tile_min)) return hipErrorInvalidConfiguration;
   // 4 waves x 4 TM KB of LDS for the prefetched epilogue operand (OU_TILE_PREFETCH=0 switches it off)
   const bool prefetch = (a.res || a.add) && (a.Tout & 3) == 0 && a.tile_prefetch != 0;
   void (*kern)(ConvArgs) = nullptr;
-  if (wino)
-    kern = a.KW == 3 ? (prefetch ? conv_direct3w_kernel<3, true> : conv_direct3w_kernel<3, false>)
-                     : (prefetch ? conv_direct3w_kernel<5, true> : conv_direct3w_kernel<5, false>);
-  else
+  if (wino) {
+    for (const Direct3wCfg& c : kDirect3wCfgs)
+      if (c.KW == a.KW && c.TM == tm) { kern = prefetch ? c.kern_pre : c.kern; break; }
+  } else {
     for (const Direct3Cfg& c : kDirect3Cfgs)
       if (c.KW == a.KW && c.TM == tm) { kern = prefetch ? c.kern_pre : c.kern; break; }
+  }
   if (!kern) return hipErrorInvalidConfiguration;
   ConvArgs aa = a;
   aa.grid_m = (int)gy;
   const long chunks = (ct + 3) / 4, total8 = (chunks * a.B + 7) / 8 * 8;
   aa.grid_n = (int)chunks;
-  if (cfg_out) *cfg_out = wino ? 280 + a.KW : 200 + 10 * tm + a.KW;
+  if (cfg_out) *cfg_out = (wino ? 500 : 200) + 10 * tm + a.KW;
   const size_t smem = prefetch ? (size_t)4 * 4 * tm * 1024 : 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)(total8 * gy)), dim3(256), smem, stream, aa);
   return hipGetLastError();

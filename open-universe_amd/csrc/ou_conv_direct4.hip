@@ -296,6 +296,244 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_direct4_kernel(ConvArgs p) 
   if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// conv_direct4w_kernel<KW, TM, WK>: the stride-1 k3 / k5 layers with FEW output columns (the 401-frame levels at batch 1) in
+// minimal-filtering form, F(2, KW) (round 5; scheme and numerics: conv_direct2w_kernel).  conv_direct2w_kernel needs 64-column
+// tiles of 32 rows -- 112 blocks for a 512 x 401 layer, less than half the chip; its plain form with 32-column tiles gets 208
+// and runs its loop at 77 % of the matrix pipe on 2 KB of L1 traffic per three MFMAs.  Here: conv_direct3w_kernel's operands
+// (v_mfma_f32_16x16x4_f32: a lane's four adjacent columns are two tile positions, A lane (m, kk) loads the KW + 1 values U_x of
+// (row m0 + 16 i + m, channel 4 J + kk), B lane (n, kk) the KW + 3 samples of its window) on (16 TM) x 64 wave tiles, the
+// reduction split over the WK waves of a block (slot g of wave wk = channel group wk + WK g) and conv_direct4_kernel's epilogue
+// (A^T in registers, 16-byte LDS writes into a per-wave slab, K slices summed on read, 16-byte stores).  16-row tiles: 32 x 7 =
+// 224 blocks for 512 x 401, one per CU; per ring slot 2 (KW + 1) MFMAs of 32 cycles on 2.5 / 3.5 KB of operands -- 2/3 (3/5) of
+// the matrix-pipe time and 5/8 of the L1 traffic of the kernel it replaces.
+// ---------------------------------------------------------------------------------------------------------
+template <int KW, int TM, int WK>
+__global__ __launch_bounds__(64 * WK) void conv_direct4w_kernel(ConvArgs p) {
+  constexpr int D = 4, TN = 4, NX = KW + 1, W = KW + TN - 1, KWP = KW == 3 ? 4 : 8, PAD = (KW - 1) / 2, BM = 16 * TM, EP = 68;
+  constexpr int A2 = KW == 5 ? 1 : 0;
+  constexpr int LPS = TM * (1 + A2) + 2;
+  static_assert(KW == 3 || KW == 5, "k3 / k5");
+  static_assert(D * LPS <= 60, "loads in flight must fit vmcnt");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // block -> tile: row groups are dealt to the XCDs (the weights are the larger operand on these levels), the blocks of an XCD
+  // walk the column tiles of ITS row groups (xcd_map 1 of conv_direct4_kernel)
+  const int L = blockIdx.x, q8 = L >> 3;
+  const int gm8 = (p.grid_m + 7) >> 3;
+  const int rg = (q8 % gm8) * 8 + (L & 7), cidx = q8 / gm8;
+  const int b = cidx / p.grid_n, chunk = cidx - b * p.grid_n;
+  const int n0 = chunk * 64, m0 = rg * BM;
+  if (b >= p.B || rg >= p.grid_m) return;  // (block-uniform)
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const int l15 = lane & 15, kk = lane >> 4;
+  const int Tin = p.Tin, Mp = p.Mp;
+  const float alpha = p.act ? p.alpha_val : 1.0f;
+  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  const u32x4 rw = direct_desc(p.wu, (unsigned)p.Cin * (unsigned)Mp * (unsigned)KWP * 4u);
+  const int avo = (kk * Mp + m0 + l15) * KWP * 4;
+  const int t0 = n0 + TN * l15 - PAD;
+  const int sh = t0 < 0 ? -t0 : 0;
+  const int bvo = (t0 + sh < Tin) ? (kk * Tin + t0 + sh) * 4 : (int)0x80000000;
+  const bool edge = __builtin_amdgcn_readfirstlane((n0 < PAD || n0 + 64 + KW - 1 - PAD > Tin) ? 1 : 0) != 0;
+  unsigned vmask = 0;  // bit i: window element i is inside the row
+#pragma unroll
+  for (int i = 0; i < W; i++) vmask |= (t0 + i >= 0 && t0 + i < Tin) ? (1u << i) : 0u;
+
+  const int NS = (p.Cin >> 2) / WK;  // ring slots of this wave (launcher: a multiple of D)
+  f32x4 a4[D][TM], b4[D], b4b[D];
+  f32x2 a2[D][TM], b2[D];
+#pragma unroll
+  for (int d0 = 0; d0 < D; d0++) {
+#pragma unroll
+    for (int i = 0; i < TM; i++) { a4[d0][i] = f32x4{0.f, 0.f, 0.f, 0.f}; a2[d0][i] = f32x2{0.f, 0.f}; }
+    b4[d0] = f32x4{0.f, 0.f, 0.f, 0.f}; b4b[d0] = f32x4{0.f, 0.f, 0.f, 0.f}; b2[d0] = f32x2{0.f, 0.f};
+  }
+  f32x4acc acc[TM][2][NX];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int x = 0; x < NX; x++) acc[i][q][x] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+
+#define OU_ISSUE(g_, d)                                                                                               \
+  {                                                                                                                   \
+    const int c4 = (wk + WK * (g_)) * 4;                                                                              \
+    const int aso = c4 * Mp * KWP * 4, xso = c4 * Tin * 4;                                                            \
+    _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                  \
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"                                               \
+                   : "+v"(a4[d][i]) : "v"(avo), "s"(rw), "s"(aso), "n"(i * 16 * KWP * 4));                            \
+      if constexpr (A2 == 1)                                                                                          \
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4"                                             \
+                     : "+v"(a2[d][i]) : "v"(avo), "s"(rw), "s"(aso), "n"(i * 16 * KWP * 4 + 16));                     \
+    }                                                                                                                 \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(b4[d]) : "v"(bvo), "s"(rx), "s"(xso));             \
+    if constexpr (KW == 3)                                                                                            \
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:16" : "+v"(b2[d]) : "v"(bvo), "s"(rx), "s"(xso)); \
+    else                                                                                                              \
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "+v"(b4b[d]) : "v"(bvo), "s"(rx), "s"(xso)); \
+  }
+#define OU_MMA(d, out)                                                                                                \
+  {                                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS));                                                           \
+    _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                  \
+      asm volatile("" : "+v"(a4[d][i]));                                                                              \
+      if constexpr (A2 == 1) asm volatile("" : "+v"(a2[d][i]));                                                       \
+    }                                                                                                                 \
+    asm volatile("" : "+v"(b4[d]));                                                                                   \
+    if constexpr (KW == 3) asm volatile("" : "+v"(b2[d]));                                                            \
+    else asm volatile("" : "+v"(b4b[d]));                                                                             \
+    const float Lw[8] = {b4[d].x, b4[d].y, b4[d].z, b4[d].w, KW == 3 ? b2[d].x : b4b[d].x, KW == 3 ? b2[d].y : b4b[d].y, \
+                         b4b[d].z, b4b[d].w};                                                                         \
+    float X[W];                                                                                                       \
+    if (edge) {                                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < W; i++) {                                                                 \
+        float v = Lw[i];                                                                                              \
+        _Pragma("unroll") for (int s2 = 1; s2 <= PAD; s2++) v = sh == s2 ? (i - s2 >= 0 ? Lw[i - s2 >= 0 ? i - s2 : 0] : 0.f) : v; \
+        X[i] = ((vmask >> i) & 1u) ? v : 0.f;                                                                         \
+      }                                                                                                               \
+    } else {                                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < W; i++) X[i] = Lw[i];                                                     \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < W; i++) X[i] = X[i] >= 0.f ? X[i] : alpha * X[i];                           \
+    _Pragma("unroll") for (int q = 0; q < 2; q++) {                                                                   \
+      float V[NX];                                                                                                    \
+      wino_bt<KW>(X + 2 * q, V);                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < TM; i++)                                                                  \
+        _Pragma("unroll") for (int x = 0; x < NX; x++) {                                                              \
+          const float av = x == 0 ? a4[d][i].x : (x == 1 ? a4[d][i].y : (x == 2 ? a4[d][i].z : (x == 3 ? a4[d][i].w : (x == 4 ? a2[d][i].x : a2[d][i].y)))); \
+          acc[i][q][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, V[x], acc[i][q][x], 0, 0, 0);                       \
+        }                                                                                                             \
+    }                                                                                                                 \
+  }
+  OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
+  const int NR = NS / 4;
+  for (int r = 0; r + 1 < NR; r++) {
+    const int g = r * 4;
+    OU_MMA(0, 3); OU_ISSUE(g + 4, 0);
+    OU_MMA(1, 3); OU_ISSUE(g + 5, 1);
+    OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
+    OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
+  }
+  OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
+#undef OU_ISSUE
+#undef OU_MMA
+
+  // ---- epilogue: A^T -> this wave's slab [BM][EP] (lane (n = l15, q = kk), register r = row 16 i + 4 q + r, columns 4 n .. + 3)
+  float* Ew = smem + (size_t)wk * BM * EP;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        if constexpr (KW == 3) {
+          v[2 * q] = acc[i][q][0][r] + acc[i][q][1][r] + acc[i][q][2][r];
+          v[2 * q + 1] = acc[i][q][1][r] - acc[i][q][2][r] - acc[i][q][3][r];
+        } else {
+          v[2 * q] = acc[i][q][0][r] + acc[i][q][1][r] + acc[i][q][2][r] + acc[i][q][3][r] + acc[i][q][4][r];
+          v[2 * q + 1] = acc[i][q][1][r] - acc[i][q][2][r] + 0.5f * acc[i][q][3][r] - 2.0f * acc[i][q][4][r] + acc[i][q][5][r];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&Ew[(16 * i + 4 * kk + r) * EP + 4 * l15]) = v;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+  const size_t ybase = (size_t)b * p.Cout * p.Tout;
+  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+  const int nvalid = p.Nq - n0;  // columns of this tile inside the signal (>= 1)
+  constexpr int RNT = 64 * WK, NQ = BM * 16, QPT = (NQ + RNT - 1) / RNT;
+#pragma unroll
+  for (int u = 0; u < QPT; u++) {
+    const int e = tid + u * RNT;
+    if (NQ % RNT != 0 && e >= NQ) break;
+    const int row = e >> 4, cq = (e & 15) * 4;
+    const int m = m0 + row;
+    if (m >= p.M || cq >= nvalid) continue;
+    const size_t idx = ybase + (size_t)m * p.Tout + n0 + cq;
+    const bool full = cq + 4 <= nvalid;
+    f32x4 ad = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+    if (full) {
+      if (p.add) ad = *reinterpret_cast<const f32x4u*>(p.add + idx);
+      if (p.res) rs = *reinterpret_cast<const f32x4u*>(p.res + idx);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        if (p.add && cq + s < nvalid) ad[s] = p.add[idx + s];
+        if (p.res && cq + s < nvalid) rs[s] = p.res[idx + s];
+      }
+    }
+    f32x4 v = *reinterpret_cast<const f32x4*>(&smem[row * EP + cq]);
+#pragma unroll
+    for (int k = 1; k < WK; k++) v += *reinterpret_cast<const f32x4*>(&smem[(k * BM + row) * EP + cq]);
+    if (p.in_scale) v *= insc;
+    v += p.bias[m];
+    if (p.add) v = (v + ad) * p.add_scale;
+    if (filmb) v = filmb[m] * v + filmb[p.Cout + m];
+    if (p.res) v = (v + rs) * p.res_scale;
+    if (full) {
+      *reinterpret_cast<f32x4u*>(p.y + idx) = v;
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+        if (cq + s < nvalid) p.y[idx + s] = v[s];
+    }
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+struct Direct4wCfg {
+  int KW, TM, WK;
+  void (*kern)(ConvArgs);
+};
+#define OU_D4W(KW, TM, WK) {KW, TM, WK, conv_direct4w_kernel<KW, TM, WK>}
+static const Direct4wCfg kDirect4wCfgs[] = {OU_D4W(3, 1, 8), OU_D4W(3, 2, 8), OU_D4W(5, 1, 8), OU_D4W(5, 2, 8),
+                                            OU_D4W(3, 1, 4), OU_D4W(3, 2, 4), OU_D4W(5, 1, 4), OU_D4W(5, 2, 4)};
+// The k3 / k5 layers of the 401-frame levels at small batch.  Tile height for an even fill of the CUs (cost = rounds x rows, as
+// direct4_pick); hipErrorInvalidConfiguration = "not a layer for it" (the caller goes on to the other kernels).
+// force_cfg 600 + 10 TM + KW (+ 100: four K slices instead of eight): tuning.
+hipError_t launch_conv_direct4w(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
+  if (!a.wu || a.stride != 1 || a.up != 1 || (a.KW != 3 && a.KW != 5) || a.pad != (a.KW - 1) / 2 || a.fir || a.Cin % 16 ||
+      (a.in_scale != nullptr && a.act))
+    return hipErrorInvalidConfiguration;
+  if ((long)a.Cin * a.Tin * 4 >= (1L << 31) || (long)a.Cin * a.Mp * 8 * 4 >= (1L << 31)) return hipErrorInvalidConfiguration;
+  const bool forced = a.force_cfg >= 600 && a.force_cfg < 800;
+  if (!forced && !(a.wino && a.direct >= 5)) return hipErrorInvalidConfiguration;
+  const int slots = a.Cin / 4;
+  const long ct = (a.Nq + 63) / 64;
+  int tm = 0, wk = 8;
+  if (forced) {
+    tm = ((a.force_cfg % 100) / 10);
+    wk = a.force_cfg >= 700 ? 4 : 8;
+  } else {
+    // short layers only, and only where conv_direct2w_kernel's 64-column x 32-row tiles leave CUs idle
+    const long b64 = (long)((a.M + 31) / 32) * ct * a.B;
+    if (a.Nq >= 1024 || b64 * 10 >= (long)num_cu * 8) return hipErrorInvalidConfiguration;
+    long best = 0;
+    for (int t = 1; t <= 2; t++) {
+      const long blocks = (long)((a.M + 16 * t - 1) / (16 * t)) * ct * a.B;
+      const long cost = (blocks + num_cu - 1) / num_cu * t;
+      if (!tm || cost <= best) { tm = t; best = cost; }  // (ties: the taller tile -- PP24's 768 x 401: 27.0 vs 32.4 us)
+    }
+  }
+  if (tm < 1 || tm > 2 || slots % (wk * 4) != 0) return hipErrorInvalidConfiguration;
+  const Direct4wCfg* c = nullptr;
+  for (const Direct4wCfg& k : kDirect4wCfgs)
+    if (k.KW == a.KW && k.TM == tm && k.WK == wk) { c = &k; break; }
+  if (!c) return hipErrorInvalidConfiguration;
+  ConvArgs aa = a;
+  const long gy = (a.M + 16 * tm - 1) / (16 * tm);
+  aa.grid_m = (int)gy;
+  aa.grid_n = (int)ct;
+  const long nblocks = 8L * ((gy + 7) / 8) * ct * a.B;
+  if (cfg_out) *cfg_out = (wk == 4 ? 700 : 600) + 10 * tm + a.KW;
+  hipLaunchKernelGGL(c->kern, dim3((unsigned)nblocks), dim3(64 * wk), (size_t)wk * 16 * tm * 68 * 4, stream, aa);
+  return hipGetLastError();
+}
+
 // ---- dispatch -----------------------------------------------------------------------------------------------
 struct Direct4Cfg {
   int R, TM, WN, WK, D;

@@ -487,7 +487,8 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   if (a.Cin % a.CK || a.CK < 2 || (a.CK & (a.CK - 1)) || a.Mp % 64 || a.Nq <= 0) return hipErrorInvalidValue;
   // Deep levels (what the 8-wave split-K configs below were built for): the register-direct kernels.  Wide levels
   // (many blocks of 64 x 128 per CU without splitting K) stay on the LDS-tiled configs.
-  if (a.direct >= 3 && (a.force_cfg < 0 || (a.force_cfg >= 200 && a.force_cfg < 300))) {
+  const bool force_d3 = (a.force_cfg >= 200 && a.force_cfg < 300) || (a.force_cfg >= 500 && a.force_cfg < 600);
+  if (a.direct >= 3 && (a.force_cfg < 0 || force_d3)) {
     hipError_t e = launch_conv_direct3(a, num_cu, stream, cfg_out);
     if (e != hipErrorInvalidConfiguration) return e;
     if (a.force_cfg >= 200) return e;
@@ -495,7 +496,7 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   // 1x1 convs, phase GEMMs and k = s = r rate-change convs with too few columns for the no-split-K kernel above: the
   // wide-load split-K kernel (conv_direct4_kernel).  It has no fused up-path FIR: a layer it would take runs as conv + FIR
   // pass (the caller's fallback on hipErrorNotSupported) unless a.d4_fir_unfused is off.
-  if (a.direct >= 4 && (a.force_cfg < 0 || a.force_cfg >= 300)) {
+  if (a.direct >= 4 && (a.force_cfg < 0 || (a.force_cfg >= 300 && a.force_cfg < 500))) {
     if (a.fir) {
       if (a.d4_fir_unfused && a.force_cfg < 0) {
         ConvArgs probe = a;
@@ -507,6 +508,12 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
       if (e != hipErrorInvalidConfiguration) return e;
       if (a.force_cfg >= 300) return e;
     }
+  }
+  // stride-1 k3 / k5 layers with few columns (the 401-frame levels at batch 1): minimal filtering on 16 / 32-row tiles
+  if (a.direct >= 5 && (a.force_cfg < 0 || (a.force_cfg >= 600 && a.force_cfg < 800))) {
+    hipError_t e = launch_conv_direct4w(a, num_cu, stream, cfg_out);
+    if (e != hipErrorInvalidConfiguration) return e;
+    if (a.force_cfg >= 600) return e;
   }
   if (a.direct != 0 && (a.force_cfg < 0 || (a.force_cfg >= 100 && a.force_cfg < 200))) {
     const long wide = (long)((a.M + 63) / 64) * ((a.Nq + 127) / 128) * a.B;

@@ -16,4 +16,5 @@ hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream,
 hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out);
 // (probe: only answer whether the family takes the layer, launch nothing)
 hipError_t launch_conv_direct4(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out, bool probe);
+hipError_t launch_conv_direct4w(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out);
 }  // namespace ou

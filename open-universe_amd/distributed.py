@@ -254,7 +254,7 @@ def enhance_sharded(model, signals, seed=1028282, gather=True, batch_size=1, pad
 
         sizes = {len(g) for g in groups}
         # (groups of different sizes in flight side by side: the lanes must agree on the GRU cluster layout -- the pool's largest)
-        with LanePool(model, min(in_flight, LanePool.MAX_LANES), max_batch=max(sizes) if len(sizes) > 1 else 0) as pool:
+        with LanePool(model, min(in_flight, LanePool.MAX_LANES), max_batch=max(sizes) if (len(sizes) > 1 or max(sizes) > 1) else 0) as pool:
             for group in groups:
                 _, res = pool.submit(lambda m, g=group: run_group(m, g))
                 for i, o in zip(group, res):

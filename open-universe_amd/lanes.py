@@ -30,6 +30,9 @@ class LanePool:
         lanes = int(lanes)
         if not 1 <= lanes <= self.MAX_LANES:
             raise ValueError(f"lanes must be in [1, {self.MAX_LANES}]")
+        if max_batch and max_batch > 1:
+            # every lane's GRU clusters have to be resident together: no more lanes than the device holds at this batch size
+            lanes = max(1, min(lanes, int(model._L.ou_lane_capacity(model._handle, int(max_batch)))))
         self.device = model.device
         # the forks (a C handle + workspaces each) are kept on the primary model and re-used by later pools
         forks = model.__dict__.setdefault("_lane_forks", [])

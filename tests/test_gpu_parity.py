@@ -67,7 +67,9 @@ def test_networks_vs_oracle_intermediates(name):
     c_ref, y_ref, h_ref = O.conditioner_network(sd, "condition_model", sdict, xin, taps=taps)
     cond, aux, lat = model.condition_model(xin.cuda(), train=True)
     for b in range(B):  # the stored mel is un-normalised: per-utterance scale, so compare per batch element
-        record(f"net.{name}.mel{b}", O.si_sdr(taps["mel"][b], model.tensor("cond.mel")[b].cpu()), 80)
+        # (scale-invariant ON PURPOSE -- a plain float, no SNR gate: the global norm is applied by the next kernel, and the
+        #  x_mel / cond taps below, which are held to the plain SNR too, see it)
+        record(f"net.{name}.mel{b}", float(O.si_sdr(taps["mel"][b], model.tensor("cond.mel")[b].cpu())), 80)
     checks = [("x_mel", "cond.melblock.v"), ("enc_sum", "cond.enc_sum"), ("gru", "cond.gru")]
     checks += [(f"st{i}", f"cond.st{i}") for i in range(len(spec.score.rate_factors) - 1)]
     for tap, nm in checks:

@@ -31,7 +31,8 @@ for lname, Tin in layers:
         else:
             os.environ["OU_XCD_MAP"] = mp
         row = []
-        for tag, cfg in (("auto", -1), ("wk8.tn2", 105), ("wk8.tn1", 106), ("wk4.tn2", 107), ("wk4.tn1", 108), ("wino8", 109), ("wino4", 110)):
+        for tag, cfg in (("auto", -1), ("wk8.tn2", 105), ("wk8.tn1", 106), ("wk4.tn2", 107), ("wk4.tn1", 108), ("wino8", 109), ("wino4", 110), ("d4w.tm1", 610), ("d4w.tm2", 620), ("d4w4.tm1", 710), ("d4w4.tm2", 720)):
+            if cfg >= 600: cfg += 5 if 'conv1' in lname else 3
             try:
                 best = None
                 for rep in range(3):

@@ -50,7 +50,7 @@ for lname, Tin in layers:
     if KW in (3, 5) and stride == 1 and tm == 4:
         variants += [("tm2", 200 + 20 + KW, None), ("tm3", 200 + 30 + KW, None)]
     if KW in (3, 5) and stride == 1:
-        variants += [("wino", 280 + KW, None), ("plain", -1, "4")]
+        variants += [(f"w{t}", 500 + 10 * t + KW, None) for t in ((1, 2, 3) if KW == 3 else (1, 2))] + [("plain", -1, "4")]
     for tag, cfg, env in variants:
         if env is not None:
             os.environ["OU_CONV_DIRECT"] = env
