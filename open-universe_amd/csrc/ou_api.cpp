@@ -404,6 +404,7 @@ struct Runner {
     auto chain_conv = [&](const ConvL& L) {
       ChainConv c;
       c.w = W(L.w_off); c.bias = W(L.b_off); c.alpha = h->alphas[L.a_off]; c.KW = L.KW; c.CK = L.CK;
+      if (L.KWP) c.wu = W(L.wu_off);
       return c;
     };
     // wide, shallow levels: the body runs as one fused launch (conv_chain_kernel), or conv1 + a fused (conv2, conv3)
@@ -424,6 +425,7 @@ struct Runner {
           ca.cv[0] = chain_conv(Bk.c2); ca.cv[1] = chain_conv(Bk.c3);
         }
         ca.force_nc = h->fuse_nc;
+        ca.wino = env.wino && env.conv_direct >= 5;
         if (!env.chain_ts.empty() && nm == env.chain_ts) ca.tstamps = (long long*)(base + cap - (16u << 20));
         int variant = -1;
         if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {

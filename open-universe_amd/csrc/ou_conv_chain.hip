@@ -268,6 +268,300 @@ __global__ __launch_bounds__(64 * NWV) void conv_chain_kernel(ChainArgs p, int T
   if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
+// =========================================================================================================
+// conv_chainw_kernel: the fused ConvBlock body of the 32-channel level in MINIMAL-FILTERING form (round 5)
+//   conv1 (k5, F(2, 5)) -> (+cond)/sqrt2 -> FiLM -> conv2 (k3, F(2, 3)) -> conv3 (k3) -> (+h)/sqrt2      (blocks.py:377-399)
+// conv_chain_kernel spends 55 % of a block's life in its MFMA phases (two waves per SIMD, 84 % of the pipe there) and the rest
+// staging, in epilogues and at one barrier per weight slot (tools/chain_ts.py: 27 k of 48.5 k cycles).  Here:
+//   * F(2, KW) (see conv_direct2w_kernel): a wave owns 32 rows x 32 tile positions = 64 columns of every stage; per channel
+//     pair KW + 1 MFMAs on independent accumulators instead of 2 KW -- 224 MFMAs per wave and block instead of 352;
+//   * ALL weights of the three convs sit in LDS in the Winograd domain for the whole block (C = 32: 24 + 16 + 16 KB, loaded
+//     once beside the input tile): no slot ring, no per-slot barrier -- three barriers per block in all;
+//   * four waves, one per SIMD, 256 columns per block (252 finished: the halo of 2 + 1 + 1 is recomputed, as before);
+//     operands come from LDS with 16- / 8-byte reads (A: the KW + 1 values U_x of (channel, row) are adjacent; B: the window of
+//     a tile position starts at an even column of the activation tile, whatever the stage -- stage s writes its output u
+//     where stage s + 1 reads input u), ~3-5 LDS instructions per 4-6 MFMAs;
+//   * the global operands of the epilogues (cond add, residual) are requested before the channel loop of their stage.
+// Same masking of columns outside the signal as conv_chain_kernel (the next conv must see zero padding there).  Results
+// differ from the plain fused kernel by the rounding of the transforms (tests: > 100 dB against it and the oracle).
+// =========================================================================================================
+__global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, int ntiles) {
+  constexpr int C = 32, NW = 4, NC = 64 * NW, XS = NC + 8, NTH = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufA = smem;               // [C][XS]
+  float* bufB = bufA + C * XS;      // [C][XS]
+  float* U1a = bufB + C * XS;       // [C ci][C m][4]   conv1: U_0 .. U_3
+  float* U1b = U1a + C * C * 4;     // [C ci][C m][2]   conv1: U_4, U_5
+  float* U2 = U1b + C * C * 2;      // [C ci][C m][4]
+  float* U3 = U2 + C * C * 4;       // [C ci][C m][4]
+  float* prm = U3 + C * C * 4;      // bias[3][C], gamma[C], beta[C]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lhalf = lane >> 5, l31 = lane & 31;
+  const int tile = blockIdx.x % ntiles, b = blockIdx.x / ntiles;
+  const int T = p.T, Mp = p.Mp;
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const int t0 = tile * TN;
+  constexpr int R0 = 2, R1 = 1;     // halo still needed downstream of stage 0 / 1 (k3, k3 follow)
+  const bool ts_on = p.tstamps != nullptr;  // tuning (OU_CHAIN_TS): cycles {loads issued, first barrier, 3 x (channel loop, epilogue + barrier)}
+  long long tsv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (ts_on) tsv[0] = __builtin_readcyclecounter();
+  const size_t rowbase = (size_t)b * C * T;
+  const unsigned plane = (unsigned)C * (unsigned)T * 4u;
+  const int Tb = T * 4;
+
+  // ---- weights -> registers (item = (ci, m): 1024 per conv, four per thread)
+  f32x4 w1a[4], w2[4], w3[4];
+  f32x2 w1b[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int it = tid + k * NTH, ci = it >> 5, m = it & 31;
+    const float* s1 = p.cv[0].wu + ((size_t)ci * Mp + m) * 8;
+    w1a[k] = *reinterpret_cast<const f32x4*>(s1);
+    w1b[k] = *reinterpret_cast<const f32x2*>(s1 + 4);
+    w2[k] = *reinterpret_cast<const f32x4*>(p.cv[1].wu + ((size_t)ci * Mp + m) * 4);
+    w3[k] = *reinterpret_cast<const f32x4*>(p.cv[2].wu + ((size_t)ci * Mp + m) * 4);
+  }
+  // ---- conv1's B operands come STRAIGHT FROM GLOBAL MEMORY into registers (as in conv_direct2w_kernel): lane (position, half)
+  // loads the six samples of its window of channel 2 I + half for all 16 channel pairs, 2 x 16 loads issued here, consumed in
+  // order by the stage-0 loop -- conv1 starts as soon as the first rows and its weights are there instead of after the whole
+  // 33 KB input tile has been staged through LDS and a barrier (7 k + 2 k of 42 k cycles per block in the first version).
+  const int pcol = 64 * wave + 2 * l31;   // this lane's tile position: outputs u = pcol, pcol + 1 of every stage
+  const int tw = t0 - R0 - 2 + pcol;      // time of window element 0 (even)
+  const int sh = tw < 0 ? -tw : 0;        // samples cut off in front of the row (first tile: 4, 2)
+  unsigned wmask = 0;                     // bit i: window element i is inside the signal
+#pragma unroll
+  for (int i = 0; i < 6; i++) wmask |= (tw + i >= 0 && tw + i < T) ? (1u << i) : 0u;
+  const bool edge = __builtin_amdgcn_readfirstlane((t0 - R0 - 2 < 0 || t0 - R0 - 2 + NC + 4 > T) ? 1 : 0) != 0;
+  f32x4 gw4[C / 2];
+  f32x2 gw2[C / 2];
+  {
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + rowbase, plane);
+    const int wvo = wmask ? (lhalf * T + tw + sh) * 4 : (int)0x80000000;  // (windows wholly outside: out of range, reads 0)
+#pragma unroll
+    for (int I = 0; I < C / 2; I++) {
+      gw4[I] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, wvo, 2 * I * Tb, 0));
+      gw2[I] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, wvo + 16, 2 * I * Tb, 0));
+    }
+  }
+  if (ts_on) tsv[1] = __builtin_readcyclecounter();
+  for (int i = tid; i < C; i += NTH) {
+    prm[i] = p.cv[0].bias[i];
+    prm[C + i] = p.cv[1].bias[i];
+    prm[2 * C + i] = p.cv[2].bias[i];
+    prm[3 * C + i] = p.film ? p.film[(size_t)b * p.film_bstride + i] : 1.f;
+    prm[4 * C + i] = p.film ? p.film[(size_t)b * p.film_bstride + C + i] : 0.f;
+  }
+  for (int i = tid; i < C * 8; i += NTH) {  // columns NC .. NC + 7 of both tiles: read by the last windows, never written
+    bufB[(i >> 3) * XS + NC + (i & 7)] = 0.f;
+    bufA[(i >> 3) * XS + NC + (i & 7)] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {  // (conv2 / conv3: written at the end of stage 0 -- their loads land under its MFMAs)
+    const int it = tid + k * NTH;
+    *reinterpret_cast<f32x4*>(&U1a[it * 4]) = w1a[k];
+    *reinterpret_cast<f32x2*>(&U1b[it * 2]) = w1b[k];
+  }
+  __syncthreads();
+  if (ts_on) tsv[2] = __builtin_readcyclecounter();
+
+  const int lrow = 4 * lhalf;             // lane part of the accumulator row: row(r) = lrow + (r & 3) + 8 (r >> 2)
+
+  auto run_stage = [&](auto SC) {
+    constexpr int s = decltype(SC)::value;
+    constexpr int KW = s == 0 ? 5 : 3, NX = KW + 1;
+    const float* inb = (s & 1) ? bufB : bufA;
+    float* outb = (s & 1) ? bufA : bufB;
+    const float* Ua = s == 0 ? U1a : (s == 1 ? U2 : U3);
+    const int t = t0 - (s == 0 ? R0 : (s == 1 ? R1 : 0)) + pcol;   // time of output u = pcol (even)
+    const bool in0 = t >= 0 && t < T, in1 = t + 1 >= 0 && t + 1 < T;
+    // epilogue operand (cond add of conv1 / residual of conv3), requested before the channel loop
+    f32x2 ev[16];
+    const float* src = s == 2 ? p.res : (s == 0 ? p.add : nullptr);
+    if (src) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(src + rowbase, plane);
+      const int vo = (in0 || in1) ? (lrow * T + t) * 4 : (int)0x80000000;  // (t even, T even: whole pairs inside or outside)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        ev[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, ((r & 3) + 8 * (r >> 2)) * Tb, 0));
+    }
+    floatx16 acc[NX];
+#pragma unroll
+    for (int x = 0; x < NX; x++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[x][r] = 0.f;
+    const float* ap = Ua + (lhalf * C + l31) * 4;            // U_0..3 of (ci = half, m = l31); + 2 I C 4 per channel pair
+    const float* ap2 = U1b + (lhalf * C + l31) * 2;
+    const float* bp = inb + lhalf * XS + pcol;               // window of (ci = half, position); + 2 I XS per channel pair
+    // ONE wave per SIMD: nothing but this wave's own instruction stream can fill the matrix pipe's 64 cycles per MFMA.  The
+    // loop is software-pipelined by hand -- the MFMAs of channel pair I are interleaved with B^T of pair I + 1 (whose LDS reads
+    // were issued an iteration earlier) and with the LDS reads of pair I + 2 -- and the interleaving is pinned with
+    // sched_group_barrier (one MFMA, then a few VALU / one LDS read), or the scheduler clusters the MFMAs and the wave sits
+    // in their issue queue with the transform still to do.
+    struct Ops { f32x4 a4; f32x2 a2, d01, d23, d45; };
+    auto fetch = [&](int I) {
+      Ops o;
+      o.a4 = *reinterpret_cast<const f32x4*>(ap + I * (2 * C * 4));
+      o.a2 = f32x2{0.f, 0.f}; o.d01 = f32x2{0.f, 0.f}; o.d23 = f32x2{0.f, 0.f}; o.d45 = f32x2{0.f, 0.f};
+      if constexpr (KW == 5) o.a2 = *reinterpret_cast<const f32x2*>(ap2 + I * (2 * C * 2));
+      if constexpr (s > 0) {
+        const float* bq = bp + I * (2 * XS);
+        o.d01 = *reinterpret_cast<const f32x2*>(bq);
+        o.d23 = *reinterpret_cast<const f32x2*>(bq + 2);
+      }
+      return o;
+    };
+    // V = B^T d of channel pair I: stages 1 / 2 from the LDS tile (PReLU applied by the producer), stage 0 from the window
+    // registers -- edge fix-up (first / last tile only: shift what was loaded from the row start, zero what is outside the
+    // signal), then conv1's PReLU
+    auto transform = [&](const Ops& o, int I, float (&V)[NX]) {
+      float X[6] = {o.d01.x, o.d01.y, o.d23.x, o.d23.y, 0.f, 0.f};
+      if constexpr (s == 0) {
+        const float L[6] = {gw4[I].x, gw4[I].y, gw4[I].z, gw4[I].w, gw2[I].x, gw2[I].y};
+        const float a0 = p.cv[0].alpha;
+        if (edge) {
+#pragma unroll
+          for (int i = 0; i < 6; i++) {
+            float v = L[i];
+            v = sh == 2 ? (i >= 2 ? L[i >= 2 ? i - 2 : 0] : 0.f) : v;
+            v = sh == 4 ? (i >= 4 ? L[i >= 4 ? i - 4 : 0] : 0.f) : v;
+            X[i] = ((wmask >> i) & 1u) ? v : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 6; i++) X[i] = L[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) X[i] = X[i] >= 0.f ? X[i] : a0 * X[i];
+      }
+      wino_bt<KW>(X, V);
+    };
+    // (LDS read latency under four waves' traffic is ~300 cycles -- more than the 256 MFMA cycles of a k3 channel pair: with
+    // the reads one pair ahead the loop ran at 55 % of the pipe.  Ring of four pairs: reads three pairs ahead.)
+    constexpr int NP = C / 2, RD = 4;
+    static_assert(NP % RD == 0, "ring");
+    Ops ring[RD];
+#pragma unroll
+    for (int k = 0; k < RD; k++) ring[k] = fetch(k);
+    float Vc[NX];
+    transform(ring[0], 0, Vc);
+#pragma unroll
+    for (int I0 = 0; I0 < NP; I0 += RD) {   // (fully unrolled: the window registers of stage 0 are indexed by the pair)
+#pragma unroll
+      for (int k = 0; k < RD; k++) {
+        const int I = I0 + k;
+        float Vn[NX];
+        transform(ring[(k + 1) % RD], I + 1 < NP ? I + 1 : NP - 1, Vn);   // pair I + 1
+        const Ops cur = ring[k];
+        const float A[6] = {cur.a4.x, cur.a4.y, cur.a4.z, cur.a4.w, cur.a2.x, cur.a2.y};
+#pragma unroll
+        for (int x = 0; x < NX; x++) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[x], Vc[x], acc[x], 0, 0, 0);
+        ring[k] = fetch(I + RD < NP ? I + RD : NP - 1);     // pair I + 4 into the slot that has just been consumed
+#pragma unroll
+        for (int x = 0; x < NX; x++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, KW == 5 ? 6 : 2, 0);  // a slice of the next pair's transform
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // one LDS read
+        }
+#pragma unroll
+        for (int x = 0; x < NX; x++) Vc[x] = Vn[x];
+      }
+    }
+    if (ts_on) tsv[3 + 2 * s] = __builtin_readcyclecounter();
+    // A^T -> outputs u = pcol (o0), pcol + 1 (o1)
+    floatx16 o0, o1;
+    if constexpr (KW == 3) {
+      o0 = acc[0] + acc[1] + acc[2];
+      o1 = acc[1] - acc[2] - acc[3];
+    } else {
+      o0 = acc[0] + acc[1] + acc[2] + acc[3] + acc[4];
+      o1 = acc[1] - acc[2] + 0.5f * acc[3] - 2.0f * acc[4] + acc[5];
+    }
+    const float* bias_l = prm + s * C + lrow;
+    if constexpr (s < 2) {
+      const float an = p.cv[s + 1].alpha;
+      float* out_l = outb + lrow * XS + pcol;
+      const __amdgpu_buffer_rsrc_t rc = make_rsrc((p.c1_out ? p.c1_out : p.y) + rowbase, plane);
+      const bool own0 = in0 && t >= t0 && t < t0 + TN, own1 = in1 && t + 1 >= t0 && t + 1 < t0 + TN;
+      float v0[16], v1[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int kr = (r & 3) + 8 * (r >> 2);
+        v0[r] = o0[r] + bias_l[kr]; v1[r] = o1[r] + bias_l[kr];
+      }
+      if constexpr (s == 0) {
+        if (p.add) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) { v0[r] = (v0[r] + ev[r].x) * p.add_scale; v1[r] = (v1[r] + ev[r].y) * p.add_scale; }
+        }
+        if (p.film) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int kr = (r & 3) + 8 * (r >> 2);
+            const float ga = prm[3 * C + lrow + kr], be = prm[4 * C + lrow + kr];
+            v0[r] = ga * v0[r] + be; v1[r] = ga * v1[r] + be;
+          }
+        }
+        if (p.c1_out) {
+          const int vo0 = own0 ? (lrow * T + t) * 4 : (int)0x80000000, vo1 = own1 ? (lrow * T + t + 1) * 4 : (int)0x80000000;
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int kr = (r & 3) + 8 * (r >> 2);
+            buf_store(v0[r], rc, vo0, kr * Tb);
+            buf_store(v1[r], rc, vo1, kr * Tb);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int kr = (r & 3) + 8 * (r >> 2);
+        float a = in0 ? v0[r] : 0.f;  // the zero padding the next conv sees outside the signal
+        float c = in1 ? v1[r] : 0.f;
+        a = a >= 0.f ? a : an * a;
+        c = c >= 0.f ? c : an * c;
+        *reinterpret_cast<f32x2*>(&out_l[kr * XS]) = f32x2{a, c};
+      }
+    } else {
+      const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + rowbase, plane);
+      const bool st0 = in0 && pcol < TN, st1 = in1 && pcol + 1 < TN;
+      // (pairs are whole: t, T and TN are even; a store past the signal or the tile goes to an out-of-range offset = dropped)
+      const int vo = (st0 && st1) ? (lrow * T + t) * 4 : (int)0x80000000;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int kr = (r & 3) + 8 * (r >> 2);
+        float v0 = o0[r] + bias_l[kr], v1 = o1[r] + bias_l[kr];
+        if (p.res) { v0 = (v0 + ev[r].x) * p.res_scale; v1 = (v1 + ev[r].y) * p.res_scale; }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{v0, v1}), ry, vo, kr * Tb, 0);
+      }
+    }
+    if constexpr (s == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int it = tid + k * NTH;
+        *reinterpret_cast<f32x4*>(&U2[it * 4]) = w2[k];
+        *reinterpret_cast<f32x4*>(&U3[it * 4]) = w3[k];
+      }
+    }
+    if constexpr (s < 2) __syncthreads();
+    if (ts_on) tsv[4 + 2 * s] = __builtin_readcyclecounter();
+  };
+  run_stage(std::integral_constant<int, 0>{});
+  run_stage(std::integral_constant<int, 1>{});
+  run_stage(std::integral_constant<int, 2>{});
+  if (ts_on && lane == 0) {
+    long long* o = p.tstamps + ((size_t)blockIdx.x * NW + wave) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = tsv[i + 1] - tsv[i];
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+static constexpr size_t kChainwSmem = 4 * ((size_t)2 * 32 * (256 + 8) + 32 * 32 * (4 + 2 + 4 + 4) + 5 * 32);
+static bool chainw_ok(const ChainArgs& a) {
+  return a.wino && a.C == 32 && a.depth == 3 && a.cv[0].KW == 5 && a.cv[1].KW == 3 && a.cv[2].KW == 3 && a.cv[0].wu && a.cv[1].wu &&
+         a.cv[2].wu && a.T % 4 == 0 && a.T >= 252 && (long)a.C * a.T * 4 < (1L << 31) && a.force_nc == 0;
+}
+
 struct ChainVariant {
   int C, NC, NWV;
   void (*kern)(ChainArgs, int, int);
@@ -312,6 +606,11 @@ static double chain_variant_cost(const ChainArgs& a, const ChainVariant& v, int 
 
 double chain_cost(const ChainArgs& a, int num_cu, int* nc_out) {
   if (!chain_shape_ok(a)) return -1.0;
+  if (chainw_ok(a)) {  // one wave per SIMD, 224 MFMAs per wave at ~85 %, ~9 k cycles of staging / epilogues / barriers
+    const long blocks = (long)a.B * ((a.T + 251) / 252);
+    if (nc_out) *nc_out = 256;
+    return (double)((blocks + num_cu - 1) / num_cu) * (224 * 64.0 / 0.85 + 9000.0);
+  }
   double best = -1.0;
   for (int i = 0; i < kNumChainVariants; i++) {
     const ChainVariant& v = kChainVariants[i];
@@ -323,6 +622,11 @@ double chain_cost(const ChainArgs& a, int num_cu, int* nc_out) {
 }
 
 hipError_t init_chain_kernels() {
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_chainw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kChainwSmem);
+    if (e != hipSuccess) return e;
+  }
   for (int i = 0; i < kNumChainVariants; i++) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kChainVariants[i].kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(kChainVariants[i]));
@@ -334,6 +638,12 @@ hipError_t init_chain_kernels() {
 hipError_t launch_chain(const ChainArgs& a, int num_cu, hipStream_t st, int* variant) {
   int nc = 0;
   if (chain_cost(a, num_cu, &nc) < 0) return hipErrorInvalidConfiguration;
+  if (chainw_ok(a)) {  // the minimal-filtering form (32 channels, depth 3): 252 finished columns per block
+    const int TN = 252, ntiles = (a.T + TN - 1) / TN;
+    if (variant) *variant = 190 + a.depth;
+    hipLaunchKernelGGL(conv_chainw_kernel, dim3(ntiles * a.B), dim3(256), kChainwSmem, st, a, TN, ntiles);
+    return hipGetLastError();
+  }
   for (int i = 0; i < kNumChainVariants; i++) {
     const ChainVariant& v = kChainVariants[i];
     if (v.C != a.C || v.NC != nc) continue;

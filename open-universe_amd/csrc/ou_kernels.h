@@ -146,6 +146,7 @@ hipError_t launch_sum(const float* a, const float* b, const float* c, const floa
 // Fused body of a ConvBlock (blocks.py:377-399) for the wide, shallow levels (C = 32 / 64): two or three stride-1
 // 'same' convs chained through LDS-resident activation tiles, see conv_chain_kernel.
 struct ChainConv {
+  const float* wu = nullptr;    // Winograd-domain copy [C][Mp][4 | 8] (conv_chainw_kernel) or null
   const float* w = nullptr;     // packed generic-conv weights [C/CK][KW][CK][Mp]
   const float* bias = nullptr;  // [C]
   float alpha = 0.f;            // PReLU slope applied to this conv's INPUT
@@ -165,6 +166,7 @@ struct ChainArgs {
   int depth = 3;               // number of fused convs: 3 = conv1..conv3, 2 = conv2, conv3
   ChainConv cv[3];
   int force_nc = 0;            // tuning: 128 / 256 columns per tile (0: chosen by the launcher)
+  int wino = 1;                // minimal-filtering form where there is one (32 channels, depth 3); OU_WINO / OU_CONV_DIRECT < 5: 0
   unsigned long long* prof = nullptr;
   long long* tstamps = nullptr;  // tuning: per-wave phase cycle counts
 };
