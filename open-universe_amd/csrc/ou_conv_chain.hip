@@ -285,100 +285,124 @@ __global__ __launch_bounds__(64 * NWV) void conv_chain_kernel(ChainArgs p, int T
 // Same masking of columns outside the signal as conv_chain_kernel (the next conv must see zero padding there).  Results
 // differ from the plain fused kernel by the rounding of the transforms (tests: > 100 dB against it and the oracle).
 // =========================================================================================================
+// MT: 32-row tiles (C = 32 MT).  D3: depth 3 = conv1 (k5), conv2, conv3 (k3); else depth 2 = conv2, conv3 (conv1 was a launch of
+// its own -- the 64-channel level: a depth-3 tile of 128 columns finishes 124 of them, 259 tiles for T = 32 080 on 256 CUs).
+//   C = 32, depth 3: four waves = four column groups of 64; all weights resident (U1a | U1b | U2 | U3), two activation tiles.
+//   C = 64, depth 2: four waves = two row tiles x two column groups, 128 columns per block (126 finished); ONE weight region
+//     (64 KB) that holds U2 during stage 0 and U3 -- parked in registers since kernel entry -- from the barrier behind it; one
+//     activation tile.
+template <int MT, bool D3>
 __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, int ntiles) {
-  constexpr int C = 32, NW = 4, NC = 64 * NW, XS = NC + 8, NTH = 64 * NW;
+  constexpr int C = 32 * MT, NW = 4, NWN = NW / MT, NC = 64 * NWN, XS = NC + 8, NTH = 64 * NW, NS = D3 ? 3 : 2;
+  constexpr int WI = C * C / NTH;  // (ci, m) items per thread and conv
+  static_assert(!D3 || MT == 1, "depth 3: the 32-channel level");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* bufA = smem;               // [C][XS]
-  float* bufB = bufA + C * XS;      // [C][XS]
-  float* U1a = bufB + C * XS;       // [C ci][C m][4]   conv1: U_0 .. U_3
-  float* U1b = U1a + C * C * 4;     // [C ci][C m][2]   conv1: U_4, U_5
-  float* U2 = U1b + C * C * 2;      // [C ci][C m][4]
-  float* U3 = U2 + C * C * 4;       // [C ci][C m][4]
-  float* prm = U3 + C * C * 4;      // bias[3][C], gamma[C], beta[C]
+  float* bufB = smem;                          // [C][XS]  output of stage 0
+  float* bufA = bufB + C * XS;                 // [C][XS]  output of stage 1 (depth 3 only)
+  float* Ua0 = bufA + (D3 ? C * XS : 0);       // [C ci][C m][4]  stage 0: U_0 .. U_3
+  float* Ub0 = Ua0 + C * C * 4;                // [C ci][C m][2]  stage 0 of depth 3: U_4, U_5
+  float* U2 = Ub0 + (D3 ? C * C * 2 : 0);      // depth 3: conv2, conv3
+  float* U3 = U2 + (D3 ? C * C * 4 : 0);
+  float* prm = D3 ? U3 + C * C * 4 : Ub0;      // bias[3][C], gamma[C], beta[C]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % MT, wn = wave / MT;
   const int lhalf = lane >> 5, l31 = lane & 31;
   const int tile = blockIdx.x % ntiles, b = blockIdx.x / ntiles;
   const int T = p.T, Mp = p.Mp;
   if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
   const int t0 = tile * TN;
-  constexpr int R0 = 2, R1 = 1;     // halo still needed downstream of stage 0 / 1 (k3, k3 follow)
-  const bool ts_on = p.tstamps != nullptr;  // tuning (OU_CHAIN_TS): cycles {loads issued, first barrier, 3 x (channel loop, epilogue + barrier)}
+  constexpr int KW0 = D3 ? 5 : 3, PAD0 = (KW0 - 1) / 2, R0 = D3 ? 2 : 1;  // halo still needed downstream of stage 0
+  const bool ts_on = p.tstamps != nullptr;  // tuning (OU_CHAIN_TS): cycles {loads issued, first barrier, NS x (channel loop, epilogue + barrier)}
   long long tsv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (ts_on) tsv[0] = __builtin_readcyclecounter();
   const size_t rowbase = (size_t)b * C * T;
   const unsigned plane = (unsigned)C * (unsigned)T * 4u;
   const int Tb = T * 4;
 
-  // ---- weights -> registers (item = (ci, m): 1024 per conv, four per thread)
-  f32x4 w1a[4], w2[4], w3[4];
-  f32x2 w1b[4];
+  // ---- weights -> registers (item = (ci, m)); the first stage's are staged to LDS below, the others parked
+  f32x4 wa[WI], wb[WI], wc[D3 ? WI : 1];
+  f32x2 wa2[D3 ? WI : 1];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int it = tid + k * NTH, ci = it >> 5, m = it & 31;
-    const float* s1 = p.cv[0].wu + ((size_t)ci * Mp + m) * 8;
-    w1a[k] = *reinterpret_cast<const f32x4*>(s1);
-    w1b[k] = *reinterpret_cast<const f32x2*>(s1 + 4);
-    w2[k] = *reinterpret_cast<const f32x4*>(p.cv[1].wu + ((size_t)ci * Mp + m) * 4);
-    w3[k] = *reinterpret_cast<const f32x4*>(p.cv[2].wu + ((size_t)ci * Mp + m) * 4);
+  for (int k = 0; k < WI; k++) {
+    const int it = tid + k * NTH, ci = it / C, m = it % C;
+    if constexpr (D3) {
+      const float* s1 = p.cv[0].wu + ((size_t)ci * Mp + m) * 8;
+      wa[k] = *reinterpret_cast<const f32x4*>(s1);
+      wa2[k] = *reinterpret_cast<const f32x2*>(s1 + 4);
+      wb[k] = *reinterpret_cast<const f32x4*>(p.cv[1].wu + ((size_t)ci * Mp + m) * 4);
+      wc[k] = *reinterpret_cast<const f32x4*>(p.cv[2].wu + ((size_t)ci * Mp + m) * 4);
+    } else {
+      wa[k] = *reinterpret_cast<const f32x4*>(p.cv[0].wu + ((size_t)ci * Mp + m) * 4);
+    }
   }
-  // ---- conv1's B operands come STRAIGHT FROM GLOBAL MEMORY into registers (as in conv_direct2w_kernel): lane (position, half)
-  // loads the six samples of its window of channel 2 I + half for all 16 channel pairs, 2 x 16 loads issued here, consumed in
-  // order by the stage-0 loop -- conv1 starts as soon as the first rows and its weights are there instead of after the whole
-  // 33 KB input tile has been staged through LDS and a barrier (7 k + 2 k of 42 k cycles per block in the first version).
-  const int pcol = 64 * wave + 2 * l31;   // this lane's tile position: outputs u = pcol, pcol + 1 of every stage
-  const int tw = t0 - R0 - 2 + pcol;      // time of window element 0 (even)
-  const int sh = tw < 0 ? -tw : 0;        // samples cut off in front of the row (first tile: 4, 2)
+  // ---- stage 0's B operands come STRAIGHT FROM GLOBAL MEMORY into registers (as in conv_direct2w_kernel): lane (position, half)
+  // loads the KW + 1 samples of its window of channel 2 I + half for all C / 2 channel pairs, issued here, consumed in order by
+  // the stage-0 loop -- the first conv starts as soon as the first rows and its weights are there instead of after the whole
+  // input tile has been staged through LDS and a barrier (7 k + 2 k of 42 k cycles per block in the first version).
+  const int pcol = 64 * wn + 2 * l31;     // this lane's tile position: outputs u = pcol, pcol + 1 of every stage
+  const int tw = t0 - R0 - PAD0 + pcol;   // time of window element 0 (even)
+  const int sh = tw < 0 ? -tw : 0;        // samples cut off in front of the row (first tile: 4 / 2)
   unsigned wmask = 0;                     // bit i: window element i is inside the signal
 #pragma unroll
-  for (int i = 0; i < 6; i++) wmask |= (tw + i >= 0 && tw + i < T) ? (1u << i) : 0u;
-  const bool edge = __builtin_amdgcn_readfirstlane((t0 - R0 - 2 < 0 || t0 - R0 - 2 + NC + 4 > T) ? 1 : 0) != 0;
+  for (int i = 0; i <= KW0; i++) wmask |= (tw + i >= 0 && tw + i < T) ? (1u << i) : 0u;
+  const bool edge = __builtin_amdgcn_readfirstlane((t0 - R0 - PAD0 < 0 || t0 - R0 - PAD0 + NC + KW0 - 1 > T) ? 1 : 0) != 0;
   f32x4 gw4[C / 2];
-  f32x2 gw2[C / 2];
+  f32x2 gw2[D3 ? C / 2 : 1];
   {
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + rowbase, plane);
     const int wvo = wmask ? (lhalf * T + tw + sh) * 4 : (int)0x80000000;  // (windows wholly outside: out of range, reads 0)
 #pragma unroll
     for (int I = 0; I < C / 2; I++) {
       gw4[I] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, wvo, 2 * I * Tb, 0));
-      gw2[I] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, wvo + 16, 2 * I * Tb, 0));
+      if constexpr (D3) gw2[I] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, wvo + 16, 2 * I * Tb, 0));
+    }
+  }
+  if constexpr (!D3) {  // the second conv's weights: parked in registers until the weight region is free (behind stage 0)
+#pragma unroll
+    for (int k = 0; k < WI; k++) {
+      const int it = tid + k * NTH, ci = it / C, m = it % C;
+      wb[k] = *reinterpret_cast<const f32x4*>(p.cv[1].wu + ((size_t)ci * Mp + m) * 4);
     }
   }
   if (ts_on) tsv[1] = __builtin_readcyclecounter();
   for (int i = tid; i < C; i += NTH) {
     prm[i] = p.cv[0].bias[i];
     prm[C + i] = p.cv[1].bias[i];
-    prm[2 * C + i] = p.cv[2].bias[i];
-    prm[3 * C + i] = p.film ? p.film[(size_t)b * p.film_bstride + i] : 1.f;
-    prm[4 * C + i] = p.film ? p.film[(size_t)b * p.film_bstride + C + i] : 0.f;
+    prm[2 * C + i] = D3 ? p.cv[2].bias[i] : 0.f;
+    prm[3 * C + i] = (D3 && p.film) ? p.film[(size_t)b * p.film_bstride + i] : 1.f;
+    prm[4 * C + i] = (D3 && p.film) ? p.film[(size_t)b * p.film_bstride + C + i] : 0.f;
   }
-  for (int i = tid; i < C * 8; i += NTH) {  // columns NC .. NC + 7 of both tiles: read by the last windows, never written
+  for (int i = tid; i < C * 8; i += NTH) {  // columns NC .. NC + 7 of the tiles: read by the last windows, never written
     bufB[(i >> 3) * XS + NC + (i & 7)] = 0.f;
-    bufA[(i >> 3) * XS + NC + (i & 7)] = 0.f;
+    if constexpr (D3) bufA[(i >> 3) * XS + NC + (i & 7)] = 0.f;
   }
 #pragma unroll
-  for (int k = 0; k < 4; k++) {  // (conv2 / conv3: written at the end of stage 0 -- their loads land under its MFMAs)
+  for (int k = 0; k < WI; k++) {
     const int it = tid + k * NTH;
-    *reinterpret_cast<f32x4*>(&U1a[it * 4]) = w1a[k];
-    *reinterpret_cast<f32x2*>(&U1b[it * 2]) = w1b[k];
+    *reinterpret_cast<f32x4*>(&Ua0[it * 4]) = wa[k];
+    if constexpr (D3) *reinterpret_cast<f32x2*>(&Ub0[it * 2]) = wa2[k];
   }
   __syncthreads();
   if (ts_on) tsv[2] = __builtin_readcyclecounter();
 
-  const int lrow = 4 * lhalf;             // lane part of the accumulator row: row(r) = lrow + (r & 3) + 8 (r >> 2)
+  const int lrow = 32 * wm + 4 * lhalf;   // lane part of the accumulator row: row(r) = lrow + (r & 3) + 8 (r >> 2)
 
   auto run_stage = [&](auto SC) {
     constexpr int s = decltype(SC)::value;
-    constexpr int KW = s == 0 ? 5 : 3, NX = KW + 1;
-    const float* inb = (s & 1) ? bufB : bufA;
-    float* outb = (s & 1) ? bufA : bufB;
-    const float* Ua = s == 0 ? U1a : (s == 1 ? U2 : U3);
-    const int t = t0 - (s == 0 ? R0 : (s == 1 ? R1 : 0)) + pcol;   // time of output u = pcol (even)
+    constexpr int KW = (D3 && s == 0) ? 5 : 3, NX = KW + 1;
+    constexpr bool last = s == NS - 1;
+    constexpr bool first3 = D3 && s == 0;          // conv1: cond add + FiLM + c1_out
+    const float* inb = (s == 1) ? bufB : bufA;     // (stage 0 reads registers)
+    float* outb = (s == 0) ? bufB : bufA;
+    const float* Ua = D3 ? (s == 0 ? Ua0 : (s == 1 ? U2 : U3)) : Ua0;
+    constexpr int Rs = NS - 1 - s;                  // halo still needed downstream of this stage (k3 convs follow)
+    const int t = t0 - Rs + pcol;                   // time of output u = pcol (even)
     const bool in0 = t >= 0 && t < T, in1 = t + 1 >= 0 && t + 1 < T;
-    // epilogue operand (cond add of conv1 / residual of conv3), requested before the channel loop
+    // epilogue operand (cond add of conv1 / residual of the last conv), requested before the channel loop
     f32x2 ev[16];
-    const float* src = s == 2 ? p.res : (s == 0 ? p.add : nullptr);
+    const float* src = last ? p.res : (first3 ? p.add : nullptr);
     if (src) {
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(src + rowbase, plane);
       const int vo = (in0 || in1) ? (lrow * T + t) * 4 : (int)0x80000000;  // (t even, T even: whole pairs inside or outside)
@@ -391,19 +415,18 @@ __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, i
     for (int x = 0; x < NX; x++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[x][r] = 0.f;
-    const float* ap = Ua + (lhalf * C + l31) * 4;            // U_0..3 of (ci = half, m = l31); + 2 I C 4 per channel pair
-    const float* ap2 = U1b + (lhalf * C + l31) * 2;
+    const float* ap = Ua + (lhalf * C + 32 * wm + l31) * 4;  // U_0..3 of (ci = half, m); + 2 I C 4 per channel pair
+    const float* ap2 = Ub0 + (lhalf * C + 32 * wm + l31) * 2;
     const float* bp = inb + lhalf * XS + pcol;               // window of (ci = half, position); + 2 I XS per channel pair
     // ONE wave per SIMD: nothing but this wave's own instruction stream can fill the matrix pipe's 64 cycles per MFMA.  The
-    // loop is software-pipelined by hand -- the MFMAs of channel pair I are interleaved with B^T of pair I + 1 (whose LDS reads
-    // were issued an iteration earlier) and with the LDS reads of pair I + 2 -- and the interleaving is pinned with
-    // sched_group_barrier (one MFMA, then a few VALU / one LDS read), or the scheduler clusters the MFMAs and the wave sits
-    // in their issue queue with the transform still to do.
-    struct Ops { f32x4 a4; f32x2 a2, d01, d23, d45; };
+    // loop is software-pipelined by hand -- the MFMAs of channel pair I are interleaved with B^T of pair I + 1 and with the LDS
+    // reads of pair I + 4 -- and the interleaving is pinned with sched_group_barrier (one MFMA, then a few VALU / one LDS
+    // read), or the scheduler clusters the MFMAs and the wave sits in their issue queue with the transform still to do.
+    struct Ops { f32x4 a4; f32x2 a2, d01, d23; };
     auto fetch = [&](int I) {
       Ops o;
       o.a4 = *reinterpret_cast<const f32x4*>(ap + I * (2 * C * 4));
-      o.a2 = f32x2{0.f, 0.f}; o.d01 = f32x2{0.f, 0.f}; o.d23 = f32x2{0.f, 0.f}; o.d45 = f32x2{0.f, 0.f};
+      o.a2 = f32x2{0.f, 0.f}; o.d01 = f32x2{0.f, 0.f}; o.d23 = f32x2{0.f, 0.f};
       if constexpr (KW == 5) o.a2 = *reinterpret_cast<const f32x2*>(ap2 + I * (2 * C * 2));
       if constexpr (s > 0) {
         const float* bq = bp + I * (2 * XS);
@@ -412,28 +435,29 @@ __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, i
       }
       return o;
     };
-    // V = B^T d of channel pair I: stages 1 / 2 from the LDS tile (PReLU applied by the producer), stage 0 from the window
+    // V = B^T d of channel pair I: later stages from the LDS tile (PReLU applied by the producer), stage 0 from the window
     // registers -- edge fix-up (first / last tile only: shift what was loaded from the row start, zero what is outside the
-    // signal), then conv1's PReLU
+    // signal), then the first conv's PReLU
     auto transform = [&](const Ops& o, int I, float (&V)[NX]) {
       float X[6] = {o.d01.x, o.d01.y, o.d23.x, o.d23.y, 0.f, 0.f};
       if constexpr (s == 0) {
-        const float L[6] = {gw4[I].x, gw4[I].y, gw4[I].z, gw4[I].w, gw2[I].x, gw2[I].y};
+        const float L[6] = {gw4[I].x, gw4[I].y, gw4[I].z, gw4[I].w, D3 ? gw2[D3 ? I : 0].x : 0.f, D3 ? gw2[D3 ? I : 0].y : 0.f};
         const float a0 = p.cv[0].alpha;
         if (edge) {
 #pragma unroll
-          for (int i = 0; i < 6; i++) {
+          for (int i = 0; i < NX; i++) {
             float v = L[i];
+            v = sh == 1 ? (i >= 1 ? L[i >= 1 ? i - 1 : 0] : 0.f) : v;
             v = sh == 2 ? (i >= 2 ? L[i >= 2 ? i - 2 : 0] : 0.f) : v;
             v = sh == 4 ? (i >= 4 ? L[i >= 4 ? i - 4 : 0] : 0.f) : v;
             X[i] = ((wmask >> i) & 1u) ? v : 0.f;
           }
         } else {
 #pragma unroll
-          for (int i = 0; i < 6; i++) X[i] = L[i];
+          for (int i = 0; i < NX; i++) X[i] = L[i];
         }
 #pragma unroll
-        for (int i = 0; i < 6; i++) X[i] = X[i] >= 0.f ? X[i] : a0 * X[i];
+        for (int i = 0; i < NX; i++) X[i] = X[i] >= 0.f ? X[i] : a0 * X[i];
       }
       wino_bt<KW>(X, V);
     };
@@ -479,7 +503,7 @@ __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, i
       o1 = acc[1] - acc[2] + 0.5f * acc[3] - 2.0f * acc[4] + acc[5];
     }
     const float* bias_l = prm + s * C + lrow;
-    if constexpr (s < 2) {
+    if constexpr (!last) {
       const float an = p.cv[s + 1].alpha;
       float* out_l = outb + lrow * XS + pcol;
       const __amdgpu_buffer_rsrc_t rc = make_rsrc((p.c1_out ? p.c1_out : p.y) + rowbase, plane);
@@ -490,7 +514,7 @@ __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, i
         const int kr = (r & 3) + 8 * (r >> 2);
         v0[r] = o0[r] + bias_l[kr]; v1[r] = o1[r] + bias_l[kr];
       }
-      if constexpr (s == 0) {
+      if constexpr (first3) {
         if (p.add) {
 #pragma unroll
           for (int r = 0; r < 16; r++) { v0[r] = (v0[r] + ev[r].x) * p.add_scale; v1[r] = (v1[r] + ev[r].y) * p.add_scale; }
@@ -535,20 +559,25 @@ __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, i
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{v0, v1}), ry, vo, kr * Tb, 0);
       }
     }
-    if constexpr (s == 0) {
+    if constexpr (D3 && s == 0) {  // conv2 / conv3 weights: their loads have landed under this stage's MFMAs
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < WI; k++) {
         const int it = tid + k * NTH;
-        *reinterpret_cast<f32x4*>(&U2[it * 4]) = w2[k];
-        *reinterpret_cast<f32x4*>(&U3[it * 4]) = w3[k];
+        *reinterpret_cast<f32x4*>(&U2[it * 4]) = wb[k];
+        *reinterpret_cast<f32x4*>(&U3[it * 4]) = wc[D3 ? k : 0];
       }
     }
-    if constexpr (s < 2) __syncthreads();
+    if constexpr (!D3 && s == 0) {  // the weight region is free once every wave has left the loop: U3 takes U2's place
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < WI; k++) *reinterpret_cast<f32x4*>(&Ua0[(tid + k * NTH) * 4]) = wb[k];
+    }
+    if constexpr (!last) __syncthreads();
     if (ts_on) tsv[4 + 2 * s] = __builtin_readcyclecounter();
   };
   run_stage(std::integral_constant<int, 0>{});
   run_stage(std::integral_constant<int, 1>{});
-  run_stage(std::integral_constant<int, 2>{});
+  if constexpr (D3) run_stage(std::integral_constant<int, 2>{});
   if (ts_on && lane == 0) {
     long long* o = p.tstamps + ((size_t)blockIdx.x * NW + wave) * 8;
 #pragma unroll
@@ -556,10 +585,18 @@ __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, i
   }
   if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
-static constexpr size_t kChainwSmem = 4 * ((size_t)2 * 32 * (256 + 8) + 32 * 32 * (4 + 2 + 4 + 4) + 5 * 32);
-static bool chainw_ok(const ChainArgs& a) {
-  return a.wino && a.C == 32 && a.depth == 3 && a.cv[0].KW == 5 && a.cv[1].KW == 3 && a.cv[2].KW == 3 && a.cv[0].wu && a.cv[1].wu &&
-         a.cv[2].wu && a.T % 4 == 0 && a.T >= 252 && (long)a.C * a.T * 4 < (1L << 31) && a.force_nc == 0;
+static constexpr size_t kChainwSmem32 = 4 * ((size_t)2 * 32 * (256 + 8) + 32 * 32 * (4 + 2 + 4 + 4) + 5 * 32);
+static constexpr size_t kChainwSmem64 = 4 * ((size_t)64 * (128 + 8) + 64 * 64 * 4 + 5 * 64);
+// 0: not a shape for the minimal-filtering form; 1: 32 channels, depth 3; 2: 64 channels, depth 2
+static int chainw_kind(const ChainArgs& a) {
+  if (!a.wino || a.T % 4 || (long)a.C * a.T * 4 >= (1L << 31) || a.force_nc != 0) return 0;
+  if (a.C == 32 && a.depth == 3 && a.cv[0].KW == 5 && a.cv[1].KW == 3 && a.cv[2].KW == 3 && a.cv[0].wu && a.cv[1].wu && a.cv[2].wu &&
+      a.T >= 252)
+    return 1;
+  if (a.C == 64 && a.depth == 2 && a.cv[0].KW == 3 && a.cv[1].KW == 3 && a.cv[0].wu && a.cv[1].wu && a.T >= 126 && !a.add &&
+      !a.film && !a.c1_out)
+    return 2;
+  return 0;
 }
 
 struct ChainVariant {
@@ -606,10 +643,11 @@ static double chain_variant_cost(const ChainArgs& a, const ChainVariant& v, int 
 
 double chain_cost(const ChainArgs& a, int num_cu, int* nc_out) {
   if (!chain_shape_ok(a)) return -1.0;
-  if (chainw_ok(a)) {  // one wave per SIMD, 224 MFMAs per wave at ~85 %, ~9 k cycles of staging / epilogues / barriers
-    const long blocks = (long)a.B * ((a.T + 251) / 252);
-    if (nc_out) *nc_out = 256;
-    return (double)((blocks + num_cu - 1) / num_cu) * (224 * 64.0 / 0.85 + 9000.0);
+  if (const int kind = chainw_kind(a)) {  // one wave per SIMD, 224 / 256 MFMAs per wave at ~70 %, ~12 k cycles of everything else
+    const int TN = kind == 1 ? 252 : 126;
+    const long blocks = (long)a.B * ((a.T + TN - 1) / TN);
+    if (nc_out) *nc_out = kind == 1 ? 256 : 128;
+    return (double)((blocks + num_cu - 1) / num_cu) * ((kind == 1 ? 224 : 256) * 64.0 / 0.7 + 12000.0);
   }
   double best = -1.0;
   for (int i = 0; i < kNumChainVariants; i++) {
@@ -623,8 +661,11 @@ double chain_cost(const ChainArgs& a, int num_cu, int* nc_out) {
 
 hipError_t init_chain_kernels() {
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_chainw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)kChainwSmem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_chainw_kernel<1, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainwSmem32);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_chainw_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kChainwSmem64);
     if (e != hipSuccess) return e;
   }
   for (int i = 0; i < kNumChainVariants; i++) {
@@ -638,10 +679,11 @@ hipError_t init_chain_kernels() {
 hipError_t launch_chain(const ChainArgs& a, int num_cu, hipStream_t st, int* variant) {
   int nc = 0;
   if (chain_cost(a, num_cu, &nc) < 0) return hipErrorInvalidConfiguration;
-  if (chainw_ok(a)) {  // the minimal-filtering form (32 channels, depth 3): 252 finished columns per block
-    const int TN = 252, ntiles = (a.T + TN - 1) / TN;
+  if (const int kind = chainw_kind(a)) {  // the minimal-filtering forms: 252 (C = 32, depth 3) / 126 (C = 64, depth 2) finished columns
+    const int TN = kind == 1 ? 252 : 126, ntiles = (a.T + TN - 1) / TN;
     if (variant) *variant = 190 + a.depth;
-    hipLaunchKernelGGL(conv_chainw_kernel, dim3(ntiles * a.B), dim3(256), kChainwSmem, st, a, TN, ntiles);
+    if (kind == 1) hipLaunchKernelGGL((conv_chainw_kernel<1, true>), dim3(ntiles * a.B), dim3(256), kChainwSmem32, st, a, TN, ntiles);
+    else hipLaunchKernelGGL((conv_chainw_kernel<2, false>), dim3(ntiles * a.B), dim3(256), kChainwSmem64, st, a, TN, ntiles);
     return hipGetLastError();
   }
   for (int i = 0; i < kNumChainVariants; i++) {
