@@ -567,6 +567,8 @@ def main():
             return 1e3 * (time.perf_counter() - t0) / args.steps
 
         try:
+            if os.environ.get("OU_BENCH_NO_GRAPH"):  # (tools/hwq_probe.sh: which leg hangs under GPU_MAX_HW_QUEUES=2)
+                raise RuntimeError("hipGraph legs skipped (OU_BENCH_NO_GRAPH)")
             # the capturable form: one chain on one stream (OU_ENH_SERIAL); and, for the record, the eager call's own
             # fork / join structure captured as it is
             run = model.graphed_enhance(args.batch, T, n_steps=args.n_steps, serial=True)
@@ -598,23 +600,37 @@ def main():
         model.profile(False)
         # records: (ms, algorithmic flops, algorithmic bytes, variant); variant < 40: conv_mfma_kernel tile configs,
         # 40-49: rate_down_kernel,
-        # 66 / 76 / 67 / 77: conv_direct2_kernel, 78 / 79: conv_direct2w_kernel, other 50-99: conv_direct_kernel / conv_direct_strided_kernel variants,
+        # 66 / 76 / 67 / 77: conv_direct2_kernel, 400 + 10 WK + KW: conv_direct2w_kernel, 600 / 700 + 10 TM + KW: conv_direct4w_kernel, other 50-99: conv_direct_kernel / conv_direct_strided_kernel variants,
         # 100-199: conv_chain_kernel (fused ConvBlock body), 200-299: conv_direct3_kernel (2xx: 200 + 10 TM + KW) /
         # conv_direct3s_kernel (260 + R), 500-599: conv_direct3w_kernel (500 + 10 TM + KW), 300-399: conv_direct4_kernel (300 + 10 TM + log2 WK), >= 1000: one GRU pass
         # (1000 + steps).
         gru_recs = [r for r in recs if r[3] >= 1000]
         recs = [r for r in recs if r[3] < 1000]
+        def executed_fraction(cfg):
+            """MFMA multiply-adds a launch issues / its algorithmic ones: the minimal-filtering kernels (F(2, KW): KW + 1 products
+            per pair of outputs instead of 2 KW) carry KW in their variant code."""
+            if 400 <= cfg < 800:
+                kw = cfg % 10
+                return (kw + 1) / (2.0 * kw)
+            if cfg == 193:  # conv_chainw_kernel, depth 3: k5, k3, k3
+                return 14 / 22.0
+            if cfg == 192:  # depth 2: k3, k3
+                return 8 / 12.0
+            return 1.0
+
         def summarise(rr):
             if not rr:
                 return None
             ms_ = sum(r[0] for r in rr)
             fl_ = sum(r[1] for r in rr)
             by_ = sum(r[2] for r in rr)
+            ex_ = sum(r[1] * executed_fraction(r[3]) for r in rr)
             return {"launches": len(rr) // max(1, args.profile_steps), "avg_launch_us": 1e3 * ms_ / len(rr),
                     "ms_per_enhance": ms_ / max(1, args.profile_steps),
                     "algorithmic_gflop_per_enhance": fl_ / max(1, args.profile_steps) / 1e9,
                     "algorithmic_GB_per_enhance": by_ / max(1, args.profile_steps) / 1e9,
                     "tflops": fl_ / (ms_ * 1e-3) / 1e12, "gbs": by_ / (ms_ * 1e-3) / 1e9,
+                    "executed_tflops": ex_ / (ms_ * 1e-3) / 1e12,
                     "algorithmic_bytes_per_launch": by_ / len(rr)}
         KERNELS = {
             "direct2": "ou::conv_direct2_kernel / conv_direct2w_kernel (register-direct split-K fp32-MFMA Conv1d, wide operand loads: "
@@ -633,7 +649,7 @@ def main():
         }
         # conv_direct2_kernel (8 / 4 K slices), its minimal-filtering form conv_direct2w_kernel, and conv_direct4w_kernel
         # (6xx / 7xx: the same layers on 16 / 32-row tiles where there are few columns)
-        D2 = (66, 76, 67, 77, 78, 79) + tuple(range(600, 800))
+        D2 = (66, 76, 67, 77) + tuple(range(400, 500)) + tuple(range(600, 800))
         groups = {"direct2": summarise([r for r in recs if r[3] in D2]),
                   "direct": summarise([r for r in recs if 50 <= r[3] < 100 and r[3] not in D2]),
                   "lds": summarise([r for r in recs if r[3] < 40]),
@@ -695,6 +711,11 @@ def main():
             "peak": FP32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": gen["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+            "executed": {"tflops": gen["executed_tflops"], "frac_of_peak": gen["executed_tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                         "note": "achieved / frac count ALGORITHMIC FLOPs (2 M Cin KW Nq per launch, SURVEY.md 8(d)); the "
+                                 "minimal-filtering kernels (Winograd / Cook-Toom F(2, 3), F(2, 5): conv_direct2w / 3w / 4w, "
+                                 "conv_chainw) issue 2/3 (k3) and 3/5 (k5) of them on the matrix pipe -- `executed` is what the "
+                                 "pipe actually ran, the figure that cannot exceed its 157.3 TFLOP/s"},
             "traffic": traffic,
             "traffic_note": traffic_note,
             "launches": gen["launches"],
@@ -706,9 +727,11 @@ def main():
                          "algorithmic_GB_per_enhance": gen["algorithmic_GB_per_enhance"]},
             "other_conv_kernels": {KERNELS[k]: {
                 "achieved": v["tflops"], "frac": v["tflops"] / FP32_MFMA_PEAK_TFLOPS, "launches": v["launches"],
+                "executed_tflops": v["executed_tflops"],
                 "avg_launch_us": v["avg_launch_us"], "ms_per_enhance": v["ms_per_enhance"],
                 "algorithmic_gflop_per_enhance": v["algorithmic_gflop_per_enhance"]} for k, v in groups.items() if k != dom},
             "all_conv_kernels": {"achieved": allconv["tflops"], "frac": allconv["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                                 "executed_tflops": allconv["executed_tflops"],
                                  "launches": allconv["launches"], "ms_per_enhance": allconv["ms_per_enhance"],
                                  "algorithmic_gflop_per_enhance": allconv["algorithmic_gflop_per_enhance"]},
             "pointwise_family": None if not fam else {

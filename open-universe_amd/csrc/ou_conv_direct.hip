@@ -1118,7 +1118,7 @@ hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream,
     if (wino) {
       if (wk == 8) kern = a.KW == 3 ? conv_direct2w_kernel<3, 8> : conv_direct2w_kernel<5, 8>;
       else kern = a.KW == 3 ? conv_direct2w_kernel<3, 4> : conv_direct2w_kernel<5, 4>;
-      variant = wk == 8 ? 78 : 79;  // minimal-filtering variants (64-column tiles)
+      variant = 400 + 10 * wk + a.KW;  // minimal-filtering variants (64-column tiles): 483 / 485 (eight slices), 443 / 445
     } else {
       if (wk == 8)
         kern = a.KW == 3 ? (tn == 2 ? conv_direct2_kernel<3, 2, 8> : conv_direct2_kernel<3, 1, 8>)
@@ -1157,7 +1157,7 @@ hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream,
   aa.tile_bm = bm_step; aa.tile_bn = BN - 2 * halo; aa.tile_halo = halo;
   aa.grid_n = (a.Nq + aa.tile_bn - 1) / aa.tile_bn;
   aa.grid_m = (int)gm_fir;
-  const bool is_d2 = variant == 66 || variant == 76 || variant == 67 || variant == 77 || variant == 78 || variant == 79;
+  const bool is_d2 = variant == 66 || variant == 76 || variant == 67 || variant == 77 || (variant >= 400 && variant < 500);
   {
     const double xb = (double)a.Cin * a.Nq * a.stride, wb = (double)a.M * a.Cin * a.KW;
     aa.xcd_map = 0;

@@ -597,6 +597,16 @@ class Universe:
         capturable by construction: no allocation, no host synchronisation, GRU exchange tags advance on the device."""
         n_steps = self.diff_kwargs.n_steps if n_steps is None else int(n_steps)
         epsilon = self.diff_kwargs.epsilon if epsilon is None else float(epsilon)
+        if not serial:
+            # Measured (tools/hwq_probe.sh, profiles/r05_final_hwq_probe.txt): with GPU_MAX_HW_QUEUES below 4 the HIP runtime
+            # SEGFAULTS replaying a captured graph that has this call's four-stream fork / join structure (round 4 recorded it
+            # as a hang of bench.py); the eager call and the serial-chain capture are fine with 1, 2 or 4 queues.
+            import os
+
+            hwq = os.environ.get("GPU_MAX_HW_QUEUES")
+            if hwq is not None and hwq.strip().isdigit() and int(hwq) < 4:
+                raise RuntimeError(f"graphed_enhance(serial=False) captures four streams; GPU_MAX_HW_QUEUES={hwq} makes the HIP "
+                                   "runtime crash when such a graph is replayed -- use serial=True (the default)")
         B, mix_len = int(batch), int(length)
         T = mix_len + (self.tot_ds - mix_len % self.tot_ds)
         dev = self.device

@@ -4,7 +4,7 @@ import csv, json, os, shutil, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "final")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05_final"
 shutil.copy(os.path.join(src, "prof", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats_PP16_B1.csv"))
 for n in sorted(os.listdir(src)):
     if n.startswith("bench_") and n.endswith(".json"):
@@ -16,13 +16,16 @@ for n in sorted(os.listdir(src)):
         open(os.path.join(dst, f"{tag}_{n}"), "w").write(lines[-1] + "\n")
 for n in sorted(os.listdir(src)):
     if n.startswith(("kstats_", "pmc_sq_", "gru_ts", "layers", "direct_ts", "direct_sweep", "ubench_", "tile_sweep", "stress_",
-                     "xcc_migrate", "timings", "sharded_rate", "box_health", "d4_sweep", "d4_ts", "lanes_", "free_run")):
+                     "xcc_migrate", "timings", "sharded_rate", "box_health", "d4_sweep", "d4_ts", "lanes_", "free_run", "d2_sweep", "chainw_ts",
+                     "hwq", "env_knobs")):
         shutil.copy(os.path.join(src, n), os.path.join(dst, f"{tag}_{n}"))
 
-FAMS = {"direct2": ("conv_direct2_kernel",), "direct": ("conv_direct_kernel", "conv_direct_strided_kernel"),
+FAMS = {"direct2": ("conv_direct2_kernel", "conv_direct2w_kernel", "conv_direct4w_kernel"),
+        "direct": ("conv_direct_kernel", "conv_direct_strided_kernel"),
         "direct4": ("conv_direct4_kernel",),
-        "direct3": ("conv_direct3_kernel", "conv_direct3s_kernel"),
-        "lds": ("conv_mfma_kernel",), "rate": ("rate_down_kernel", "rate_up_kernel"), "chain": ("conv_chain_kernel",), "gru_ring": ("gru_ring_kernel",),
+        "direct3": ("conv_direct3_kernel", "conv_direct3w_kernel", "conv_direct3s_kernel"),
+        "lds": ("conv_mfma_kernel",), "rate": ("rate_down_kernel", "rate_up_kernel"),
+        "chain": ("conv_chain_kernel", "conv_chainw_kernel"), "gru_ring": ("gru_ring_kernel",),
         "gru_cluster": ("gru_cluster_kernel",)}
 
 

@@ -93,12 +93,8 @@ python - >> $O/stress_two_ranks.txt <<PY
 import json
 d=json.loads([l for l in open("$O/st.out") if l.startswith("{")][-1]); print("last run:", d["ms_per_step"], d["gru_exchange"])
 PY
-OU_TRACE=1 OU_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr -o t -- python tools/gpu_debug.py timing PP16 iters=2 > /dev/null 2> $O/trace.log
-python tools/trace_summary.py $O/tr/t_kernel_trace.csv $O/trace.log > $O/layers_PP16_B1.txt 2>&1
-for cfg in "PP24_B8 PP24 B=8 T=96000 iters=1" "PP16_B8 PP16 B=8 iters=1"; do
-  set -- $cfg; name=$1; shift
-  OU_TRACE=1 OU_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr_$name -o t -- python tools/gpu_debug.py timing "$@" > /dev/null 2> $O/trace_$name.log
-  python tools/trace_summary.py $O/tr_$name/t_kernel_trace.csv $O/trace_$name.log > $O/layers_$name.txt 2>&1
-  rm -rf $O/tr_$name $O/trace_$name.log
-done
-rm -rf $O/tr $O/trace.log
+# per-layer tables: the library's own per-launch records paired with its OU_TRACE lines in launch order (tools/layer_table.py)
+timeout 600 python tools/layer_table.py PP16 1 2>&1 | grep -v amdgpu.ids > $O/layers_PP16_B1.txt; tail -2 $O/layers_PP16_B1.txt
+OU_NO_OVERLAP=1 timeout 600 python tools/layer_table.py PP16 1 2>&1 | grep -v amdgpu.ids > $O/layers_PP16_B1_serial.txt
+timeout 600 python tools/layer_table.py PP16 8 2>&1 | grep -v amdgpu.ids > $O/layers_PP16_B8.txt
+timeout 600 python tools/layer_table.py PP24 8 2>&1 | grep -v amdgpu.ids > $O/layers_PP24_B8.txt
