@@ -671,8 +671,10 @@ def main():
             ent = tj.get("configs", {}).get(cfg_tag)
             if ent is not None:
                 traffic = ent.get(dom + "_bytes_per_launch")
-                traffic_note = (f"STATIC: copied from profiles/pmc_traffic.json [{cfg_tag}] (separate rocprofv3 --pmc FETCH_SIZE / "
-                                "WRITE_SIZE passes of this command on an earlier box), not measured in this run. "
+                traffic_note = (f"STATIC: copied from profiles/pmc_traffic.json [{cfg_tag}] -- separate rocprofv3 --pmc FETCH_SIZE / "
+                                "WRITE_SIZE passes of this command, collected by tools/round_profile.sh in the evidence run of the "
+                                "round on the box of the committed profiles/rNN_final_* files (profiles/rNN_final_box_health.txt); "
+                                "not measured in THIS run: PMC passes need rocprofv3 around the process. "
                                 + tj.get("note", ""))
 
         # whole score-network forward (the unit of work of SURVEY 8(d)): HIP events on the launch stream around

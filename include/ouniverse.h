@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OU_ABI_VERSION 2
+#define OU_ABI_VERSION 3 /* 3: the packed blob carries a Winograd-domain weight copy (round 5); ou_set_lane_batch, ou_lane_capacity */
 
 enum {
   OU_OK = 0,

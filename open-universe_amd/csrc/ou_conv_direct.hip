@@ -716,18 +716,27 @@ __device__ __forceinline__ void direct2w_tile(const ConvArgs& p, float* smem, in
     if constexpr (X2 == 2) asm volatile("" : "+v"(b2[d]));                                                           \
     direct2w_mma<KW>(a4[d], a2[d], b4[d], b2[d], acc, alpha, edge, sh, vmask);                                       \
   }
+  // tuning only (OU_TS): per-wave phase stamps, as in conv_direct2_kernel
+  const bool ts_on = p.tstamps != nullptr;
+  long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, r0 = 0;
+  if (ts_on) { r0 = (long long)__builtin_amdgcn_s_memrealtime(); c0 = __builtin_readcyclecounter(); }
   OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
+  if (ts_on) c1 = __builtin_readcyclecounter();
   const int NR = NG / D;
   for (int r = 0; r + 1 < NR; r++) {
     const int g = r * D;
-    OU_MMA(0, 3 * LPS); OU_ISSUE(g + 4, 0);
+    OU_MMA(0, 3 * LPS);
+    if (ts_on && r == 0) c2 = __builtin_readcyclecounter();
+    OU_ISSUE(g + 4, 0);
     OU_MMA(1, 3 * LPS); OU_ISSUE(g + 5, 1);
     OU_MMA(2, 3 * LPS); OU_ISSUE(g + 6, 2);
     OU_MMA(3, 3 * LPS); OU_ISSUE(g + 7, 3);
   }
+  if (ts_on) c3 = __builtin_readcyclecounter();
   typename Epi::Pre pre;
   Epi::issue(p, pre, tid, b, m0, n0);  // the epilogue's global operands travel under the drain
   OU_MMA(0, 3 * LPS + NE); OU_MMA(1, 2 * LPS + NE); OU_MMA(2, LPS + NE); OU_MMA(3, NE);
+  if (ts_on) c4 = __builtin_readcyclecounter();
 #undef OU_ISSUE
 #undef OU_MMA
   // A^T: the wave's KW + 1 partial GEMM results -> its two output accumulators (even / odd columns of the tile)
@@ -740,6 +749,12 @@ __device__ __forceinline__ void direct2w_tile(const ConvArgs& p, float* smem, in
     out[1] = acc[1] - acc[2] + 0.5f * acc[3] - 2.0f * acc[4] + acc[5];
   }
   Epi::run(p, out, pre, smem, tid, kw, b, m0, n0, 0, 0x7fffffff);
+  if (ts_on && lane == 0) {
+    const long long c5 = __builtin_readcyclecounter();
+    long long* o = p.tstamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + kw) * 8;
+    o[0] = r0; o[1] = c1 - c0; o[2] = (NR > 1 ? c2 : c4) - c1; o[3] = NR > 1 ? c3 - c2 : 0; o[4] = c4 - c3; o[5] = c5 - c4;
+    o[6] = 0; o[7] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
 }
 template <int KW, int WK>
 __global__ __launch_bounds__(64 * WK) void conv_direct2w_kernel(ConvArgs p) {

@@ -32,6 +32,8 @@ for lname, Tin in layers:
         ts = tail[: 4096 * 8 * 8].view(4096, 8, 8).cpu().double()
         on = ts[:, 0, 7] > 0
         ts = ts[on]
+        nwv = int((ts[0, :, 7] > 0).sum().item()) if ts.shape[0] else 8   # 8 waves per block, or 4 (the four-slice variants)
+        ts = ts[:, :nwv]
         nb = ts.shape[0]
         if nb == 0:
             print(f"{lname[-40:]:40s} cfg{used.value}: no stamps (not a direct kernel)")

@@ -29,15 +29,18 @@ model = cls(spec, state_dict=S.synthetic_state_dict(spec, 0), device="cuda:0")
 mix = synth_mix(spec, B, 4 * spec.fs).cuda()
 model.check_status = False
 g = torch.Generator(device="cuda").manual_seed(0)
-for _ in range(2):
-    model.enhance(mix, n_steps=n_steps, rng=g)
-torch.cuda.synchronize()
-# one profiled call with the library's stderr captured
+# the library's stderr (one OU_TRACE line per conv launch) is captured from here on: two warm-up calls, then the profiled one
 sys.stderr.flush()
 saved = os.dup(2)
 tmp = tempfile.TemporaryFile(mode="w+b")
 os.dup2(tmp.fileno(), 2)
 try:
+    for _ in range(2):
+        model.enhance(mix, n_steps=n_steps, rng=g)
+    torch.cuda.synchronize()
+    sys.stderr.flush()
+    tmp.seek(0)
+    tmp.truncate()
     model.profile(True)
     model.enhance(mix, n_steps=n_steps, rng=g)
     torch.cuda.synchronize()

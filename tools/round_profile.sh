@@ -10,9 +10,17 @@ export TMPDIR=/tmp
 O=gpurun_out/final
 rm -rf $O
 mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$PWD}
 timeout 120 python tools/box_health.py 2>&1 | grep "box health" | tee $O/box_health.txt
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -c 400 $O/bench_default.json
+# the same loop under an initialised RCCL group of ONE rank (communicator set-up, device-side weight broadcast, `rccl` block)
+timeout 300 python bench.py --gpus 1 --force-nccl --sustained-s 0 --in-flight "" --batch-sweep "" --no-cpu-baseline --steps 10 --warmup 2 > $O/bench_force_nccl.json 2>> $O/bench_default.err
+python - $O/bench_force_nccl.json <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+print("force-nccl:", d["ms_per_step"], {k: d["rccl"][k] for k in ("ranks", "distinct_device_uuids", "backend", "rccl_version")}, d["weight_broadcast"]["backend"])
+PY
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- \
   python bench.py --sustained-s 0 --in-flight "" --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_under_rocprof.json 2> $O/rocprof.err
 python tools/kstats.py $O/prof/bench_kernel_trace.csv | head -16 | tee $O/kstats_PP16_B1.txt
@@ -71,10 +79,15 @@ timeout 300 python tools/sharded_rate.py PP16 32 2>&1 | grep -v amdgpu.ids > $O/
 # has the 64-row shapes too); its phase stamps; ragged sets through K lanes; what runs beside what; batch x lanes; free-running
 for b in 1 4 8; do OU_LIBRARY=$PWD/open-universe_amd/lib/libouniverse_experiments.so timeout 600 python tools/d4_sweep.py PP16 $b 2>&1 | grep -v amdgpu.ids | cut -c1-330 > $O/d4_sweep_PP16_B$b.txt; tail -1 $O/d4_sweep_PP16_B$b.txt; done
 OU_LIBRARY=$PWD/open-universe_amd/lib/libouniverse_experiments.so timeout 300 python tools/d4_ts.py 1 2>&1 | grep -v amdgpu.ids > $O/d4_ts_B1.txt
-timeout 900 python tools/lanes_rate.py PP16 32 1,2,3,4,8 2>&1 | grep -v amdgpu.ids | tee $O/lanes_rate.txt
+timeout 900 python tools/lanes_rate.py PP16 32 1,2,3,4,6,8 2>&1 | grep -v amdgpu.ids | tee $O/lanes_rate.txt
 for K in 1 2 4; do timeout 300 python tools/lanes_timeline.py $K 32 2>&1 | grep -v amdgpu.ids; done > $O/lanes_timeline.txt
 timeout 600 python tools/lanes_batch.py 64 2>&1 | grep -v amdgpu.ids > $O/lanes_batch.txt
 { timeout 300 python tools/free_run.py; OU_NO_OVERLAP=1 timeout 300 python tools/free_run.py; } 2>&1 | grep -v amdgpu.ids > $O/free_run.txt
+# round 5: the wide-load split-K family per layer (8 / 4 slices, minimal filtering, 16-row tiles, XCD ownerships), phase stamps of
+# the minimal-filtering fused ConvBlock bodies, the two open questions of round 4 (GPU_MAX_HW_QUEUES=2, three lanes)
+timeout 600 python tools/d2_sweep.py PP16 1 -1,2,3 2>&1 | grep -v amdgpu.ids | cut -c1-420 > $O/d2_sweep_PP16_B1.txt; tail -3 $O/d2_sweep_PP16_B1.txt | cut -c1-200
+{ timeout 300 python tools/chainw_ts.py score.enc0; timeout 300 python tools/chainw_ts.py score.dec4; timeout 300 python tools/chainw_ts.py score.enc1; } 2>&1 | grep -v amdgpu.ids | cut -c1-330 > $O/chainw_ts.txt; cat $O/chainw_ts.txt
+bash tools/hwq_probe.sh $O/hwq > /dev/null 2>&1; cp $O/hwq/hwq_probe.txt $O/hwq_probe.txt; cp $O/hwq/lanes3_probe.txt $O/lanes_three_probe.txt; rm -rf $O/hwq; cat $O/hwq_probe.txt | cut -c1-200
 # microbenchmarks behind the design decisions
 for u in xchg_latency launch_overhead vmem_issue; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o /tmp/$u 2>> $O/rocprof.err && timeout 150 /tmp/$u > $O/ubench_$u.txt 2>&1
