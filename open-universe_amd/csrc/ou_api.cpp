@@ -107,7 +107,7 @@ struct Tensor {
 // Tuning / debug switches, read ONCE per C-ABI call: a forward walks ~400 launches and used to call getenv
 // eight times for each of them (a linear scan of the environment: a third of the host time of an enhance call).
 struct EnvCfg {
-  int dbg = 0, xcd_map = -1, conv_direct = 5, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1, d4_force = 0, d4_short = 1, d2_wk = 0, wino = 1, d2_map = -1, unfuse64 = 0;
+  int dbg = 0, xcd_map = -1, conv_direct = 5, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1, d4_force = 0, d4_short = 1, d2_wk = 0, wino = 1, d2_map = -1, unfuse64 = 0, preact = 1;
   int gru_v = 2, gru_bmax = 0, gru_ts = 0, gru_upw = 0, gru_backoff = 0, gru_agent = -1, gru_dbg = 0;
   int dbg_dec0_under_gru = 0;  // OU_DBG_DEC0: measurement only, INVALID results (see run_score)
   double tile_min = -1.0;  // < 0: the launcher's default
@@ -124,6 +124,7 @@ struct EnvCfg {
     d2_wk = geti("OU_D2_WK", 0);
     wino = geti("OU_WINO", 1);
     d2_map = geti("OU_D2_MAP", -1);
+    preact = geti("OU_PREACT", 1);  // 0: every PReLU in its consumer's operand path (ConvArgs::out_act never set)
     unfuse64 = geti("OU_UNFUSE64", 0);
     block3 = geti("OU_BLOCK3", 0);
     gru_v = geti("OU_GRU_V", 2); gru_bmax = geti("OU_GRU_BMAX", 0); gru_ts = std::getenv("OU_GRU_TS") ? 1 : 0;
@@ -219,7 +220,12 @@ struct Runner {
     // small-K rate-change conv of a wide level on rate_down_kernel (`fir` = the filter applied BEFORE the conv, or null)
     bool rate_down = false;
     bool rate_up = false;  // the last up conv on rate_up_kernel (`fir` = the filter AFTER the conv or null, fir_bias / res)
+    // store prelu(y; out_alpha) instead of y (ConvArgs::out_act): for outputs whose only reader is the next PReLU_Conv.  conv()
+    // leaves in `stored_act` whether the kernel that took the layer did so (else y is stored and the reader keeps its PReLU).
+    bool out_act = false;
+    float out_alpha = 1.f;
   };
+  bool stored_act = false;
   bool unsupported = false;
   // conv() in collect mode: the launch arguments are appended here instead of being launched (block(): the three body convs
   // of a deep-level ConvBlock in one launch, conv_block3_kernel)
@@ -252,6 +258,8 @@ struct Runner {
     a.add = e.add; a.add_scale = e.add_scale;
     a.film = e.film; a.film_bstride = e.film_bstride;
     a.res = e.res; a.res_scale = e.res_scale;
+    if (e.out_act && !collect && !e.fir && !e.rate_down && !e.rate_up) { a.out_act = 1; a.out_alpha = e.out_alpha; }
+    stored_act = false;
     if (e.fir && !e.rate_down) { a.fir = e.fir; a.fir_len = e.fir_len; a.bias = e.fir_bias; }  // (also rate_up)
     if (e.rate_down) { a.fir = e.fir; a.fir_len = e.fir ? e.fir_len : 0; }
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
@@ -279,7 +287,12 @@ struct Runner {
     } else if (e.rate_up) {
       chk(launch_rate_up(a, st, &cfg), L.name.c_str());
     } else {
-      const hipError_t le = launch_conv(a, h->num_cu, st, &cfg);
+      hipError_t le = launch_conv(a, h->num_cu, st, &cfg);
+      if (le == hipErrorNotSupported && a.out_act) {  // the kernel for this layer has no activating epilogue: store y
+        a.out_act = 0;
+        le = launch_conv(a, h->num_cu, st, &cfg);
+      }
+      stored_act = a.out_act != 0;
       if (le == hipErrorNotSupported && e.fir) {  // the caller falls back to conv + launch_fir
         if (a.prof) { h->prof.pop_back(); h->prof_used--; }
         unsupported = true;
@@ -481,8 +494,16 @@ struct Runner {
         }
       }
       if (!fused) {
+        // c1 (unless it is exported as a condition) and c2 are read by the next conv only: stored ACTIVATED by the epilogue of the
+        // conv that produces them, so that the reader's operand path has no PReLU (ConvArgs::out_act; bit-identical)
+        const bool c1_private = !need_c1 && !c1_dst;
+        if (env.preact && c1_private && Bk.c2.act) { e1.out_act = true; e1.out_alpha = h->alphas[Bk.c2.a_off]; }
         conv(Bk.c1, hu, nm + ".c1", e1, &c1);
-        conv(Bk.c2, c1, nm + ".c2", Epi(), &c2);
+        Epi e2;
+        e2.act = !stored_act;
+        if (env.preact && Bk.c3.act) { e2.out_act = true; e2.out_alpha = h->alphas[Bk.c3.a_off]; }
+        conv(Bk.c2, c1, nm + ".c2", e2, &c2);
+        e3.act = !stored_act;
         conv(Bk.c3, c2, nm + ".v", e3, &v);
       }
     }
@@ -1314,6 +1335,9 @@ int ou_bench_conv(ou_handle* h, const char* layer, int32_t B, int32_t Tin, int32
   hipStream_t st = (hipStream_t)stream;
   Runner r(h, ws, ws_bytes, false, st, B);
   auto keep = h->tensors;
+  // (kernels whose windows begin a few samples in front of a row read -- and mask -- the bytes in front of their input tensor: it
+  // must not be the first bytes of the caller's allocation; in the model's own layout the status header comes first)
+  r.alloc_raw(64);
   Tensor in = r.alloc("", L->Cin, Tin);
   if (r.oom) return finish(h, r);
   r.chk(hipMemsetAsync(in.p, 0x3c, (size_t)B * L->Cin * Tin * 4, st), "fill");

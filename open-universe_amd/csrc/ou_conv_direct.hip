@@ -434,6 +434,10 @@ struct Direct2Epilogue {
       if (p.add) v = (v + q.ad[j]) * p.add_scale;
       if (p.film) v = q.ga[j] * v + q.be[j];
       if (p.res) v = (v + q.rs[j]) * p.res_scale;
+      if (p.out_act) {
+#pragma unroll
+        for (int oa = 0; oa < 4; oa++) v[oa] = v[oa] >= 0.f ? v[oa] : p.out_alpha * v[oa];
+      }
       if (e_0 == 0 && e_n == 4) {  // 16-byte store at dword alignment (the 401- / 2005-frame levels too)
         *reinterpret_cast<f32x4u*>(p.y + eidx) = v;
       } else {
@@ -476,26 +480,19 @@ __device__ __forceinline__ void direct2_mma(const f32x4& a4, float a1, const f32
 // One ring slot of conv_direct2w_kernel after its wait: window -> (edge fix-up) -> PReLU -> B^T -> KW + 1 MFMAs on independent
 // accumulators.  B^T of F(2, 3): points 0, 1, -1, inf; of F(2, 5): points 0, 1, -1, 1/2, -2, inf, rows scaled to small integers
 // (the scale is in G, ou_model.cpp; tests/test_packing.py holds U, B^T and A^T against the convolution they must reproduce).
-template <int KW>
+template <int KW, bool EDGE, bool ACT>
 __device__ __forceinline__ void direct2w_mma(const f32x4& a4, const f32x2& a2, const f32x4& b4, const f32x2& b2,
-                                             floatx16 (&acc)[KW + 1], float alpha, bool edge, int sh, unsigned vmask) {
-  constexpr int W = KW + 1, PAD = (KW - 1) / 2;
+                                             floatx16 (&acc)[KW + 1], float alpha, unsigned vmask) {
+  constexpr int W = KW + 1;
   const float L[6] = {b4.x, b4.y, b4.z, b4.w, b2.x, b2.y};
   float X[W];
-  if (edge) {  // block-uniform: first / last column tiles only
 #pragma unroll
-    for (int i = 0; i < W; i++) {
-      float v = L[i];  // sh == 0
-#pragma unroll
-      for (int s = 1; s <= PAD; s++) v = sh == s ? (i - s >= 0 ? L[i - s >= 0 ? i - s : 0] : 0.f) : v;
-      X[i] = ((vmask >> i) & 1u) ? v : 0.f;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < W; i++) X[i] = L[i];
+  for (int i = 0; i < W; i++) {
+    X[i] = L[i];
+    if constexpr (EDGE) X[i] = ((vmask >> i) & 1u) ? X[i] : 0.f;  // first / last column tiles only (the window starts in front of the row
+                                                                 // or ends behind it: neighbouring rows' samples, not zeros)
+    if constexpr (ACT) X[i] = X[i] >= 0.f ? X[i] : alpha * X[i];  // (ACT = false: the producer's epilogue stored activated values)
   }
-#pragma unroll
-  for (int i = 0; i < W; i++) X[i] = X[i] >= 0.f ? X[i] : alpha * X[i];
   float V[W];
   wino_bt<KW>(X, V);
   const float A[6] = {a4.x, a4.y, a4.z, a4.w, a2.x, a2.y};
@@ -655,7 +652,10 @@ __global__ __launch_bounds__(64 * WK) void conv_direct2_kernel(ConvArgs p) {
 // tolerance of the path, see DESIGN.md 5.  64-column tiles only (32 tile positions = one MFMA's columns): the 401-frame
 // levels at batch 1 (32-column tiles) stay on conv_direct2_kernel.  OU_WINO=0 switches the variant off.
 // ---------------------------------------------------------------------------------------------------------
-template <int KW, int WK>
+// EDGE: this tile's windows leave the row (first / last column tile); ACT: PReLU in the operand path (false: the producer's
+// epilogue stored activated values, ConvArgs::out_act).  Whole-function variants behind the kernel's block-uniform branch: each
+// has its own register allocation (loop-level variants inside one function made the compiler spill the ring).
+template <int KW, int WK, bool EDGE, bool ACT>
 __device__ __forceinline__ void direct2w_tile(const ConvArgs& p, float* smem, int b, int m0, int n0) {
   constexpr int D = 4, TN = 2, NX = KW + 1, W = NX, KWP = KW == 3 ? 4 : 8, PAD = (KW - 1) / 2;
   constexpr int X2 = NX - 4;                  // elements in the second load of either operand: 0 (k3) / 2 (k5)
@@ -664,20 +664,19 @@ __device__ __forceinline__ void direct2w_tile(const ConvArgs& p, float* smem, in
   constexpr int NE = Epi::NLOAD;
   static_assert(KW == 3 || KW == 5, "k3 / k5");
   static_assert(D * LPS + NE <= 60, "vmcnt");
-  constexpr int BN = 32 * TN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int kw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lhalf = lane >> 5, l31 = lane & 31;
   const int Tin = p.Tin, Mp = p.Mp;
   const float alpha = p.act ? p.alpha_val : 1.0f;
-  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  // (the descriptor starts PAD samples in front of the tensor -- workspace memory, never the first bytes of an allocation --: the
+  // window of the first lane of the first tile, which begins at t = -PAD, is an in-range load whose leading elements are masked)
+  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin - PAD, ((unsigned)p.Cin * (unsigned)Tin + PAD) * 4u);
   const u32x4 rw = direct_desc(p.wu, (unsigned)p.Cin * (unsigned)Mp * (unsigned)KWP * 4u);
   const int avo = ((lhalf * Mp) + m0 + l31) * KWP * 4;
-  // this lane's window: samples t0 .. t0 + W - 1 of row 2I + half; `sh` = samples cut off in front of the row
+  // this lane's window: samples t0 .. t0 + W - 1 of row 2I + half
   const int t0 = n0 + TN * l31 - PAD;
-  const int sh = t0 < 0 ? -t0 : 0;
-  const int bvo = (t0 + sh < Tin) ? (lhalf * Tin + t0 + sh) * 4 : (int)0x80000000;
-  const bool edge = __builtin_amdgcn_readfirstlane((n0 < PAD || n0 + BN + KW - 1 - PAD > Tin) ? 1 : 0) != 0;
+  const int bvo = (t0 < Tin) ? (lhalf * Tin + t0 + PAD) * 4 : (int)0x80000000;
   unsigned vmask = 0;  // bit i: window element i is inside the row
 #pragma unroll
   for (int i = 0; i < W; i++) vmask |= (t0 + i >= 0 && t0 + i < Tin) ? (1u << i) : 0u;
@@ -714,7 +713,7 @@ __device__ __forceinline__ void direct2w_tile(const ConvArgs& p, float* smem, in
     asm volatile("" : "+v"(b4[d]));                                                                                  \
     if constexpr (X2 == 2) asm volatile("" : "+v"(a2[d]));                                                           \
     if constexpr (X2 == 2) asm volatile("" : "+v"(b2[d]));                                                           \
-    direct2w_mma<KW>(a4[d], a2[d], b4[d], b2[d], acc, alpha, edge, sh, vmask);                                       \
+    direct2w_mma<KW, EDGE, ACT>(a4[d], a2[d], b4[d], b2[d], acc, alpha, vmask);                                      \
   }
   // tuning only (OU_TS): per-wave phase stamps, as in conv_direct2_kernel
   const bool ts_on = p.tstamps != nullptr;
@@ -762,7 +761,16 @@ __global__ __launch_bounds__(64 * WK) void conv_direct2w_kernel(ConvArgs p) {
   int tile_m, tile_n;
   if (!direct_tile(p, tile_m, tile_n)) return;
   if (p.prof && threadIdx.x == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
-  direct2w_tile<KW, WK>(p, smem, blockIdx.z, tile_m * 32, tile_n * 64);
+  const int n0 = tile_n * 64;
+  constexpr int PAD = (KW - 1) / 2;
+  const bool edge = n0 < PAD || n0 + 64 + KW - 1 - PAD > p.Tin;  // (block-uniform)
+  if (edge) {
+    if (p.act) direct2w_tile<KW, WK, true, true>(p, smem, blockIdx.z, tile_m * 32, n0);
+    else direct2w_tile<KW, WK, true, false>(p, smem, blockIdx.z, tile_m * 32, n0);
+  } else {
+    if (p.act) direct2w_tile<KW, WK, false, true>(p, smem, blockIdx.z, tile_m * 32, n0);
+    else direct2w_tile<KW, WK, false, false>(p, smem, blockIdx.z, tile_m * 32, n0);
+  }
   if (p.prof && threadIdx.x == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
@@ -1125,8 +1133,9 @@ hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream,
     if (a.force_cfg < 0 && (fused + slots - 1) / slots > (plain + slots - 1) / slots) return hipErrorNotSupported;
   }
   int wk = 8;
-  if (a.stride == 1 && a.wd && a.direct >= 2 && !a.fir && a.up == 1 && (a.KW == 3 || a.KW == 5) && npw % 4 == 0 &&
-      a.pad == (a.KW - 1) / 2 && (long)a.Cin * a.Mp * 8 * 4 < (1L << 31) && (long)a.Cout * a.Tout * 4 < (1L << 31)) {
+  const bool wide = a.stride == 1 && a.wd && a.direct >= 2 && !a.fir && a.up == 1 && (a.KW == 3 || a.KW == 5) && npw % 4 == 0 &&
+                    a.pad == (a.KW - 1) / 2 && (long)a.Cin * a.Mp * 8 * 4 < (1L << 31) && (long)a.Cout * a.Tout * 4 < (1L << 31);
+  if (wide) {
     // wide-load variant (taps-innermost weight copy); the reduction split over 8 or 4 waves (direct2_pick)
     bool wino = false;
     direct2_pick(a, num_cu, tn, wk, wino);
@@ -1166,6 +1175,7 @@ hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream,
     }
   }
   if (!kern) return a.fir ? hipErrorNotSupported : hipErrorInvalidConfiguration;
+  if (a.out_act && !wide) return hipErrorNotSupported;  // (only Direct2Epilogue -- the wide-load kernels -- has the activating form)
   ConvArgs aa = a;
   const int BN = 32 * tn;
   aa.magic_up = a.up == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.up) + 1u;

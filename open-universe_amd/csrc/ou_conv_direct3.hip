@@ -216,6 +216,10 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
         if (p.add) v = (v + ad[r]) * p.add_scale;
         if (filmb) v = ga[r] * v + be[r];
         if (p.res) v = (v + rs[r]) * p.res_scale;
+        if (p.out_act) {
+#pragma unroll
+          for (int oa = 0; oa < 4; oa++) v[oa] = v[oa] >= 0.f ? v[oa] : p.out_alpha * v[oa];
+        }
         if (vec4) {
           *reinterpret_cast<f32x4u*>(p.y + idx) = v;
         } else {
@@ -239,8 +243,9 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
 // four adjacent samples exactly as before.  32-row tiles only (TM = 2): the accumulators of a 64-row tile would not leave room
 // for the ring (k3: 64 + 56 ring registers at TM = 2, 128 + 88 at TM = 4).
 // ---------------------------------------------------------------------------------------------------------
-template <int KW, int TM, bool PRE>
-__global__ __launch_bounds__(256, 2) void conv_direct3w_kernel(ConvArgs p) {
+// (EDGE / ACT: whole-function variants behind the kernel's wave-uniform branch, see direct2w_tile)
+template <int KW, int TM, bool PRE, bool EDGE, bool ACT>
+__device__ __forceinline__ void direct3w_body(const ConvArgs& p) {
   constexpr int D = 4, TN = 4, NX = KW + 1, W = KW + TN - 1, KWP = KW == 3 ? 4 : 8, PAD = (KW - 1) / 2;
   constexpr int A2 = KW == 5 ? 1 : 0;       // second A load per row tile (U_4, U_5)
   constexpr int LPS = TM * (1 + A2) + 2;    // load instructions per ring slot
@@ -256,13 +261,13 @@ __global__ __launch_bounds__(256, 2) void conv_direct3w_kernel(ConvArgs p) {
   const int l15 = lane & 15, kk = lane >> 4;
   const int Tin = p.Tin, Mp = p.Mp;
   const float alpha = p.act ? p.alpha_val : 1.0f;
-  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  // (the descriptor starts PAD samples in front of the tensor -- workspace memory, never the first bytes of an allocation --: the
+  // window of the first lane of the first tile, which begins at t = -PAD, is an in-range load whose leading elements are masked)
+  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin - PAD, ((unsigned)p.Cin * (unsigned)Tin + PAD) * 4u);
   const u32x4 rw = direct_desc(p.wu, (unsigned)p.Cin * (unsigned)Mp * (unsigned)KWP * 4u);
   const int avo = (kk * Mp + m0 + l15) * KWP * 4;
   const int t0 = n0 + TN * l15 - PAD;
-  const int sh = t0 < 0 ? -t0 : 0;
-  const int bvo = (t0 + sh < Tin) ? (kk * Tin + t0 + sh) * 4 : (int)0x80000000;
-  const bool edge = __builtin_amdgcn_readfirstlane((n0 < PAD || n0 + 64 + KW - 1 - PAD > Tin) ? 1 : 0) != 0;
+  const int bvo = (t0 < Tin) ? (kk * Tin + t0 + PAD) * 4 : (int)0x80000000;
   unsigned vmask = 0;  // bit i: window element i is inside the row
 #pragma unroll
   for (int i = 0; i < W; i++) vmask |= (t0 + i >= 0 && t0 + i < Tin) ? (1u << i) : 0u;
@@ -314,16 +319,11 @@ __global__ __launch_bounds__(256, 2) void conv_direct3w_kernel(ConvArgs p) {
     const float Lw[8] = {b4[d].x, b4[d].y, b4[d].z, b4[d].w, KW == 3 ? b2[d].x : b4b[d].x, KW == 3 ? b2[d].y : b4b[d].y, \
                          b4b[d].z, b4b[d].w};                                                                         \
     float X[W];                                                                                                       \
-    if (edge) {                                                                                                       \
-      _Pragma("unroll") for (int i = 0; i < W; i++) {                                                                 \
-        float v = Lw[i];                                                                                              \
-        _Pragma("unroll") for (int s2 = 1; s2 <= PAD; s2++) v = sh == s2 ? (i - s2 >= 0 ? Lw[i - s2 >= 0 ? i - s2 : 0] : 0.f) : v; \
-        X[i] = ((vmask >> i) & 1u) ? v : 0.f;                                                                         \
-      }                                                                                                               \
-    } else {                                                                                                          \
-      _Pragma("unroll") for (int i = 0; i < W; i++) X[i] = Lw[i];                                                     \
+    _Pragma("unroll") for (int i = 0; i < W; i++) {                                                                   \
+      X[i] = Lw[i];                                                                                                   \
+      if constexpr (EDGE) X[i] = ((vmask >> i) & 1u) ? X[i] : 0.f;                                                    \
+      if constexpr (ACT) X[i] = X[i] >= 0.f ? X[i] : alpha * X[i];                                                    \
     }                                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < W; i++) X[i] = X[i] >= 0.f ? X[i] : alpha * X[i];                           \
     _Pragma("unroll") for (int q = 0; q < 2; q++) {                                                                   \
       float V[NX];                                                                                                    \
       wino_bt<KW>(X + 2 * q, V);                                                                                      \
@@ -424,6 +424,10 @@ __global__ __launch_bounds__(256, 2) void conv_direct3w_kernel(ConvArgs p) {
         if (p.add) v = (v + ad[r]) * p.add_scale;
         if (filmb) v = ga[r] * v + be[r];
         if (p.res) v = (v + rs[r]) * p.res_scale;
+        if (p.out_act) {
+#pragma unroll
+          for (int oa = 0; oa < 4; oa++) v[oa] = v[oa] >= 0.f ? v[oa] : p.out_alpha * v[oa];
+        }
         if (vec4) {
           *reinterpret_cast<f32x4u*>(p.y + idx) = v;
         } else {
@@ -435,6 +439,23 @@ __global__ __launch_bounds__(256, 2) void conv_direct3w_kernel(ConvArgs p) {
     }
   }
   if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+template <int KW, int TM, bool PRE>
+__global__ __launch_bounds__(256, 2) void conv_direct3w_kernel(ConvArgs p) {
+  constexpr int PAD = (KW - 1) / 2;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q8 = blockIdx.x >> 3, cidx = (q8 / p.grid_m) * 8 + (blockIdx.x & 7);
+  const int chunk = cidx - (cidx / p.grid_n) * p.grid_n;
+  const int n0 = (chunk * 4 + wv) * 64;
+  const bool edge = n0 < PAD || n0 + 64 + KW - 1 - PAD > p.Tin;  // (wave-uniform)
+  if (edge) {
+    if (p.act) direct3w_body<KW, TM, PRE, true, true>(p);
+    else direct3w_body<KW, TM, PRE, true, false>(p);
+  } else {
+    if (p.act) direct3w_body<KW, TM, PRE, false, true>(p);
+    else direct3w_body<KW, TM, PRE, false, false>(p);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -696,6 +717,7 @@ static hipError_t launch_conv_direct3s(const ConvArgs& a, int num_cu, hipStream_
   const long gy = (a.M + 63) / 64, ct = (a.Nq + 63) / 64;
   const double per_simd = (double)gy * ct * a.B / (4.0 * num_cu);
   if (a.force_cfg < 200 && per_simd < tile_min) return hipErrorInvalidConfiguration;
+  if (a.out_act) return hipErrorNotSupported;  // (this kernel would take the layer, but has no activating epilogue)
   ConvArgs aa = a;
   aa.grid_m = (int)gy;
   aa.magic_up = a.up == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.up) + 1u;
@@ -709,6 +731,7 @@ hipError_t launch_conv_direct3(const ConvArgs& a, int num_cu, hipStream_t stream
   const double tile_min_s = a.tile_min >= 0 ? a.tile_min : 1.2;
   if (a.KW == 1 || a.stride > 1) {
     if (tile_min_s > 0 && a.Nq < 1024 && a.force_cfg < 200) return hipErrorInvalidConfiguration;
+
     // (with the up-path FIR requested as a fused epilogue: refuse, so that the caller runs conv + FIR pass -- unless the layer
     // is too small for this kernel anyway, then the split-K kernel with its fused FIR gets its chance)
     if (a.fir) {

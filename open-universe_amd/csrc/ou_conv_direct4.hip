@@ -330,12 +330,14 @@ __global__ __launch_bounds__(64 * WK) void conv_direct4w_kernel(ConvArgs p) {
   const int l15 = lane & 15, kk = lane >> 4;
   const int Tin = p.Tin, Mp = p.Mp;
   const float alpha = p.act ? p.alpha_val : 1.0f;
-  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin, (unsigned)p.Cin * (unsigned)Tin * 4u);
+  // (the descriptor starts PAD samples in front of the tensor -- workspace memory, never the start of an allocation -- so that the
+  // window of the first lane of the first tile, which begins at t = -PAD, is an ordinary in-range load whose first elements are
+  // masked like those behind the end of a row: one select per window element in the two edge tiles, none elsewhere)
+  const u32x4 rx = direct_desc(p.x + (size_t)b * p.Cin * Tin - PAD, ((unsigned)p.Cin * (unsigned)Tin + PAD) * 4u);
   const u32x4 rw = direct_desc(p.wu, (unsigned)p.Cin * (unsigned)Mp * (unsigned)KWP * 4u);
   const int avo = (kk * Mp + m0 + l15) * KWP * 4;
   const int t0 = n0 + TN * l15 - PAD;
-  const int sh = t0 < 0 ? -t0 : 0;
-  const int bvo = (t0 + sh < Tin) ? (kk * Tin + t0 + sh) * 4 : (int)0x80000000;
+  const int bvo = (t0 < Tin) ? (kk * Tin + t0 + PAD) * 4 : (int)0x80000000;
   const bool edge = __builtin_amdgcn_readfirstlane((n0 < PAD || n0 + 64 + KW - 1 - PAD > Tin) ? 1 : 0) != 0;
   unsigned vmask = 0;  // bit i: window element i is inside the row
 #pragma unroll
@@ -377,6 +379,9 @@ __global__ __launch_bounds__(64 * WK) void conv_direct4w_kernel(ConvArgs p) {
   }
 #define OU_MMA(d, out)                                                                                                \
   {                                                                                                                   \
+    if (ts_on) { const long long ta = __builtin_readcyclecounter();                                                  \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS) : "memory");                                              \
+      twait += (unsigned)(__builtin_readcyclecounter() - ta); }                                                                               \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS));                                                           \
     _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                  \
       asm volatile("" : "+v"(a4[d][i]));                                                                              \
@@ -388,16 +393,11 @@ __global__ __launch_bounds__(64 * WK) void conv_direct4w_kernel(ConvArgs p) {
     const float Lw[8] = {b4[d].x, b4[d].y, b4[d].z, b4[d].w, KW == 3 ? b2[d].x : b4b[d].x, KW == 3 ? b2[d].y : b4b[d].y, \
                          b4b[d].z, b4b[d].w};                                                                         \
     float X[W];                                                                                                       \
-    if (edge) {                                                                                                       \
-      _Pragma("unroll") for (int i = 0; i < W; i++) {                                                                 \
-        float v = Lw[i];                                                                                              \
-        _Pragma("unroll") for (int s2 = 1; s2 <= PAD; s2++) v = sh == s2 ? (i - s2 >= 0 ? Lw[i - s2 >= 0 ? i - s2 : 0] : 0.f) : v; \
-        X[i] = ((vmask >> i) & 1u) ? v : 0.f;                                                                         \
-      }                                                                                                               \
-    } else {                                                                                                          \
-      _Pragma("unroll") for (int i = 0; i < W; i++) X[i] = Lw[i];                                                     \
+    _Pragma("unroll") for (int i = 0; i < W; i++) {                                                                   \
+      X[i] = Lw[i];                                                                                                   \
+      if constexpr (EDGE) X[i] = ((vmask >> i) & 1u) ? X[i] : 0.f;                                                    \
+      if constexpr (ACT) X[i] = X[i] >= 0.f ? X[i] : alpha * X[i];                                                    \
     }                                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < W; i++) X[i] = X[i] >= 0.f ? X[i] : alpha * X[i];                           \
     _Pragma("unroll") for (int q = 0; q < 2; q++) {                                                                   \
       float V[NX];                                                                                                    \
       wino_bt<KW>(X + 2 * q, V);                                                                                      \
@@ -408,16 +408,34 @@ __global__ __launch_bounds__(64 * WK) void conv_direct4w_kernel(ConvArgs p) {
         }                                                                                                             \
     }                                                                                                                 \
   }
-  OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
-  const int NR = NS / 4;
-  for (int r = 0; r + 1 < NR; r++) {
-    const int g = r * 4;
-    OU_MMA(0, 3); OU_ISSUE(g + 4, 0);
-    OU_MMA(1, 3); OU_ISSUE(g + 5, 1);
-    OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
-    OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
+  // tuning only (OU_TS, tools/d4_ts.py): per-wave phase stamps
+  const bool ts_on = p.tstamps != nullptr;
+  long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0, tr0 = 0;
+  unsigned twait = 0;  // cycles inside the loop's s_waitcnt vmcnt
+  if (ts_on) { tr0 = (long long)__builtin_amdgcn_s_memrealtime(); tc0 = __builtin_readcyclecounter(); }
+  // four copies of the loop behind block-uniform branches: with / without the edge masks, with / without the PReLU of the operand
+  // path (act = 0: the producer's epilogue stored activated values, ConvArgs::out_act)
+  auto run = [&](auto edge_c, auto act_c) __attribute__((always_inline)) {
+    constexpr bool EDGE = decltype(edge_c)::value, ACT = decltype(act_c)::value;
+    OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
+    if (ts_on) tc1 = __builtin_readcyclecounter();
+    const int NR = NS / 4;
+    for (int r = 0; r + 1 < NR; r++) {
+      const int g = r * 4;
+      OU_MMA(0, 3); OU_ISSUE(g + 4, 0);
+      OU_MMA(1, 3); OU_ISSUE(g + 5, 1);
+      OU_MMA(2, 3); OU_ISSUE(g + 6, 2);
+      OU_MMA(3, 3); OU_ISSUE(g + 7, 3);
+    }
+    OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
+  };
+  const bool act_on = p.act != 0;
+  if (edge) {
+    if (act_on) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{});
+  } else {
+    if (act_on) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{});
   }
-  OU_MMA(0, 3); OU_MMA(1, 2); OU_MMA(2, 1); OU_MMA(3, 0);
+  if (ts_on) tc2 = __builtin_readcyclecounter();
 #undef OU_ISSUE
 #undef OU_MMA
 
@@ -440,7 +458,9 @@ __global__ __launch_bounds__(64 * WK) void conv_direct4w_kernel(ConvArgs p) {
       }
       *reinterpret_cast<f32x4*>(&Ew[(16 * i + 4 * kk + r) * EP + 4 * l15]) = v;
     }
+  if (ts_on) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tc3 = __builtin_readcyclecounter(); }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (ts_on) tc4 = __builtin_readcyclecounter();
   const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
   const size_t ybase = (size_t)b * p.Cout * p.Tout;
   const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
@@ -474,6 +494,10 @@ __global__ __launch_bounds__(64 * WK) void conv_direct4w_kernel(ConvArgs p) {
     if (p.add) v = (v + ad) * p.add_scale;
     if (filmb) v = filmb[m] * v + filmb[p.Cout + m];
     if (p.res) v = (v + rs) * p.res_scale;
+    if (p.out_act) {
+#pragma unroll
+      for (int s = 0; s < 4; s++) v[s] = v[s] >= 0.f ? v[s] : p.out_alpha * v[s];
+    }
     if (full) {
       *reinterpret_cast<f32x4u*>(p.y + idx) = v;
     } else {
@@ -481,6 +505,12 @@ __global__ __launch_bounds__(64 * WK) void conv_direct4w_kernel(ConvArgs p) {
       for (int s = 0; s < 4; s++)
         if (cq + s < nvalid) p.y[idx + s] = v[s];
     }
+  }
+  if (ts_on && lane == 0) {  // {start ticks, cycles: prologue, loop, A^T + slab write, barrier wait, reduce + store, -, end ticks}
+    const long long tc5 = __builtin_readcyclecounter();
+    long long* o = p.tstamps + ((size_t)blockIdx.x * WK + wk) * 8;
+    o[0] = tr0; o[1] = tc1 - tc0; o[2] = tc2 - tc1; o[3] = tc3 - tc2; o[4] = tc4 - tc3; o[5] = tc5 - tc4; o[6] = twait;
+    o[7] = (long long)__builtin_amdgcn_s_memrealtime();
   }
   if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
@@ -638,6 +668,7 @@ hipError_t launch_conv_direct4(const ConvArgs& a, int num_cu, hipStream_t stream
       if (c.R == R && slots % (c.WK * c.D) == 0 && code(c) == want) { best = &c; break; }
   }
   if (!best) return hipErrorInvalidConfiguration;
+  if (a.out_act) return hipErrorNotSupported;  // (this family would take the layer, but has no activating epilogue)
   if (probe) return hipSuccess;
   const Direct4Cfg& c = *best;
   ConvArgs aa = a;

@@ -557,6 +557,7 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
     if (blocks >= want) break;
   }
   if (pick < 0) return hipErrorInvalidConfiguration;
+  if (a.out_act) return hipErrorNotSupported;  // (the LDS-tiled kernels have no activating epilogue)
   const ConvCfg& c = kConvCfgs[pick];
   if (cfg_out) *cfg_out = pick;
   ConvArgs aa = a;

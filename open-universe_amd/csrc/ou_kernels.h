@@ -53,6 +53,14 @@ struct ConvArgs {
   // Anti-alias FIR of the up path fused into the epilogue (direct kernel, up > 1, KW == 1 only; launch_conv returns
   // hipErrorNotSupported otherwise and the caller runs launch_fir after a plain launch):
   //   y = FIR_{2 up + 1}(u) + bias ; y = res ? (y + res) * res_scale : y,   u = the transposed conv's output WITHOUT bias
+  // Activation moved from the consumer's operand path to the producer's epilogue (round 5): with out_act the kernel stores
+  // prelu(y; out_alpha) INSTEAD of y -- for tensors whose only reader is the next PReLU_Conv (conv1 -> conv2 -> conv3 inside a
+  // ConvBlock, blocks.py:395-399); that conv then runs with act = 0 and its loop has no PReLU (every input element used to be
+  // activated again by every row group and every overlapping window, and each VALU instruction beside fp32 MFMAs costs ~3 cycles
+  // of the matrix pipe: tools/ubench/mfma_valu_mix.hip).  Same arithmetic on the same values: bit-identical.
+  // Kernels without the epilogue form return hipErrorNotSupported (the caller stores y and keeps act = 1 downstream).
+  int out_act = 0;
+  float out_alpha = 1.f;
   const float* fir = nullptr;
   int fir_len = 0;
   int tile_bm = 32, tile_bn = 0, tile_halo = 0;  // filled by launch_conv_direct: rows / columns a tile advances by, left halo

@@ -476,6 +476,28 @@ def test_four_slice_wide_load_kernel_vs_eight_slices(name, B, T, monkeypatch):
 
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 1, 64000), ("PP16", 2, 23517), ("PP16", 3, 777), ("OR16", 2, 9000), ("PP24", 1, 30011),
+                                      ("PP16", 1, 161), ("PP16", 8, 16000), ("PP24", 4, 8000)])
+def test_activation_in_the_producer_epilogue_is_bit_identical(name, B, T, monkeypatch):
+    """Inside a ConvBlock (blocks.py:395-399) conv1's and conv2's outputs are read by the next PReLU_Conv only: the epilogue that
+    produces them stores prelu(y) (ConvArgs::out_act) and the reader's operand path has no PReLU -- the same fp32 operation on the
+    same values, once per element instead of once per (row group, overlapping window).  Against OU_PREACT=0 (every PReLU in the
+    consumer's loop) over whole enhance calls: bit-identical at every batch size / kernel family (split-K kernels at small batch,
+    the no-split-K ones from batch 4), ragged and tiny lengths included; with the edge windows read from in front of the row
+    and masked (first column tile) instead of shifted."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(67, 2, B, Tp)
+    monkeypatch.setenv("OU_PREACT", "0")
+    ref = run_enhance(model, mix, nz, n_steps=2)
+    n_ref = model.launch_stats()
+    monkeypatch.delenv("OU_PREACT")
+    out = run_enhance(model, mix, nz, n_steps=2)
+    assert model.launch_stats() == n_ref
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("name,B,T", [("PP16", 1, 64000), ("PP16", 2, 23517), ("PP16", 3, 777), ("OR16", 2, 9000), ("PP24", 1, 30011),
                                       ("PP16", 1, 4001)])
 def test_minimal_filtering_kernels_vs_plain_summation(name, B, T, monkeypatch):
     """conv_direct2w_kernel (Winograd / Cook-Toom F(2, 3) and F(2, 5): KW + 1 instead of 2 KW products per pair of adjacent

@@ -17,11 +17,12 @@ p = "_edm_model"
 T0 = 64160
 layers = [(p + ".encoder.gru#l0", T0 // 160, 128, 1), (p + ".decoder.up_modules.2.rate_change_conv", T0 // 32, 64, 1),
           (p + ".decoder.up_modules.3.rate_change_conv", T0 // 8, 32, 1), (p + ".encoder.ds_modules.2.rate_change_conv", T0 // 8, 32, 4),
-          (p + ".decoder.signal_cond_proj.0", T0 // 160, 128, 1)]
+          (p + ".decoder.signal_cond_proj.0", T0 // 160, 128, 1),
+          (p + ".encoder.ds_modules.4.conv1", T0 // 160, 128, 0), (p + ".encoder.ds_modules.4.conv2", T0 // 160, 128, 0)]
 ws = torch.zeros(1 << 29, dtype=torch.uint8, device="cuda")
 tail = ws[ws.numel() - (16 << 20):].view(torch.int64)
 for lname, Tin, slots, R in layers:
-    for cfg in (-1, 323, 343, 322, 342):
+    for cfg in ((-1, 323, 343, 322, 342) if R else (-1,)):
         tm, wk = ((cfg - 300) // 10, 1 << ((cfg - 300) % 10)) if cfg > 0 else (0, 0)
         ms, used = c_float(), c_int32()
         tail.zero_()
@@ -32,6 +33,17 @@ for lname, Tin, slots, R in layers:
             continue
         torch.cuda.synchronize()
         u = used.value
+        if 600 <= u < 800:  # conv_direct4w_kernel: 600 / 700 + 10 TM + KW
+            wk, tm, kw = (8 if u < 700 else 4), (u % 100) // 10, u % 10
+            ts = tail[: 8192 * 8 * 8].view(-1, 8).cpu().double()
+            ts = ts[ts[:, 7] > 0]
+            t0, t1 = ts[:, 0], ts[:, 7]
+            m, mx = ts.mean(dim=0), ts.max(dim=0).values
+            mfma = slots / wk * 2 * (kw + 1) * tm * 32
+            print(f"{lname[-40:]:40s} cfg{u} {ms.value * 1e3:6.1f} us/launch | {ts.shape[0]} waves, span {(t1.max() - t0.min()).item() / 100:5.1f} us "
+                  f"| cycles/wave mean (max): prologue {m[1]:5.0f} ({mx[1]:5.0f}) loop {m[2]:6.0f} ({mx[2]:6.0f}) [MFMA {mfma:6.0f}] "
+                  f"(of which in s_waitcnt vmcnt {m[6]:6.0f}) A^T + slab write {m[3]:5.0f} ({mx[3]:5.0f}) barrier wait {m[4]:5.0f} ({mx[4]:5.0f}) reduce + store {m[5]:5.0f} ({mx[5]:5.0f})", flush=True)
+            continue
         if not 300 <= u < 400:
             print(f"{lname[-40:]:40s} cfg{u} {ms.value * 1e3:6.1f} us/launch (not conv_direct4_kernel)")
             continue

@@ -81,5 +81,21 @@ int main() {
       run<4>(buf, sink, out, blocks, np, rowlen);
     }
   }
+  // Is the ~14-20 B/clk/CU of the L2-streaming case a per-CU limit or an aggregate one?  The same stream from fewer blocks
+  // (one 8-wave block per CU while blocks <= 256): bytes per clock per BLOCK and the aggregate.
+  for (int blocks : {16, 32, 64, 128, 192, 256}) {
+    const int np = 24, rep = 20;
+    hipLaunchKernelGGL((stream_kernel<4>), dim3(blocks), dim3(512), 0, 0, buf, rowlen, np, 2, sink, out);
+    hipLaunchKernelGGL((stream_kernel<4>), dim3(blocks), dim3(512), 0, 0, buf, rowlen, np, rep, sink, out);
+    CHECK(hipDeviceSynchronize());
+    long long h[1024];
+    CHECK(hipMemcpy(h, out, blocks * 8, hipMemcpyDeviceToHost));
+    double avg = 0;
+    for (int i = 0; i < blocks; i++) avg += h[i];
+    avg /= blocks;
+    const double bytes = (double)rep * np * 8 * 1024.0;
+    printf("  dwordx4 L2 stream, %3d blocks of 8 waves: %6.1f B/clk per block, aggregate %7.0f B/clk\n", blocks, bytes / avg,
+           bytes / avg * blocks);
+  }
   return 0;
 }
