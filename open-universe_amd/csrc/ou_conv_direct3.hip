@@ -308,6 +308,9 @@ __device__ __forceinline__ void direct3w_body(const ConvArgs& p) {
 #define OU_MMA(d, out) OU_MMAX(d, out, 0)
 #define OU_MMAX(d, out, extra)                                                                                        \
   {                                                                                                                   \
+    if (ts_on) { const long long ta = __builtin_readcyclecounter();                                                  \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS + (extra)) : "memory");                                    \
+      twait += (unsigned)(__builtin_readcyclecounter() - ta); }                                                       \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((out) * LPS + (extra)));                                                 \
     _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                  \
       asm volatile("" : "+v"(a4[d][i]));                                                                              \
@@ -346,6 +349,11 @@ __device__ __forceinline__ void direct3w_body(const ConvArgs& p) {
   const float* pre = p.res ? p.res : p.add;  // the operand that is prefetched (PRE: see conv_direct3_kernel)
   constexpr bool pre_on = PRE;
   float* const slab = smem3 + wv * (NDMA * 256);
+  // tuning only (OU_TS, tools/d3_ts.py): cycles in the loop and inside its s_waitcnt vmcnt
+  const bool ts_on = p.tstamps != nullptr;
+  unsigned twait = 0;
+  long long tl0 = 0, tr0 = 0;
+  if (ts_on) { tr0 = (long long)__builtin_amdgcn_s_memrealtime(); tl0 = __builtin_readcyclecounter(); }
   {
     OU_ISSUE(0, 0); OU_ISSUE(1, 1); OU_ISSUE(2, 2); OU_ISSUE(3, 3);
     const int NR = NG / 4;
@@ -375,6 +383,7 @@ __device__ __forceinline__ void direct3w_body(const ConvArgs& p) {
 #undef OU_ISSUE
 #undef OU_MMA
 #undef OU_MMAX
+  const long long tl1 = ts_on ? __builtin_readcyclecounter() : 0;
 
   // ---- epilogue: A^T, then bias, cond add, FiLM, residual -- straight from the accumulators, 16 bytes per lane and row
   if (ncol > 0) {
@@ -437,6 +446,11 @@ __device__ __forceinline__ void direct3w_body(const ConvArgs& p) {
         }
       }
     }
+  }
+  if (ts_on && lane == 0 && blockIdx.x < 2048) {  // {start ticks, loop cycles, cycles in s_waitcnt vmcnt, epilogue cycles, -, -, -, end ticks}
+    long long* o = p.tstamps + ((size_t)blockIdx.x * 4 + wv) * 8;
+    o[0] = tr0; o[1] = tl1 - tl0; o[2] = twait; o[3] = __builtin_readcyclecounter() - tl1; o[4] = 0; o[5] = 0; o[6] = 0;
+    o[7] = (long long)__builtin_amdgcn_s_memrealtime();
   }
   if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
