@@ -109,12 +109,14 @@ struct Tensor {
 struct EnvCfg {
   int dbg = 0, xcd_map = -1, conv_direct = 5, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1, d4_force = 0, d4_short = 1, d2_wk = 0, wino = 1, d2_map = -1, unfuse64 = 0, preact = 1;
   int gru_v = 2, gru_bmax = 0, gru_ts = 0, gru_upw = 0, gru_backoff = 0, gru_agent = -1, gru_dbg = 0;
+  int split = -1;  // OU_SPLIT (ConvArgs::split)
   int dbg_dec0_under_gru = 0;  // OU_DBG_DEC0: measurement only, INVALID results (see run_score)
   double tile_min = -1.0;  // < 0: the launcher's default
   int tile_prefetch = 1;
   std::string chain_ts;
   static int geti(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
   EnvCfg() {
+    split = geti("OU_SPLIT", -1);
     dbg = geti("OU_DBG", 0); xcd_map = geti("OU_XCD_MAP", -1); conv_direct = geti("OU_CONV_DIRECT", 5);
     fuse = geti("OU_FUSE", -1); fuse_nc = geti("OU_FUSE_NC", 0); rate_small = geti("OU_RATE_SMALL", 1);
     fuse_upfir = geti("OU_FUSE_UPFIR", 1);
@@ -252,6 +254,8 @@ struct Runner {
     ConvArgs a;
     a.x = in.p; a.w = W(L.w_off); a.bias = W(L.b_off); a.y = out.p;
     if (L.KWP) { a.wd = W(L.wd_off); a.wu = W(L.wu_off); }
+    if (L.ws_on) a.wsplit = W(L.ws_off);
+    a.split = env.split;
     a.in_scale = e.in_scale;
     a.act = (L.act && e.act) ? 1 : 0;
     a.alpha_val = a.act ? h->alphas[L.a_off] : 0.f;

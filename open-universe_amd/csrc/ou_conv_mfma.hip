@@ -480,6 +480,8 @@ hipError_t init_conv_kernels() {
   if (e_d3 != hipSuccess) return e_d3;
   e_d3 = init_direct4_kernels();
   if (e_d3 != hipSuccess) return e_d3;
+  e_d3 = init_split_kernels();
+  if (e_d3 != hipSuccess) return e_d3;
   return init_chain_kernels();
 }
 
@@ -487,6 +489,22 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   if (a.Cin % a.CK || a.CK < 2 || (a.CK & (a.CK - 1)) || a.Mp % 64 || a.Nq <= 0) return hipErrorInvalidValue;
   // Deep levels (what the 8-wave split-K configs below were built for): the register-direct kernels.  Wide levels
   // (many blocks of 64 x 128 per CU without splitting K) stay on the LDS-tiled configs.
+  // Stride-1 k3 / k5 layers with enough work per launch to feed the BF16 matrix pipe: the bf16-split kernel (conv_split_kernel,
+  // six bf16 products per fp32 product, 2.67x the f32 MFMA rate).  Rule from tools/ubench/split_conv.hip against the per-layer
+  // tables of the fp32 kernels (profiles/r05_split_*): it wins from 256 rows up once a launch fills the device twice over with
+  // 128-column tiles (PP16: the 256- / 512-channel levels from B = 16, the 256-channel k5 convs from B = 8); below that the
+  // minimal-filtering fp32 kernels are ahead (their epilogues move 16 bytes per lane, their tiles are a quarter the size).
+  if (a.wsplit && a.split != 0 && (a.force_cfg < 0 || (a.force_cfg >= 800 && a.force_cfg < 1100))) {
+    const double tiles = (double)(a.M / 64) * ((a.Nq + 127) / 128) * a.B / 4.0;  // 256 x 128 blocks' worth of output
+    // (short rows -- the 401-frame level -- are on the split-K fp32 kernels otherwise: ahead from half a device of such blocks,
+    // k3 included; long rows: k5 from half a device, k3 from a whole one)
+    const bool rule = a.M >= 256 && a.M % 256 == 0 && tiles >= ((a.KW == 5 || a.Nq < 1024) ? 0.45 : 0.9) * num_cu;
+    if (a.split == 1 || a.force_cfg >= 800 || rule) {
+      hipError_t e = launch_conv_split(a, num_cu, stream, cfg_out);
+      if (e != hipErrorInvalidConfiguration) return e;
+      if (a.force_cfg >= 800) return e;
+    }
+  }
   const bool force_d3 = (a.force_cfg >= 200 && a.force_cfg < 300) || (a.force_cfg >= 500 && a.force_cfg < 600);
   if (a.direct >= 3 && (a.force_cfg < 0 || force_d3)) {
     hipError_t e = launch_conv_direct3(a, num_cu, stream, cfg_out);

@@ -1,0 +1,358 @@
+// gfx950 (CDNA4 / MI355X) kernels of the UNIVERSE(++) enhance path: conv_split_kernel -- stride-1 k3 / k5 convs of the
+// throughput regime on the BF16 matrix pipe with fp32-faithful operands (round 5, SURVEY.md "Roofline honesty").
+// (one translation unit per kernel family; shared device helpers in ou_dev.h, cross-file launchers in ou_internal.h)
+//
+// Why: the f32-input MFMAs run at 64 FLOP/clk/SIMD (157 TFLOP/s), v_mfma_f32_32x32x16_bf16 at 1024 (2.5 PFLOP/s).  An fp32
+// value is EXACTLY the sum of three bf16 values (8 + 8 + 8 significand bits: hi = bf16(x), mid = bf16(x - hi), lo =
+// bf16(x - hi - mid)), so
+//     a * b = (ah + am + al)(bh + bm + bl) = ah bh + [ah bm + am bh] + [ah bl + am bm + al bh] + O(2^-24 |a b|)
+// -- six bf16 products per fp32 product, each exact in the pipe's fp32 accumulator, the dropped terms (am bl, al bm, al bl) of
+// the size of ONE fp32 rounding of the product.  16 / 6 = 2.67x the f32 MFMA rate at fp32-class accuracy (measured per layer
+// against a double evaluation in tools/ubench/split_conv.hip, end to end in the parity tests); fewer accumulator roundings than
+// the f32 MFMA's fmaf chain too (one per 16-deep instruction instead of one per product).
+//
+// Data flow (no change to any tensor layout: x, y stay fp32 (B, C, T)):
+//   * weights: a fourth packed copy, split on the host (ou_model.cpp) and laid out as MFMA A fragments:
+//       [Cin / 16][KW][Mp / 32][3 pieces][64 lanes][8 bf16]   lane l: row 32 mt + (l & 31), channels 16 cc + 8 (l >> 5) + 0..7
+//     one 16-byte load per lane and fragment, 1 KB contiguous per wave -- straight to registers, every wave of a block owns
+//     different rows (no LDS for weights);
+//   * activations: a block stages 16 channels x (BN + KW - 1) samples per K chunk: 4-byte global loads (coalesced along time),
+//     PReLU, the 3-way split on the VALU (v_cvt_pk_bf16_f32: 5.5 instructions per element, once per BLOCK and chunk -- every
+//     element then feeds BM x KW x 6 MACs), written to LDS as [piece][sample][16 channels] bf16: the B fragment of tap k is the
+//     16-byte read at row (column + k) -- the taps are row offsets into the same image, no im2col;
+//   * per wave a 64 x (32 TNW) output tile: 2 x TNW x KW x 6 MFMAs per chunk (k5, TNW = 4: 240 = 7 680 cycles) against one
+//     barrier, 6 KW weight fragments and 3 TNW KW fragment reads from LDS: the loop is bound by the matrix pipe by construction.
+//   Summation order per output: channel chunks ascending, taps ascending, the six piece products hi.hi first, 16 channels per
+//   instruction in the pipe's own order -- fixed, different from every other family (results agree to fp32 rounding).
+#include "ou_kernels.h"
+#include "ou_internal.h"
+#include "ou_dev.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace ou {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 values -> three dwords of packed bf16 pairs (element 0 in the low half)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& H, unsigned& M, unsigned& L) {
+  const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+  const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;  // exact
+  const __bf16 m0 = (__bf16)r0, m1 = (__bf16)r1;
+  const float q0 = r0 - (float)m0, q1 = r1 - (float)m1;  // exact
+  H = __builtin_bit_cast(unsigned, bf16x2{h0, h1});
+  M = __builtin_bit_cast(unsigned, bf16x2{m0, m1});
+  L = __builtin_bit_cast(unsigned, bf16x2{(__bf16)q0, (__bf16)q1});
+}
+
+// (TNW = 2: two blocks per CU -- the other block's MFMAs cover this one's barriers, fragment latencies, staging and epilogue)
+template <int KW, int WM, int TNW>
+__global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split_kernel(ConvArgs p) {
+  constexpr int WN = 4 / WM, WTN = 32 * TNW, BN = WN * WTN, PAD = (KW - 1) / 2;
+  constexpr int R = BN + KW - 1;          // staged samples per channel and chunk
+  constexpr int PIECE = (R + 1) * 32;     // bytes of one piece plane: [R][16 channels] bf16 (+ one row nobody reads: the halo
+                                          // item of the threads that have none is written there -- no branch in the staging code)
+  constexpr int BUF = 3 * PIECE;          // one stage (hi, mid, lo)
+  constexpr int NMAIN = BN / 32;          // staged (sample, channel pair) items per thread; + (KW - 1) * 8 halo items on threads 0..
+  static_assert(KW == 3 || KW == 5, "k3 / k5");
+  static_assert(WM == 1 || WM == 2 || WM == 4, "waves along the rows");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WN, wn = wv % WN;
+  // block -> (batch element, column tile, row tile): blocks L, L + 8, ... (one XCD) walk the row tiles of one column tile
+  const int L = blockIdx.x, q8 = L >> 3, rg = q8 % p.grid_m, cidx = (q8 / p.grid_m) * 8 + (L & 7);
+  const int b = cidx / p.grid_n, ct = cidx - b * p.grid_n;
+  if (b >= p.B) return;  // (whole blocks)
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  // tuning (two blocks per CU): one of the two gets the higher wave priority -- they drift apart, and one block's epilogue
+  // (memory-bound) runs under the other's main loop (matrix-bound) instead of both at once on every CU of the device
+  if (((p.dbg & 16) && ((L >> 8) & 1)) || ((p.dbg & 32) && ((L >> 3) & 1))) {  // start late by (dbg >> 8) us
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(p.dbg >> 8) * 100ull) __builtin_amdgcn_s_sleep(32);
+  }
+  const int n0 = ct * BN, m0 = rg * (64 * WM) + wm * 64;
+  const int Tin = p.Tin, Cin = p.Cin;
+  const int NCH = Cin >> 4, MT = p.Mp >> 5;
+  const float alpha = p.act ? p.alpha_val : 1.0f;
+  const float* xb = p.x + (size_t)b * Cin * Tin;
+
+  // ---- staging of the activation tile
+  const int cp = tid & 7;                          // channel pair 2 cp, 2 cp + 1 of the chunk
+  const int row0 = tid >> 3;                       // sample rows row0 + 32 j
+  float sx[NMAIN + 1][2];
+  auto stage_load = [&](int cc) {
+    const float* s0 = xb + (size_t)(cc * 16 + 2 * cp) * Tin;
+#pragma unroll
+    for (int j = 0; j < NMAIN; j++) {
+      const int t = n0 - PAD + row0 + 32 * j;
+      const bool ok = t >= 0 && t < Tin;
+      const int tc = t < 0 ? 0 : (t < Tin ? t : Tin - 1);  // (clamped address + select: no branch)
+      const float v0 = s0[tc], v1 = s0[Tin + tc];
+      sx[j][0] = ok ? v0 : 0.f;
+      sx[j][1] = ok ? v1 : 0.f;
+    }
+    {  // halo rows BN .. BN + KW - 2: threads 0 .. 8 (KW - 1) - 1
+      const int t = n0 - PAD + BN + row0;
+      const bool ok = tid < 8 * (KW - 1) && t >= 0 && t < Tin;
+      const int tc = t < 0 ? 0 : (t < Tin ? t : Tin - 1);
+      const float v0 = s0[tc], v1 = s0[Tin + tc];
+      sx[NMAIN][0] = ok ? v0 : 0.f;
+      sx[NMAIN][1] = ok ? v1 : 0.f;
+    }
+  };
+  auto stage_store = [&](int buf) {
+    unsigned char* base = smem_split + buf * BUF + cp * 4;
+#pragma unroll
+    for (int j = 0; j <= NMAIN; j++) {
+      const int row = j < NMAIN ? row0 + 32 * j : (tid < 8 * (KW - 1) ? BN + row0 : R);
+      unsigned H, M, Lo;
+      split_pair(prelu(sx[j][0], alpha), prelu(sx[j][1], alpha), H, M, Lo);
+      *reinterpret_cast<unsigned*>(base + row * 32) = H;
+      *reinterpret_cast<unsigned*>(base + PIECE + row * 32) = M;
+      *reinterpret_cast<unsigned*>(base + 2 * PIECE + row * 32) = Lo;
+    }
+  };
+
+  // ---- weight fragments: [cc][tap][mt][piece][lane] x 16 bytes
+  const u32x4* wsp = reinterpret_cast<const u32x4*>(p.wsplit) + lane;
+  const int mt0 = m0 >> 5;
+  // fragment registers: two sets, used alternately by consecutive steps (compile-time parity: no copies between steps)
+  u32x4 A[2][2][3];
+  auto load_a = [&](int step, u32x4 (&a)[2][3]) {  // step = cc * KW + tap
+    const u32x4* s = wsp + ((size_t)step * MT + mt0) * 3 * 64;
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+      for (int pc = 0; pc < 3; pc++) a[tm][pc] = s[(tm * 3 + pc) * 64];
+  };
+
+  floatx16 acc[2][TNW];
+#pragma unroll
+  for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+    for (int tn = 0; tn < TNW; tn++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0.f;
+
+  const int boff = (wn * WTN + (lane & 31)) * 32 + (lane >> 5) * 16;  // this lane's fragment row / half inside a piece plane
+  bf16x8 Bf[2][TNW][3];
+  auto read_b = [&](int buf, int tap, bf16x8 (&bf)[TNW][3]) {
+    const unsigned char* bb = smem_split + buf * BUF + boff + tap * 32;
+#pragma unroll
+    for (int tn = 0; tn < TNW; tn++)
+#pragma unroll
+      for (int pc = 0; pc < 3; pc++) bf[tn][pc] = *reinterpret_cast<const bf16x8*>(bb + pc * PIECE + tn * 32 * 32);
+  };
+
+  load_a(0, A[0]);
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  read_b(0, 0, Bf[0]);
+
+  // One step = (chunk, tap): 2 x TNW x 6 MFMAs on fragments that were fetched DURING the previous step (weights from L2,
+  // activations from LDS) into the other register set.  The scheduling groups spread the step's 6 weight loads and 3 TNW
+  // fragment reads over its first MFMAs (left alone the compiler either sinks every load to its first use -- an L2 round trip per
+  // step with the matrix pipe idle -- or, behind a plain barrier, issues them in one block while the pipe drains: 700 of 2 300
+  // cycles per step, measured with the phase stamps); the split + LDS write of the next chunk's activation tile rides in
+  // the last tap's step the same way.
+  const bool ts_on = p.tstamps != nullptr;
+  long long c_step = 0, c_bar = 0, c_t0 = 0;
+  if (ts_on) c_t0 = __builtin_readcyclecounter();
+  const long long c_begin = c_t0;
+  auto chunk = [&](auto P0c, int cc) {
+    constexpr int P0 = decltype(P0c)::value;
+    // (no run-time branches inside a chunk: the scheduling groups work within one basic block.  The last chunk stages itself
+    // once more into the buffer nobody reads and fetches the last step's weights again.)
+    const int ccn = cc + 1 < NCH ? cc + 1 : cc;
+    stage_load(ccn);
+#pragma unroll
+    for (int tap = 0; tap < KW; tap++) {
+      constexpr int NMMA = 2 * TNW * 6;
+      const int P = (P0 + tap) & 1;
+      const bool last = tap == KW - 1;
+      u32x4 (&ac)[2][3] = A[P];
+      bf16x8 (&bc)[TNW][3] = Bf[P];
+      load_a(last ? ccn * KW + (ccn == cc ? tap : 0) : cc * KW + tap + 1, A[P ^ 1]);
+      if (!last) read_b(cc & 1, tap + 1, Bf[P ^ 1]);
+      if (last) stage_store((cc + 1) & 1);
+      // hi.hi | hi.mid, mid.hi | hi.lo, mid.mid, lo.hi -- two independent accumulators alternate
+#pragma unroll
+      for (int tn = 0; tn < TNW; tn++) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          constexpr int QA[6] = {0, 0, 1, 0, 1, 2}, QB[6] = {0, 1, 0, 2, 1, 0};
+#pragma unroll
+          for (int tm = 0; tm < 2; tm++)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[tm][QA[q]]), bc[tn][QB[q]],
+                                                                  acc[tm][tn], 0, 0, 0);
+        }
+      }
+      // issue order of the step: 2 MFMAs, 6 x (weight load, MFMA), 3 TNW x (fragment read, MFMA), the rest of the MFMAs with the
+      // staging work of the last tap (VALU + LDS writes) in their shadow
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      if (!last) {
+#pragma unroll
+        for (int i = 0; i < 3 * TNW; i++) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMMA - 8 - 3 * TNW, 0);
+      } else {
+        // (NMAIN + 1) items x ~22 VALU (+ 3 LDS writes each, wherever they fall) in the shadow of the remaining MFMAs
+#pragma unroll
+        for (int i = 0; i < NMMA - 8; i++) {
+          __builtin_amdgcn_sched_group_barrier(0x002, ((NMAIN + 1) * 22 + NMMA - 9) / (NMMA - 8), 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ts_on) {
+        const long long now_ = __builtin_readcyclecounter();
+        c_step += now_ - c_t0;
+        c_t0 = now_;
+      }
+    }
+    __syncthreads();
+    read_b((cc + 1) & 1, 0, Bf[(P0 + KW) & 1]);
+    if (ts_on) {
+      __builtin_amdgcn_sched_barrier(0);
+      const long long now_ = __builtin_readcyclecounter();
+      c_bar += now_ - c_t0;
+      c_t0 = now_;
+    }
+  };
+  {
+    int cc = 0;
+    for (; cc + 1 < NCH; cc += 2) {
+      chunk(std::integral_constant<int, 0>{}, cc);
+      chunk(std::integral_constant<int, KW & 1>{}, cc + 1);
+    }
+    if (cc < NCH) chunk(std::integral_constant<int, 0>{}, cc);
+  }
+  if (ts_on && lane == 0) {
+    long long* o = p.tstamps + ((size_t)blockIdx.x * 4 + wv) * 8;
+    o[0] = 0; o[1] = 0; o[2] = c_step; o[3] = c_bar; o[4] = __builtin_readcyclecounter() - c_begin; o[5] = NCH * KW;
+  }
+  if (p.dbg & 1) return;  // (tuning: main loop alone)
+
+  // ---- epilogue: in_scale, bias, cond add, FiLM, residual, PReLU of the next layer -- straight from the accumulators
+  // (C / D layout of the 32 x 32 forms: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
+  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+  const size_t ybase = (size_t)b * p.Cout * p.Tout;
+  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+  const int tcol = n0 + wn * WTN + (lane & 31);
+  // (all operand loads of a 32-row tile first, with clamped addresses instead of branches: one memory round trip per tile, not
+  // one per element -- the first version of this epilogue waited out 128 dependent loads per lane, 95 of its 120 us)
+#pragma unroll
+  for (int tm = 0; tm < 2; tm++) {
+    float bi[16], ga[16], be[16], rs[TNW][16], ad[TNW][16];
+    size_t rbase[16];
+    int tc[TNW];
+#pragma unroll
+    for (int tn = 0; tn < TNW; tn++) tc[tn] = tcol + tn * 32 < p.Nq ? tcol + tn * 32 : p.Nq - 1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int rc = row < p.M ? row : p.M - 1;
+      rbase[r] = ybase + (size_t)rc * p.Tout;
+      bi[r] = p.bias[rc];
+      ga[r] = 1.f; be[r] = 0.f;
+      if (filmb) { ga[r] = filmb[rc]; be[r] = filmb[p.Cout + rc]; }
+    }
+    if (p.res) {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+#pragma unroll
+        for (int tn = 0; tn < TNW; tn++) rs[tn][r] = p.res[rbase[r] + tc[tn]];
+    }
+    if (p.add) {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+#pragma unroll
+        for (int tn = 0; tn < TNW; tn++) ad[tn][r] = p.add[rbase[r] + tc[tn]];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+      for (int tn = 0; tn < TNW; tn++) {
+        float v = acc[tm][tn][r];
+        if (p.in_scale) v *= insc;
+        v += bi[r];
+        if (p.add) v = (v + ad[tn][r]) * p.add_scale;
+        if (filmb) v = ga[r] * v + be[r];
+        if (p.res) v = (v + rs[tn][r]) * p.res_scale;
+        if (p.out_act) v = v >= 0.f ? v : p.out_alpha * v;
+        if (row < p.M && tcol + tn * 32 < p.Nq) p.y[rbase[r] + tcol + tn * 32] = v;
+      }
+    }
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+namespace {
+struct SplitCfg {
+  int KW, WM, TNW;
+  void (*kern)(ConvArgs);
+  size_t lds;
+};
+template <int KW, int WM, int TNW>
+constexpr SplitCfg split_cfg() {
+  return {KW, WM, TNW, conv_split_kernel<KW, WM, TNW>, (size_t)2 * 3 * ((4 / WM) * 32 * TNW + KW) * 32};
+}
+const SplitCfg kSplitCfgs[] = {
+    split_cfg<3, 1, 4>(), split_cfg<3, 2, 4>(), split_cfg<3, 4, 4>(), split_cfg<3, 1, 2>(), split_cfg<3, 2, 2>(), split_cfg<3, 4, 2>(),
+    split_cfg<5, 1, 4>(), split_cfg<5, 2, 4>(), split_cfg<5, 4, 4>(), split_cfg<5, 1, 2>(), split_cfg<5, 2, 2>(), split_cfg<5, 4, 2>(),
+};
+}  // namespace
+
+hipError_t init_split_kernels() {
+  for (const SplitCfg& c : kSplitCfgs) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// cfg_out: 800 + 100 (TNW == 2) + 10 log2(WM) + KW
+hipError_t launch_conv_split(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
+  if (!a.wsplit || a.stride != 1 || a.up != 1 || (a.KW != 3 && a.KW != 5) || a.pad != (a.KW - 1) / 2 || a.fir || a.Cin % 16 ||
+      a.M % 64 || (a.in_scale != nullptr && a.act))
+    return hipErrorInvalidConfiguration;
+  int wm = a.M % 256 == 0 ? 4 : (a.M % 128 == 0 ? 2 : 1);
+  int tnw = 4;
+  auto blocks = [&](int wm_, int tnw_) {
+    const long bn = (4 / wm_) * 32L * tnw_;
+    return ((a.M + 64 * wm_ - 1) / (64 * wm_)) * ((a.Nq + bn - 1) / bn) * a.B;
+  };
+  // fill the device: narrower wave tiles, then fewer rows per block, while there are fewer blocks than CUs
+  if (blocks(wm, tnw) < num_cu) tnw = 2;
+  if (a.force_cfg >= 800 && a.force_cfg < 1100) {
+    const int f = a.force_cfg - 800;
+    tnw = f >= 100 ? 2 : 4;
+    wm = 1 << ((f % 100) / 10);
+  }
+  const SplitCfg* c = nullptr;
+  for (const SplitCfg& k : kSplitCfgs)
+    if (k.KW == a.KW && k.WM == wm && k.TNW == tnw) c = &k;
+  if (!c || a.M % (64 * wm)) return hipErrorInvalidConfiguration;
+  ConvArgs aa = a;
+  const long bn = (4 / wm) * 32L * tnw;
+  aa.grid_m = a.M / (64 * wm);
+  aa.grid_n = (int)((a.Nq + bn - 1) / bn);
+  const long total8 = ((long)aa.grid_n * a.B + 7) / 8 * 8;
+  if (cfg_out) *cfg_out = 800 + (tnw == 2 ? 100 : 0) + 10 * (wm == 4 ? 2 : (wm == 2 ? 1 : 0)) + a.KW;
+  hipLaunchKernelGGL(c->kern, dim3((unsigned)(total8 * aa.grid_m)), dim3(256), c->lds, stream, aa);
+  return hipGetLastError();
+}
+
+}  // namespace ou

@@ -15,6 +15,8 @@ struct ConvArgs {
   const float* w = nullptr;       // packed [Cin/CK][KW][CK][Mp]
   const float* wd = nullptr;      // second copy, taps innermost: [Cin][Mp][4 (k3) / 8 (k5)] (conv_direct2_kernel) or null
   const float* wu = nullptr;      // third copy, Winograd domain U = G w: [Cin][Mp][4 (F(2,3)) / 8 (F(2,5): 6 used)] or null
+  const void* wsplit = nullptr;   // fourth copy, three bf16 pieces per weight as MFMA A fragments: [Cin/16][KW][Mp/32][3][64][8 bf16]
+                                  // (conv_split_kernel) or null
   const float* bias = nullptr;    // [Cout]
   float* y = nullptr;             // (B, Cout, Tout)
   const float* in_scale = nullptr;  // [B] or null
@@ -45,6 +47,8 @@ struct ConvArgs {
                                        // 5 = + minimal filtering F(2, 3) / F(2, 5) for the k3 / k5 layers on 64-column tiles
                                        //     (conv_direct2w_kernel; default)
   int d2_map = -1;                     // OU_D2_MAP: block -> tile mapping of the wide-load split-K kernels only (tuning)
+  int split = -1;                      // OU_SPLIT: -1 = the bf16-split kernel (conv_split_kernel) where the launcher's rule says so,
+                                       // 0 = never, 1 = wherever a layer has the split copy (tests / tuning)
   int wino = 1;                        // OU_WINO=0: never use the minimal-filtering variants (conv_direct2w_kernel, ...)
   int d2_wk = 0;                       // OU_D2_WK = 4 / 8: K slices (waves per block) of conv_direct2_kernel (0: the launcher's rule)
   int d4_fir_unfused = 1;              // OU_D4_FIR=0: up convs with a fusable FIR stay on the first-generation fused kernel

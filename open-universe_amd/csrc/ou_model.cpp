@@ -1,5 +1,6 @@
 // Architecture walk + weight packing (host).  See ou_model.h.
 #include "ou_model.h"
+#include "ou_split_pack.h"
 
 #include <cmath>
 #include <cstdio>
@@ -45,6 +46,8 @@ std::string finish_conv(ConvL& L, Alloc& a) {
     L.KWP = L.KW == 3 ? 4 : 8;
     L.wd_off = a.take((size_t)L.Cin * L.Mp * L.KWP);
     L.wu_off = a.take((size_t)L.Cin * L.Mp * L.KWP);
+    // the bf16-split copy (conv_split_kernel: 64-row tiles -- the 48-channel level of UNIVERSE++ 24 kHz stays on the fp32 kernels)
+    if (L.M % 64 == 0) { L.ws_on = 1; L.ws_off = a.take(split_floats(L.Cin, L.KW, L.Mp)); }
   }
   return "";
 }
@@ -132,7 +135,7 @@ void json_conv(std::ostringstream& os, const ConvL& L, bool& first) {
      << ",\"M\":" << L.M << ",\"Mp\":" << L.Mp << ",\"CK\":" << L.CK << ",\"rate\":" << L.rate << ",\"act\":" << L.act
      << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"a_off\":" << L.a_off
      << ",\"fir_mode\":" << L.fir_mode << ",\"fir_len\":" << L.fir_len << ",\"fir_off\":" << L.fir_off
-     << ",\"fbias_off\":" << L.fbias_off << ",\"wd_off\":" << L.wd_off << ",\"wu_off\":" << L.wu_off << ",\"KWP\":" << L.KWP << "}";
+     << ",\"fbias_off\":" << L.fbias_off << ",\"wd_off\":" << L.wd_off << ",\"wu_off\":" << L.wu_off << ",\"KWP\":" << L.KWP << ",\"ws_on\":" << L.ws_on << ",\"ws_off\":" << L.ws_off << "}";
 }
 void json_block(std::ostringstream& os, const BlockL& B, bool& first) {
   if (B.dir) json_conv(os, B.rc, first);
@@ -385,6 +388,11 @@ struct Packer {
         for (int mm = 0; mm < L.M; mm++)
           for (int k = 0; k < KW; k++)
             blob[L.wd_off + ((size_t)ci * Mp + mm) * L.KWP + k] = (float)W[((size_t)mm * L.Cin + ci) * KW + k];
+    if (L.ws_on) {  // three bf16 pieces of the fp32 weight the other kernels use (ou_split_pack.h)
+      std::vector<float> Wf(W.size());
+      for (size_t i = 0; i < W.size(); i++) Wf[i] = (float)W[i];
+      pack_split(Wf.data(), L.M, L.Mp, L.Cin, L.KW, reinterpret_cast<uint16_t*>(&blob[L.ws_off]));
+    }
     if (L.KWP) {
       // Winograd / Cook-Toom minimal filtering F(2, KW): two outputs from KW + 1 products instead of 2 KW.  U = G w in double,
       // rounded once.  F(2, 3): points 0, 1, -1, inf (Lavin & Gray's matrices).  F(2, 5): points 0, 1, -1, 1/2, -2, inf -- the

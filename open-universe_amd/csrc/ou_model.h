@@ -27,6 +27,9 @@ struct ConvL {
   int KWP = 0;            // ... 4 (k3) / 8 (k5); 0 = no such copy
   size_t wu_off = 0;      // ... and a third copy in the Winograd / Cook-Toom domain, U = G w: F(2, 3) -> 4 floats, F(2, 5) -> 6 (of
                           // 8) floats per (row, channel), same [Cin][Mp][KWP] slots (conv_direct2w_kernel); valid when KWP != 0
+  size_t ws_off = 0;      // ... and a fourth copy for the bf16 matrix pipe: every weight as three bf16 pieces, laid out as MFMA A
+                          // fragments [Cin/16][KW][Mp/32][3][64 lanes][8 bf16] (conv_split_kernel, ou_split_pack.h); valid when ws_on
+  int ws_on = 0;
   size_t w_off = 0;       // float offsets into the blob
   size_t b_off = 0;       // bias[Cout]
   size_t a_off = 0;       // prelu slope (1 float) when act

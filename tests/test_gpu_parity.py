@@ -629,6 +629,34 @@ def test_minimal_filtering_throughput_kernel_matches_the_plain_one(name, B, T, m
     record(f"direct3w_vs_oracle.{name}.b{B}", O.si_sdr(e_ref, out.cpu()), 80)
 
 
+@pytest.mark.parametrize("name,B,T", [("PP16", 2, 8000), ("PP24", 1, 9000), ("OR16", 2, 5000), ("PP16", 4, 2077), ("PP16", 1, 64000)])
+def test_bf16_split_kernel_matches_the_fp32_kernels(name, B, T, monkeypatch):
+    """conv_split_kernel (round 5): the stride-1 k3 / k5 convs on the BF16 matrix pipe, every fp32 operand as three bf16 pieces
+    and six piece products per fp32 product (fp32-class accuracy: 1 dB BETTER than an fp32 fmaf chain against a double evaluation,
+    tools/ubench/split_conv.hip).  OU_SPLIT=1 forces it onto every layer that has the split weight copy (rows tile by 64; unfused
+    ConvBlock bodies so that the 64-channel levels are included), OU_SPLIT=0 keeps it off: same convolution, different arithmetic
+    path -- compared with each other and with the oracle.  Ragged lengths: partial column tiles, masked halo samples, rows that
+    are not 16-byte multiples; PP24: 96 / 192 / 384 / 768 channels (row tiles of 64 and 128)."""
+    model, spec, sd = get_model(name)
+    mix = synth_mix(spec, B, T)
+    Tp = T + (spec.tot_ds - T % spec.tot_ds)
+    nz = noise_list(71, 3, B, Tp)
+    monkeypatch.setenv("OU_FUSE", "0")
+    monkeypatch.setenv("OU_SPLIT", "0")
+    ref = run_enhance(model, mix, nz, n_steps=3)
+    monkeypatch.setenv("OU_SPLIT", "1")
+    model.profile(True)
+    out = run_enhance(model, mix, nz, n_steps=3)
+    n_split = sum(1 for r in model.profile_read() if 800 <= r[3] < 1100)
+    model.profile(False)
+    assert n_split >= 3 * 10, n_split
+    assert torch.equal(out, run_enhance(model, mix, nz, n_steps=3))
+    assert not torch.equal(out, ref)
+    record(f"split_vs_fp32.{name}.b{B}.T{T}", O.si_sdr(ref, out), 85)
+    e_ref = O.enhance(sd, spec.to_dict(), mix, n_steps=3, noise=nz)
+    record(f"split_vs_oracle.{name}.b{B}.T{T}", O.si_sdr(e_ref, out.cpu()), 80)
+
+
 @pytest.mark.skipif(not experiments_built(), reason="conv_block3_kernel is in `make EXPERIMENTS=1` builds only")
 @pytest.mark.parametrize("T", [64000, 7213])
 def test_fused_deep_convblock_is_bit_identical(T, monkeypatch):

@@ -119,6 +119,36 @@ def test_winograd_domain_weight_copy_reproduces_the_convolution(built_lib):
     assert n >= 20
 
 
+def test_bf16_split_weight_copy_is_the_fp32_weight_exactly(built_lib):
+    """The fourth copy (conv_split_kernel, ou_split_pack.h): every fp32 weight as three bf16 pieces laid out as MFMA A fragments
+    [Cin/16][KW][Mp/32][3][64 lanes][8]: lane l holds row 32 mt + (l & 31), channels 16 cc + 8 (l >> 5) + j.  hi + mid + lo must BE
+    the fp32 weight (24 significand bits = 3 x 8: the split is exact), hi must be the bf16 rounding of it, padding rows zero --
+    without a GPU."""
+    spec = get_spec("PP16")
+    sd = S.synthetic_state_dict(spec, seed=5)
+    blob, plan = _lib.pack_weights(spec, sd)
+    n = 0
+    for nm, L in plan_convs(plan).items():
+        if not L.get("ws_on"):
+            assert not (L["KWP"] and L["M"] % 64 == 0), nm
+            continue
+        Cin, KW, Mp, M = L["Cin"], L["KW"], L["Mp"], L["M"]
+        W, _, _ = unpack_conv(blob, L)                                     # [M][Cin][KW]
+        nfl = Cin * KW * Mp * 3 // 2
+        raw = blob[L["ws_off"]: L["ws_off"] + nfl].view(torch.int16)       # bf16 bit patterns
+        fr = raw.view(Cin // 16, KW, Mp // 32, 3, 64, 8)
+        pieces = (fr.to(torch.int32) << 16).view(torch.float32)            # bf16 -> fp32, exact
+        # [cc][k][mt][piece][half][row32][j] -> [piece][row][ci][k]
+        pc = pieces.view(Cin // 16, KW, Mp // 32, 3, 2, 32, 8).permute(3, 2, 5, 0, 4, 6, 1).reshape(3, Mp, Cin, KW)
+        total = pc[0].double() + pc[1].double() + pc[2].double()
+        assert torch.equal(total[:M].float(), W) and torch.equal(total[:M], W.double()), nm
+        assert not pc[:, M:].any(), nm
+        assert torch.equal(pc[0][:M], W.to(torch.bfloat16).float()), nm    # hi = round-to-nearest-even bf16 of the weight
+        assert float((pc[1][:M].abs() - W.abs() * 2.0 ** -8).max()) <= 0, nm
+        n += 1
+    assert n >= 20
+
+
 def test_pack_errors(built_lib):
     spec = get_spec("PP16s")
     sd = S.synthetic_state_dict(spec, seed=0)
