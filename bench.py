@@ -612,6 +612,8 @@ def main():
             if 400 <= cfg < 800:
                 kw = cfg % 10
                 return (kw + 1) / (2.0 * kw)
+            if 800 <= cfg < 1000:  # conv_split_kernel: nothing on the f32 pipe (six bf16 products per MAC on the bf16 pipe)
+                return 0.0
             if cfg == 193:  # conv_chainw_kernel, depth 3: k5, k3, k3
                 return 14 / 22.0
             if cfg == 192:  # depth 2: k3, k3
@@ -625,12 +627,14 @@ def main():
             fl_ = sum(r[1] for r in rr)
             by_ = sum(r[2] for r in rr)
             ex_ = sum(r[1] * executed_fraction(r[3]) for r in rr)
+            bx_ = sum(r[1] * 6.0 for r in rr if 800 <= r[3] < 1000)
             return {"launches": len(rr) // max(1, args.profile_steps), "avg_launch_us": 1e3 * ms_ / len(rr),
                     "ms_per_enhance": ms_ / max(1, args.profile_steps),
                     "algorithmic_gflop_per_enhance": fl_ / max(1, args.profile_steps) / 1e9,
                     "algorithmic_GB_per_enhance": by_ / max(1, args.profile_steps) / 1e9,
                     "tflops": fl_ / (ms_ * 1e-3) / 1e12, "gbs": by_ / (ms_ * 1e-3) / 1e9,
                     "executed_tflops": ex_ / (ms_ * 1e-3) / 1e12,
+                    "bf16_pipe_tflops": bx_ / (ms_ * 1e-3) / 1e12,
                     "algorithmic_bytes_per_launch": by_ / len(rr)}
         KERNELS = {
             "direct2": "ou::conv_direct2_kernel / conv_direct2w_kernel (register-direct split-K fp32-MFMA Conv1d, wide operand loads: "
@@ -643,6 +647,9 @@ def main():
             "lds": "ou::conv_mfma_kernel (LDS-tiled fp32-MFMA implicit-GEMM Conv1d, wide levels / strided convs)",
             "rate": "ou::rate_down_kernel / rate_up_kernel (outermost rate-change convs with the anti-alias FIR fused, K = 64)",
             "chain": "ou::conv_chain_kernel (fused ConvBlock body, C = 32 / 64 levels)",
+            "split": "ou::conv_split_kernel (stride-1 k3 / k5 convs on the BF16 matrix pipe: every fp32 operand as three bf16 pieces, "
+                     "six piece products per fp32 product on v_mfma_f32_32x32x16_bf16, fp32 accumulate; 64 x 64 / 64 x 128 wave tiles, "
+                     "activations split on the fly into LDS, weights pre-split as A fragments)",
             "direct3": "ou::conv_direct3_kernel / conv_direct3w_kernel / conv_direct3s_kernel (no-split-K throughput kernels: one "
                        "(16 TM) x 64 tile per wave over the whole reduction, 16x16x4 fp32 MFMA, register-direct operands, stores from "
                        "the accumulators; the w form with minimal filtering F(2, 3) / F(2, 5))",
@@ -656,7 +663,8 @@ def main():
                   "rate": summarise([r for r in recs if 40 <= r[3] < 50]),
                   "chain": summarise([r for r in recs if 100 <= r[3] < 200]),
                   "direct3": summarise([r for r in recs if 200 <= r[3] < 300 or 500 <= r[3] < 600]),
-                  "direct4": summarise([r for r in recs if 300 <= r[3] < 400])}
+                  "direct4": summarise([r for r in recs if 300 <= r[3] < 400]),
+                  "split": summarise([r for r in recs if 800 <= r[3] < 1000])}
         groups = {k: v for k, v in groups.items() if v}
         fam = summarise([r for r in recs if (50 <= r[3] < 100 and r[3] not in D2) or 300 <= r[3] < 400 or 260 <= r[3] < 270])
         dom = max(groups, key=lambda k: groups[k]["ms_per_enhance"])  # the dominant kernel = most time per enhance
@@ -717,7 +725,9 @@ def main():
                          "note": "achieved / frac count ALGORITHMIC FLOPs (2 M Cin KW Nq per launch, SURVEY.md 8(d)); the "
                                  "minimal-filtering kernels (Winograd / Cook-Toom F(2, 3), F(2, 5): conv_direct2w / 3w / 4w, "
                                  "conv_chainw) issue 2/3 (k3) and 3/5 (k5) of them on the matrix pipe -- `executed` is what the "
-                                 "pipe actually ran, the figure that cannot exceed its 157.3 TFLOP/s"},
+                                 "pipe actually ran, the figure that cannot exceed its 157.3 TFLOP/s; conv_split_kernel runs on the "
+                                 "BF16 pipe instead (six bf16 products per fp32 product: `bf16_pipe_tflops` = 6 x algorithmic, "
+                                 "against 2 500 dense) and may exceed 157.3 algorithmic"},
             "traffic": traffic,
             "traffic_note": traffic_note,
             "launches": gen["launches"],
@@ -729,7 +739,7 @@ def main():
                          "algorithmic_GB_per_enhance": gen["algorithmic_GB_per_enhance"]},
             "other_conv_kernels": {KERNELS[k]: {
                 "achieved": v["tflops"], "frac": v["tflops"] / FP32_MFMA_PEAK_TFLOPS, "launches": v["launches"],
-                "executed_tflops": v["executed_tflops"],
+                "executed_tflops": v["executed_tflops"], "bf16_pipe_tflops": v["bf16_pipe_tflops"],
                 "avg_launch_us": v["avg_launch_us"], "ms_per_enhance": v["ms_per_enhance"],
                 "algorithmic_gflop_per_enhance": v["algorithmic_gflop_per_enhance"]} for k, v in groups.items() if k != dom},
             "all_conv_kernels": {"achieved": allconv["tflops"], "frac": allconv["tflops"] / FP32_MFMA_PEAK_TFLOPS,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OU_ABI_VERSION 3 /* 3: the packed blob carries a Winograd-domain weight copy (round 5); ou_set_lane_batch, ou_lane_capacity */
+#define OU_ABI_VERSION 4 /* 4: the packed blob carries a bf16-split weight copy (conv_split_kernel); 3: a Winograd-domain copy (round 5), ou_set_lane_batch, ou_lane_capacity */
 
 enum {
   OU_OK = 0,

@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 OU_MAX_RATES = 8
-OU_ABI_VERSION = 3
+OU_ABI_VERSION = 4
 OU_OK, OU_EINVAL, OU_ENOTIMPL, OU_EMISSING, OU_ESHAPE, OU_EHIP, OU_ENOMEM, OU_ESYNC = 0, -1, -2, -3, -4, -5, -6, -7
 OU_KIND_UNIVERSE, OU_KIND_UNIVERSE_GAN = 0, 1
 OU_ACT_NONE, OU_ACT_PRELU, OU_ACT_SNAKE = 0, 1, 2

@@ -67,12 +67,14 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
   const int b = cidx / p.grid_n, ct = cidx - b * p.grid_n;
   if (b >= p.B) return;  // (whole blocks)
   if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
-  // tuning (two blocks per CU): one of the two gets the higher wave priority -- they drift apart, and one block's epilogue
-  // (memory-bound) runs under the other's main loop (matrix-bound) instead of both at once on every CU of the device
-  if (((p.dbg & 16) && ((L >> 8) & 1)) || ((p.dbg & 32) && ((L >> 3) & 1))) {  // start late by (dbg >> 8) us
+#ifdef OU_SPLIT_TUNING  // (tools/ubench/split_conv.hip only: the product kernel has no switch that changes its results or timing)
+  // stagger experiment: every second block of a CU starts (dbg >> 8) us late, so that one block's epilogue (memory-bound) would
+  // run under the other's main loop (matrix-bound) -- measured: no gain (profiles/r05_split_ubench_stagger_experiment.txt)
+  if (((p.dbg & 16) && ((L >> 8) & 1)) || ((p.dbg & 32) && ((L >> 3) & 1))) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(p.dbg >> 8) * 100ull) __builtin_amdgcn_s_sleep(32);
   }
+#endif
   const int n0 = ct * BN, m0 = rg * (64 * WM) + wm * 64;
   const int Tin = p.Tin, Cin = p.Cin;
   const int NCH = Cin >> 4, MT = p.Mp >> 5;
@@ -242,7 +244,9 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
     long long* o = p.tstamps + ((size_t)blockIdx.x * 4 + wv) * 8;
     o[0] = 0; o[1] = 0; o[2] = c_step; o[3] = c_bar; o[4] = __builtin_readcyclecounter() - c_begin; o[5] = NCH * KW;
   }
-  if (p.dbg & 1) return;  // (tuning: main loop alone)
+#ifdef OU_SPLIT_TUNING
+  if (p.dbg & 1) return;  // (main loop alone)
+#endif
 
   // ---- epilogue: in_scale, bias, cond add, FiLM, residual, PReLU of the next layer -- straight from the accumulators
   // (C / D layout of the 32 x 32 forms: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))

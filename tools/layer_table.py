@@ -60,6 +60,8 @@ def executed_fraction(cfg, kw, depth=None):
     """MFMA multiply-adds issued / algorithmic ones."""
     if 400 <= cfg < 800:
         return (kw + 1) / (2.0 * kw)
+    if 800 <= cfg < 1000:  # conv_split_kernel: six bf16 products per MAC on the BF16 pipe (2 500 TFLOP/s dense = 16 x the f32 pipe):
+        return 6.0 / 16.0  # in units of the f32 pipe's capacity, so that the one assertion below covers both pipes
     if cfg == 193:   # conv_chainw_kernel, depth 3: k5, k3, k3
         return (6 + 4 + 4) / (10 + 6 + 6.0)
     if cfg == 192:   # depth 2: k3, k3
@@ -90,7 +92,7 @@ for ms, fl, by, cfg in recs:
         rows.append((nm, shape, us, alg, alg * frac, cfg))
         worst = max(worst, alg * frac)
         key = ("direct2/2w/4w" if cfg in (66, 76, 67, 77) or 400 <= cfg < 500 or 600 <= cfg < 800 else "direct (dword)" if 50 <= cfg < 100 else
-               "lds" if cfg < 40 else "rate" if cfg < 50 else "chain" if cfg < 200 else "direct3/3w/3s" if cfg < 300 or 500 <= cfg < 600 else "direct4")
+               "lds" if cfg < 40 else "rate" if cfg < 50 else "chain" if cfg < 200 else "direct3/3w/3s" if cfg < 300 or 500 <= cfg < 600 else "split (bf16 x 6)" if cfg >= 800 else "direct4")
     f = fam.setdefault(key, [0, 0.0, 0.0])
     f[0] += 1; f[1] += us; f[2] += fl
 tot_us = sum(r[2] for r in rows)
@@ -109,6 +111,8 @@ for nm, shape, us, alg, exe, cfg in rows:
         print(f"  {nm:34s} {'':62s} {us:8.1f} us {alg:7.1f} TF/s")
     else:
         ex = f" (executed {exe:6.1f})" if abs(exe - alg) > 1e-9 else ""
+        if 800 <= cfg < 1000:
+            ex = f" (bf16 pipe {alg * 6:6.0f})"
         print(f"  {nm:34s} {shape:62s} {us:8.1f} us {alg:7.1f} TF/s{ex}")
 print(f"largest EXECUTED rate of a launch: {worst:.1f} TFLOP/s (fp32 MFMA peak {PEAK})")
 assert worst <= PEAK, "a launch above the matrix pipe's peak: the record <-> layer pairing or the FLOP accounting is wrong"

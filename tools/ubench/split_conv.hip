@@ -2,6 +2,7 @@
 // checked against a double evaluation (beside the error of a plain fp32 fmaf chain on the same data) and timed.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o split_conv.bin split_conv.hip
 //   ./split_conv.bin M Cin KW T B [force_cfg] [iters]
+#define OU_SPLIT_TUNING 1
 #include "../../open-universe_amd/csrc/ou_conv_split.hip"
 #include "../../open-universe_amd/csrc/ou_split_pack.h"
 
@@ -52,7 +53,7 @@ int main(int argc, char** argv) {
   a.act = 1; a.alpha_val = 0.25f;
   a.B = B; a.Cin = Cin; a.Tin = T; a.Cout = M; a.M = M; a.Mp = Mp; a.KW = KW; a.pad = (KW - 1) / 2; a.Nq = T; a.Tout = T;
   a.force_cfg = force;
-  a.dbg = argc > 8 ? atoi(argv[8]) : 0;  // phase ablation (wrong results): 1 no epilogue, 2 no staging, 4 no weight loads, 8 no LDS reads
+  a.dbg = argc > 8 ? atoi(argv[8]) : 0;  // tuning: 1 = no epilogue (wrong results), 16 / 32 + 256 x us = every second block starts late
   int cfg = 0;
   CHK(ou::launch_conv_split(a, pr.multiProcessorCount, 0, &cfg));
   CHK(hipDeviceSynchronize());
