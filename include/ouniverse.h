@@ -233,6 +233,18 @@ const char* ou_packer_plan_json(const ou_packer* p);
 int ou_tensor(const ou_handle* h, const char* name, size_t* byte_offset, int32_t* C, int32_t* T);
 /* Number of kernels the last forward enqueued, and the generic-conv launch count among them. */
 int ou_launch_stats(const ou_handle* h, int32_t* n_launches, int32_t* n_conv_launches);
+/* ---- input files of the CLI ------------------------------------------------------------------------------- */
+/* FLAC stream decoder (pure host code).  Replaces the codec behind `torchaudio.load` in the reference's CLI
+ * (open_universe/bin/enhance.py:183; AUDIO_SUFFIXES :33 lists .flac) -- torchaudio is not a dependency of this package.
+ * Every checksum of the stream (frame-header CRC-8, frame CRC-16) is verified; the MD5 of the decoded audio is returned for the
+ * caller to check (open_universe_amd/audio.py does).  ou_flac_last_error(): message of the last failure on this thread.
+ *   ou_flac_info  : header fields; total_samples is counted by a decoding pass when the header does not carry it
+ *   ou_flac_decode: out[channels][capacity_per_channel] <- the samples as integers (bits_per_sample wide, sign-extended) */
+const char* ou_flac_last_error(void);
+int ou_flac_info(const uint8_t* data, size_t bytes, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample,
+                 int64_t* total_samples, uint8_t* md5 /* 16 bytes, all zero = not recorded */);
+int ou_flac_decode(const uint8_t* data, size_t bytes, int32_t* out, int64_t capacity_per_channel, int64_t* decoded);
+
 /* Measurement / tuning entry points (ou_profile_*, ou_bench_conv) are declared in ouniverse_tuning.h. */
 
 #ifdef __cplusplus

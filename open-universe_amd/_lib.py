@@ -109,6 +109,9 @@ def load():
         "ou_transform_frames": (i32, [i32, i32, i32]),
         "ou_transform_forward": (i32, [vp, i32, i32, vp, i32, i32, i32, c_float, c_float, vp, vp]),
         "ou_transform_inverse": (i32, [vp, i32, i32, vp, i32, i32, i32, c_float, c_float, i32, vp, vp, vp]),
+        "ou_flac_last_error": (c_char_p, []),
+        "ou_flac_info": (i32, [vp, sz, POINTER(i32), POINTER(i32), POINTER(i32), POINTER(ctypes.c_int64), vp]),
+        "ou_flac_decode": (i32, [vp, sz, vp, ctypes.c_int64, POINTER(ctypes.c_int64)]),
         "ou_profile_enable": (i32, [vp, i32]),
         "ou_bench_conv": (i32, [vp, c_char_p, i32, i32, i32, i32, i32, i32, vp, sz, vp, POINTER(c_float), POINTER(i32)]),
         "ou_profile_read": (i32, [vp, i32, POINTER(c_float), POINTER(c_double), POINTER(c_double), POINTER(i32), POINTER(i32)]),
@@ -129,6 +132,7 @@ EXPORTED_SYMBOLS = [
     "ou_packer_plan_json", "ou_tensor", "ou_launch_stats", "ou_workspace_init", "ou_sampler_step",
     "ou_set_gru_publish_mode", "ou_get_gru_publish_mode", "ou_set_lanes", "ou_set_lane_batch", "ou_lane_capacity",
     "ou_transform_frames", "ou_transform_forward", "ou_transform_inverse",
+    "ou_flac_last_error", "ou_flac_info", "ou_flac_decode",
 ]
 TUNING_SYMBOLS = ["ou_profile_enable", "ou_profile_read", "ou_profile_read_ticks", "ou_bench_conv",
 ]

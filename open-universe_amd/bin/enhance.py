@@ -155,7 +155,7 @@ def main(argv=None, model=None):
     if undecodable:
         # fail before the first file is enhanced, not in the middle of a directory (torchaudio is what the reference
         # decodes .mp3 / .flac with, bin/enhance.py:183)
-        raise RuntimeError(f"{len(undecodable)} input file(s) need torchaudio to be decoded (only .wav is read natively): "
+        raise RuntimeError(f"{len(undecodable)} input file(s) need torchaudio to be decoded (.wav and .flac are read natively): "
                            + ", ".join(undecodable[:5]))
     todo = plan_files(files, world, rank)
 

@@ -187,6 +187,24 @@ def plan_convs(plan_json):
     return {c["name"]: c for c in json.loads(plan_json)["convs"]}
 
 
+def split_copy_as_values(blob, plan_json):
+    """The blob with every bf16-split weight copy (conv_split_kernel: bit patterns of three bf16 pieces per weight, NOT fp32
+    numbers) replaced by the fp32 values the pieces add up to, piece order kept -- so that two blobs can be compared as numbers
+    (a weight that differs in its last bit has completely different mid / lo pieces)."""
+    out = blob.clone()
+    for L in plan_convs(plan_json).values():
+        if not L.get("ws_on"):
+            continue
+        n = L["Cin"] * L["KW"] * L["Mp"] * 3 // 2
+        raw = blob[L["ws_off"]: L["ws_off"] + n].view(torch.int16)
+        pieces = (raw.to(torch.int32) << 16).view(torch.float32).view(-1, 3, 64, 8)   # [fragment triple][piece][lane][8]
+        total = pieces.double().sum(dim=1).float()                                     # hi + mid + lo: exact
+        filler = torch.zeros(n, dtype=torch.float32)
+        filler[: total.numel()] = total.reshape(-1)
+        out[L["ws_off"]: L["ws_off"] + n] = filler
+    return out
+
+
 def experiments_built():
     """True when libouniverse.so was built with `make EXPERIMENTS=1` (conv_block3_kernel, round 1's gru_cluster_kernel and
     the never-selected conv_mfma_kernel configs are in the library only then)."""

@@ -143,9 +143,12 @@ def test_lora_and_weight_norm_removed_checkpoints():
         assert torch.equal(blob, ref_blob)
         if spec.score.use_weight_norm:
             # weight-norm folded by the packer (in double) vs folded up front in fp32: same weights to fp32 rounding
-            wn_blob, _ = _lib.pack_weights(spec, sd)
+            from helpers import split_copy_as_values
+            wn_blob, wn_plan = _lib.pack_weights(spec, sd)
             _, plain = lora_style_state_dict(sd, rank=10 ** 6)  # no adapter fits: plain == folded sd
-            pb, _ = _lib.pack_weights(spec, S.inference_state_dict(spec, plain))
+            pb, p_plan = _lib.pack_weights(spec, S.inference_state_dict(spec, plain))
+            # (the bf16-split copies hold bit patterns of pieces: compared through the values the pieces add up to)
+            pb, wn_blob = split_copy_as_values(pb, p_plan), split_copy_as_values(wn_blob, wn_plan)
             # (the Winograd-domain copies U = G w hold differences of taps: absolute, not relative, agreement there)
             assert torch.allclose(pb, wn_blob, rtol=3e-7, atol=5e-7)
         with pytest.raises(NotImplementedError):
