@@ -31,6 +31,11 @@
 #include <cstdlib>
 #include <type_traits>
 
+// scheduling of a step (tuning: the microbenchmark is built with other values; the product with 0)
+#ifndef OU_SPLIT_SCHED
+#define OU_SPLIT_SCHED 0
+#endif
+
 namespace ou {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -74,6 +79,9 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(p.dbg >> 8) * 100ull) __builtin_amdgcn_s_sleep(32);
   }
+#endif
+#if OU_SPLIT_SCHED == 4
+  __builtin_amdgcn_s_setprio(2);
 #endif
   const int n0 = ct * BN, m0 = rg * (64 * WM) + wm * 64;
   const int Tin = p.Tin, Cin = p.Cin;
@@ -181,6 +189,11 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
       load_a(last ? ccn * KW + (ccn == cc ? tap : 0) : cc * KW + tap + 1, A[P ^ 1]);
       if (!last) read_b(cc & 1, tap + 1, Bf[P ^ 1]);
       if (last) stage_store((cc + 1) & 1);
+#if OU_SPLIT_SCHED == 1
+      if (!last) __builtin_amdgcn_sched_barrier(0);  // (experiment: the step's loads in one block in front of its MFMAs)
+#elif OU_SPLIT_SCHED == 2
+      __builtin_amdgcn_sched_barrier(0);             // (experiment: loads AND the staging work in front of the MFMAs)
+#endif
       // hi.hi | hi.mid, mid.hi | hi.lo, mid.mid, lo.hi -- two independent accumulators alternate
 #pragma unroll
       for (int tn = 0; tn < TNW; tn++) {
@@ -195,27 +208,31 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
       }
       // issue order of the step: 2 MFMAs, 6 x (weight load, MFMA), 3 TNW x (fragment read, MFMA), the rest of the MFMAs with the
       // staging work of the last tap (VALU + LDS writes) in their shadow
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#if OU_SPLIT_SCHED == 0 || OU_SPLIT_SCHED == 4 || (OU_SPLIT_SCHED == 1)
+      if (OU_SPLIT_SCHED != 1 || last) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
 #pragma unroll
-      for (int i = 0; i < 6; i++) {
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      }
-      if (!last) {
-#pragma unroll
-        for (int i = 0; i < 3 * TNW; i++) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int i = 0; i < 6; i++) {
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, NMMA - 8 - 3 * TNW, 0);
-      } else {
-        // (NMAIN + 1) items x ~22 VALU (+ 3 LDS writes each, wherever they fall) in the shadow of the remaining MFMAs
+        if (!last) {
 #pragma unroll
-        for (int i = 0; i < NMMA - 8; i++) {
-          __builtin_amdgcn_sched_group_barrier(0x002, ((NMAIN + 1) * 22 + NMMA - 9) / (NMMA - 8), 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          for (int i = 0; i < 3 * TNW; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, NMMA - 8 - 3 * TNW, 0);
+        } else {
+          // (NMAIN + 1) items x ~22 VALU (+ 3 LDS writes each, wherever they fall) in the shadow of the remaining MFMAs
+#pragma unroll
+          for (int i = 0; i < NMMA - 8; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x002, ((NMAIN + 1) * 22 + NMMA - 9) / (NMMA - 8), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
         }
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       if (ts_on) {
         const long long now_ = __builtin_readcyclecounter();

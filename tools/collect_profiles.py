@@ -17,13 +17,14 @@ for n in sorted(os.listdir(src)):
 for n in sorted(os.listdir(src)):
     if n.startswith(("kstats_", "pmc_sq_", "gru_ts", "layers", "direct_ts", "direct_sweep", "ubench_", "tile_sweep", "stress_",
                      "xcc_migrate", "timings", "sharded_rate", "box_health", "d4_sweep", "d4_ts", "lanes_", "free_run", "d2_sweep", "chainw_ts",
-                     "hwq", "env_knobs")):
+                     "hwq", "env_knobs", "split_", "cumask")):
         shutil.copy(os.path.join(src, n), os.path.join(dst, f"{tag}_{n}"))
 
 FAMS = {"direct2": ("conv_direct2_kernel", "conv_direct2w_kernel", "conv_direct4w_kernel"),
         "direct": ("conv_direct_kernel", "conv_direct_strided_kernel"),
         "direct4": ("conv_direct4_kernel",),
         "direct3": ("conv_direct3_kernel", "conv_direct3w_kernel", "conv_direct3s_kernel"),
+        "split": ("conv_split_kernel",),
         "lds": ("conv_mfma_kernel",), "rate": ("rate_down_kernel", "rate_up_kernel"),
         "chain": ("conv_chain_kernel", "conv_chainw_kernel"), "gru_ring": ("gru_ring_kernel",),
         "gru_cluster": ("gru_cluster_kernel",)}
@@ -45,7 +46,7 @@ NOTE = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate runs of t
         "requests at 64 B) + WRITE_SIZE KB (uncalibrated, taken as is). Memory-side L2 traffic: Infinity-Cache hits are included.")
 out = {"note": NOTE, "configs": {}}
 # configuration tag -> sub-directory prefix written by tools/round_profile.sh (pmc_<tag>_FETCH_SIZE / _WRITE_SIZE)
-for cfg_tag in ("PP16_b1", "PP16_b8", "PP24_b8_varlen", "PP16_b4_n64", "OR16_b16_n32"):
+for cfg_tag in ("PP16_b1", "PP16_b8", "PP16_b16", "PP24_b8_varlen", "PP16_b4_n64", "OR16_b16_n32"):
     fp = os.path.join(src, f"pmc_{cfg_tag}_FETCH_SIZE", "p_counter_collection.csv")
     wp = os.path.join(src, f"pmc_{cfg_tag}_WRITE_SIZE", "p_counter_collection.csv")
     if not (os.path.exists(fp) and os.path.exists(wp)):

@@ -44,14 +44,14 @@ d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 print(sys.argv[2], "%.2f ms per step, %.1f utt/s, dominant %.1f %% of peak, all conv %.1f %%" % (d["ms_per_step"], d["utterances_per_s"], 100 * d["roofline"]["frac"], 100 * d["roofline"]["all_conv_kernels"]["frac"]))
 PY
 done
-for cfgname in "PP16_B8 --batch 8 --steps 2 --warmup 1" "C3 --batch 4 --n_steps 64 --steps 2 --warmup 1" "C4 --model OR16 --batch 16 --n_steps 32 --steps 2 --warmup 1" "C5 --model PP24 --batch 8 --varlen --steps 2 --warmup 1"; do
+for cfgname in "PP16_B8 --batch 8 --steps 2 --warmup 1" "PP16_B16 --batch 16 --steps 2 --warmup 1" "C3 --batch 4 --n_steps 64 --steps 2 --warmup 1" "C4 --model OR16 --batch 16 --n_steps 32 --steps 2 --warmup 1" "C5 --model PP24 --batch 8 --varlen --steps 2 --warmup 1"; do
   set -- $cfgname; name=$1; shift
   timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/prof_$name -o k -- python bench.py --sustained-s 0 --in-flight "" "$@" --no-cpu-baseline --profile-steps 1 --batch-sweep "" > /dev/null 2>> $O/rocprof.err
   python tools/kstats.py $O/prof_$name/k_kernel_trace.csv | head -12 > $O/kstats_$name.txt
   rm -rf $O/prof_$name
 done
 # memory-side traffic per kernel family: headline, batch 8, C5
-for cfgname in "PP16_b1 " "PP16_b8 --batch 8" "PP24_b8_varlen --model PP24 --batch 8 --varlen"; do
+for cfgname in "PP16_b1 " "PP16_b8 --batch 8" "PP16_b16 --batch 16" "PP24_b8_varlen --model PP24 --batch 8 --varlen"; do
   set -- $cfgname; tag=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${tag}_$c -o p -- \
@@ -111,3 +111,18 @@ timeout 600 python tools/layer_table.py PP16 1 2>&1 | grep -v amdgpu.ids > $O/la
 OU_NO_OVERLAP=1 timeout 600 python tools/layer_table.py PP16 1 2>&1 | grep -v amdgpu.ids > $O/layers_PP16_B1_serial.txt
 timeout 600 python tools/layer_table.py PP16 8 2>&1 | grep -v amdgpu.ids > $O/layers_PP16_B8.txt
 timeout 600 python tools/layer_table.py PP24 8 2>&1 | grep -v amdgpu.ids > $O/layers_PP24_B8.txt
+timeout 600 python tools/layer_table.py PP16 16 2>&1 | grep -v amdgpu.ids > $O/layers_PP16_B16.txt
+OU_SPLIT=0 timeout 600 python tools/layer_table.py PP16 16 2>&1 | grep -v amdgpu.ids > $O/layers_PP16_B16_fp32_only.txt
+# round 5, late: conv_split_kernel (BF16 matrix pipe, three bf16 pieces per fp32 operand) -- the layer shapes of the table in DESIGN.md
+# 4.1f in the microbenchmark (numerics against a double evaluation, phase stamps), the card's clock / power under it, A / B of the product
+(cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-function -o split_conv.bin split_conv.hip 2>> ../../$O/rocprof.err)
+{ for args in "256 256 5 2005 16" "256 256 3 2005 16" "512 512 5 401 16" "512 512 3 401 16" "256 256 5 2005 8" "256 256 3 2005 8" "128 128 5 8020 8 915" "128 128 3 8020 8 913" "128 128 5 8020 16" "64 64 5 32080 8" "64 64 3 32080 8" "512 512 5 401 8" "512 512 3 401 8" "768 768 5 601 8" "256 256 5 2003 3" "64 64 3 301 2"; do
+    OU_TS=1 timeout 120 tools/ubench/split_conv.bin $args 200; done; } 2>&1 | grep -v amdgpu.ids > $O/split_ubench.txt; tail -4 $O/split_ubench.txt
+timeout 600 python tools/split_clock.py 4 2>&1 | grep -v amdgpu.ids > $O/split_clock.txt; cat $O/split_clock.txt
+Q="--sustained-s 0 --in-flight= --no-cpu-baseline --batch-sweep= --profile-steps 0"
+for s in 0 -1 0 -1; do
+  for cfg in "--batch 16 --steps 5 --warmup 1" "--batch 32 --steps 3 --warmup 1" "--model OR16 --batch 16 --n_steps 32 --steps 3 --warmup 1"; do
+    echo "OU_SPLIT=$s $cfg: $(OU_SPLIT=$s timeout 600 python bench.py $Q $cfg 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print("%.2f ms per step, %.1f utt/s" % (d["ms_per_step"], d["utterances_per_s"]))')"
+  done
+done > $O/split_ab.txt 2>&1; cat $O/split_ab.txt
+timeout 120 tools/ubench/cumask_probe.bin > $O/cumask_probe.txt 2>&1
