@@ -117,7 +117,11 @@ struct EnvCfg {
   static int geti(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
   EnvCfg() {
     split = geti("OU_SPLIT", -1);
-    dbg = geti("OU_DBG", 0); xcd_map = geti("OU_XCD_MAP", -1); conv_direct = geti("OU_CONV_DIRECT", 5);
+#ifdef OU_EXPERIMENTS  // switches that make a call return WRONG results by design (phase ablation, the decoder-under-GRU upper bound):
+    // honoured by the experiments library only -- a stray environment variable cannot corrupt the default library's output
+    dbg = geti("OU_DBG", 0);
+#endif
+    xcd_map = geti("OU_XCD_MAP", -1); conv_direct = geti("OU_CONV_DIRECT", 5);
     fuse = geti("OU_FUSE", -1); fuse_nc = geti("OU_FUSE_NC", 0); rate_small = geti("OU_RATE_SMALL", 1);
     fuse_upfir = geti("OU_FUSE_UPFIR", 1);
     d4_fir = geti("OU_D4_FIR", 1);
@@ -133,7 +137,9 @@ struct EnvCfg {
     gru_upw = geti("OU_GRU_UPW", 0); gru_backoff = geti("OU_GRU_BACKOFF", 0); gru_agent = geti("OU_GRU_AGENT_STORES", -1);
     gru_dbg = geti("OU_GRU_DBG", 0);
 #ifdef OU_EXPERIMENTS  // measurement-only switch with INVALID results: `make EXPERIMENTS=1` builds only, never in the shipped library
+#ifdef OU_EXPERIMENTS
     dbg_dec0_under_gru = geti("OU_DBG_DEC0", 0);
+#endif
 #endif
     { const char* e = std::getenv("OU_TILE_MIN"); if (e) tile_min = std::atof(e); }
     tile_prefetch = geti("OU_TILE_PREFETCH", 1);

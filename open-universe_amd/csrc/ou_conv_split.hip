@@ -21,7 +21,9 @@
 //     element then feeds BM x KW x 6 MACs), written to LDS as [piece][sample][16 channels] bf16: the B fragment of tap k is the
 //     16-byte read at row (column + k) -- the taps are row offsets into the same image, no im2col;
 //   * per wave a 64 x (32 TNW) output tile: 2 x TNW x KW x 6 MFMAs per chunk (k5, TNW = 4: 240 = 7 680 cycles) against one
-//     barrier, 6 KW weight fragments and 3 TNW KW fragment reads from LDS: the loop is bound by the matrix pipe by construction.
+//     barrier, 6 KW weight fragments and 3 TNW KW fragment reads from LDS: the loop is bound by the matrix pipe by construction
+//     (measured, DESIGN.md 4.1f: an MFMA every 39-46 cycles instead of 32, the card power-limited at 2.0 GHz under this kernel,
+//     a fifth of a launch in the epilogue: 1.1-1.4x the fp32 kernels on the layers the launcher's rule gives it, not 2.67x).
 //   Summation order per output: channel chunks ascending, taps ascending, the six piece products hi.hi first, 16 channels per
 //   instruction in the pipe's own order -- fixed, different from every other family (results agree to fp32 rounding).
 #include "ou_kernels.h"

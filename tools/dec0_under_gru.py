@@ -1,4 +1,6 @@
-"""Upper bound for "the first decoder block under the GRU pass" (review of round 3, item 3): time of a score forward with the
+"""(needs the experiments library: make -C open-universe_amd/csrc EXPERIMENTS=1 and OU_LIBRARY=.../lib/libouniverse_experiments.so --
+the default library ignores the switches that invalidate results)
+Upper bound for "the first decoder block under the GRU pass" (review of round 3, item 3): time of a score forward with the
 three convs of score.dec0 launched on a side stream that does NOT wait for the recurrence (OU_DBG_DEC0=1: results invalid), against
 the normal forward.  A scheme that gates those convs on the recurrence's progress can only be slower than this."""
 import os, sys, time
