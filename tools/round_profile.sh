@@ -56,6 +56,8 @@ for cfgname in "PP16_b1 " "PP16_b8 --batch 8" "PP16_b16 --batch 16" "PP24_b8_var
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${tag}_$c -o p -- \
       python bench.py --sustained-s 0 --in-flight "" "$@" --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 --batch-sweep "" > /dev/null 2> $O/pmc_${tag}_$c.err
+    # per-family averages now, the raw per-dispatch CSV (tens of MB per pass) stays on the box: gpurun returns 64 MiB at most
+    python tools/collect_profiles.py --reduce $O/pmc_${tag}_$c/p_counter_collection.csv $O/pmc_${tag}_$c.json && rm -rf $O/pmc_${tag}_$c
   done
 done
 # SQ counters (4 per pass): the 512-channel k3 latent-level conv at batch 1 (split-K kernel) and the 192-channel k3 conv of
@@ -126,3 +128,7 @@ for s in 0 -1 0 -1; do
   done
 done > $O/split_ab.txt 2>&1; cat $O/split_ab.txt
 timeout 120 tools/ubench/cumask_probe.bin > $O/cumask_probe.txt 2>&1
+# what travels back (gpurun merges at most 64 MiB): the kernel trace / stats of the headline run, no other rocprofv3 directories
+find $O -mindepth 1 -maxdepth 1 -type d ! -name prof -exec rm -rf {} +
+find $O/prof -type f ! -name "bench_kernel_stats.csv" ! -name "bench_kernel_trace.csv" -delete 2>/dev/null
+du -sh $O | tail -1
