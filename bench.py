@@ -315,7 +315,7 @@ def parse_args(argv=None):
     ap.add_argument("--in-flight", default="4",
                     help="lanes of the ragged-set leg (32 utterances of 32 different lengths through "
                          "distributed.enhance_sharded, serial loop vs K calls in flight); '' = off")
-    ap.add_argument("--batch-sweep", default="1,4,8",
+    ap.add_argument("--batch-sweep", default="1,4,8,16",
                     help="also time these per-GPU batch sizes (short loops after the main one): one invocation gives the "
                          "utterances/s curve of configs[1] (batch 1) and of the batched throughput mode; '' = off")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
