@@ -142,8 +142,7 @@ def channels(path):
     if ta is not None:
         return int(ta.info(str(path)).num_channels)
     if Path(path).suffix.lower() == ".flac":
-        with open(path, "rb") as f:
-            raw = f.read(1 << 16)  # (the header: STREAMINFO is the first metadata block)
+        raw = Path(path).read_bytes()  # (the metadata may hold blocks of any size -- cover art -- in front of the first frame)
         try:
             return _flac_info_header(raw)
         except RuntimeError as e:
