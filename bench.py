@@ -776,6 +776,14 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "dtype_note": "fp32 tensors and fp32 accumulation everywhere; the timed configuration (batch %d) runs %s" % (
+                args.batch, "its k3 / k5 convs of the 256- / 512-channel levels on the BF16 matrix pipe with every fp32 operand as three "
+                "bf16 pieces and six piece products per fp32 product (conv_split_kernel, DESIGN.md 4.1f: fp32-class accuracy, measured "
+                "1 dB better than an fp32 fmaf chain against a double evaluation; OU_SPLIT=0 keeps everything on the f32 MFMAs)"
+                if (args.batch >= 16 and os.environ.get("OU_SPLIT", "-1") != "0") else
+                "every convolution on the f32-input MFMAs (exact fp32 products); from batch 16 -- the '16' entry of batch_sweep -- the "
+                "256- / 512-channel k3 / k5 convs go to conv_split_kernel (three bf16 pieces per fp32 operand on the BF16 pipe, "
+                "fp32-class accuracy, DESIGN.md 4.1f)"),
             "data": "synthetic (seeded AM-sine + noise waveforms; seeded random weights with the reference key schema)",
             "config": {
                 "workload": f"{what}, {args.n_steps} diffusion steps, batch={args.batch} utterance(s) of "
