@@ -127,7 +127,7 @@ for s in 0 -1 0 -1; do
     echo "OU_SPLIT=$s $cfg: $(OU_SPLIT=$s timeout 600 python bench.py $Q $cfg 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print("%.2f ms per step, %.1f utt/s" % (d["ms_per_step"], d["utterances_per_s"]))')"
   done
 done > $O/split_ab.txt 2>&1; cat $O/split_ab.txt
-timeout 120 tools/ubench/cumask_probe.bin > $O/cumask_probe.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/cumask_probe tools/ubench/cumask_probe.hip 2>> $O/rocprof.err && timeout 120 /tmp/cumask_probe > $O/cumask_probe.txt 2>&1
 # what travels back (gpurun merges at most 64 MiB): the kernel trace / stats of the headline run, no other rocprofv3 directories
 find $O -mindepth 1 -maxdepth 1 -type d ! -name prof -exec rm -rf {} +
 find $O/prof -type f ! -name "bench_kernel_stats.csv" ! -name "bench_kernel_trace.csv" -delete 2>/dev/null
