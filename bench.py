@@ -210,15 +210,17 @@ def cpu_baseline_worker(model_name, n_steps, seconds, budget_s):
             break
         torch.set_num_threads(c)
         timed(2)  # the thread pool of this setting
-        sweep[c] = timed(n_meas)
+        # (the cheap settings twice, the faster run counts: a single sample flipped the choice between 8 and 16 threads from run
+        # to run and moved the reported baseline by 30 %)
+        sweep[c] = min(timed(n_meas), timed(n_meas)) if c <= 16 else timed(n_meas)
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     times = [sweep[best]]
     while len(times) < 3 and time.time() - t_begin < budget_s:
         times.append(timed(n_meas))
     times.sort()
-    med = times[len(times) // 2]
-    how = f"median of {len(times)} run(s) at the best thread count"
+    med = times[0]  # the FASTEST run: the baseline gets the benefit of the doubt
+    how = f"fastest of {len(times)} run(s) at the best thread count"
     if n_meas != n_steps:
         t2 = timed(2)
         per_step = max(0.0, (med - t2) / (n_meas - 2))
