@@ -18,8 +18,9 @@
 //     different rows (no LDS for weights);
 //   * activations: a block stages 16 channels x (BN + KW - 1) samples per K chunk: 4-byte global loads (coalesced along time),
 //     PReLU, the 3-way split on the VALU (v_cvt_pk_bf16_f32: 5.5 instructions per element, once per BLOCK and chunk -- every
-//     element then feeds BM x KW x 6 MACs), written to LDS as [piece][sample][16 channels] bf16: the B fragment of tap k is the
-//     16-byte read at row (column + k) -- the taps are row offsets into the same image, no im2col;
+//     element then feeds BM x KW x 6 MACs), written to LDS as [piece][K half][sample][8 channels] bf16: the B fragment of tap k is the
+//     16-byte read at row (column + k) of the lane's K half -- the taps are row offsets into the same image, no im2col, and the
+//     32 lanes of a half read 512 contiguous bytes (no bank conflicts);
 //   * per wave a 64 x (32 TNW) output tile: 2 x TNW x KW x 6 MFMAs per chunk (k5, TNW = 4: 240 = 7 680 cycles) against one
 //     barrier, 6 KW weight fragments and 3 TNW KW fragment reads from LDS: the loop is bound by the matrix pipe by construction
 //     (measured, DESIGN.md 4.1f: an MFMA every 39-46 cycles instead of 32, the card power-limited at 2.0 GHz under this kernel,
@@ -59,8 +60,15 @@ template <int KW, int WM, int TNW>
 __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split_kernel(ConvArgs p) {
   constexpr int WN = 4 / WM, WTN = 32 * TNW, BN = WN * WTN, PAD = (KW - 1) / 2;
   constexpr int R = BN + KW - 1;          // staged samples per channel and chunk
-  constexpr int PIECE = (R + 1) * 32;     // bytes of one piece plane: [R][16 channels] bf16 (+ one row nobody reads: the halo
-                                          // item of the threads that have none is written there -- no branch in the staging code)
+  // LDS image of one piece: two planes by K half, [half][row][8 channels = 16 bytes] -- the 32 lanes of a fragment half read 512
+  // contiguous bytes (a [row][16 channels] image puts lanes i and i + 8 on the same banks: 2-way conflicts on every fragment read,
+  // 47 % of the LDS cycles in SQ_LDS_BANK_CONFLICT).  ROWS16: R + 1 rows (one row nobody reads: the halo item of the threads that
+  // have none is written there -- no branch in the staging code), padded so that the two planes start on opposite bank halves (the
+  // staging writes of a wave go to 8 rows of both planes at once).
+  constexpr int ROWS16 = ((R + 1 + 7) / 16) * 16 + 8 >= R + 1 ? ((R + 1 + 7) / 16) * 16 + 8 : ((R + 1 + 7) / 16) * 16 + 24;
+  static_assert(ROWS16 >= R + 1 && ROWS16 % 16 == 8, "plane rows");
+  constexpr int HALF = ROWS16 * 16;       // bytes of one plane
+  constexpr int PIECE = 2 * HALF;         // bytes of one piece
   constexpr int BUF = 3 * PIECE;          // one stage (hi, mid, lo)
   constexpr int NMAIN = BN / 32;          // staged (sample, channel pair) items per thread; + (KW - 1) * 8 halo items on threads 0..
   static_assert(KW == 3 || KW == 5, "k3 / k5");
@@ -116,15 +124,15 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
     }
   };
   auto stage_store = [&](int buf) {
-    unsigned char* base = smem_split + buf * BUF + cp * 4;
+    unsigned char* base = smem_split + buf * BUF + (cp >> 2) * HALF + (cp & 3) * 4;
 #pragma unroll
     for (int j = 0; j <= NMAIN; j++) {
       const int row = j < NMAIN ? row0 + 32 * j : (tid < 8 * (KW - 1) ? BN + row0 : R);
       unsigned H, M, Lo;
       split_pair(prelu(sx[j][0], alpha), prelu(sx[j][1], alpha), H, M, Lo);
-      *reinterpret_cast<unsigned*>(base + row * 32) = H;
-      *reinterpret_cast<unsigned*>(base + PIECE + row * 32) = M;
-      *reinterpret_cast<unsigned*>(base + 2 * PIECE + row * 32) = Lo;
+      *reinterpret_cast<unsigned*>(base + row * 16) = H;
+      *reinterpret_cast<unsigned*>(base + PIECE + row * 16) = M;
+      *reinterpret_cast<unsigned*>(base + 2 * PIECE + row * 16) = Lo;
     }
   };
 
@@ -149,14 +157,14 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0.f;
 
-  const int boff = (wn * WTN + (lane & 31)) * 32 + (lane >> 5) * 16;  // this lane's fragment row / half inside a piece plane
+  const int boff = (lane >> 5) * HALF + (wn * WTN + (lane & 31)) * 16;  // this lane's plane (K half) and row inside a piece
   bf16x8 Bf[2][TNW][3];
   auto read_b = [&](int buf, int tap, bf16x8 (&bf)[TNW][3]) {
-    const unsigned char* bb = smem_split + buf * BUF + boff + tap * 32;
+    const unsigned char* bb = smem_split + buf * BUF + boff + tap * 16;
 #pragma unroll
     for (int tn = 0; tn < TNW; tn++)
 #pragma unroll
-      for (int pc = 0; pc < 3; pc++) bf[tn][pc] = *reinterpret_cast<const bf16x8*>(bb + pc * PIECE + tn * 32 * 32);
+      for (int pc = 0; pc < 3; pc++) bf[tn][pc] = *reinterpret_cast<const bf16x8*>(bb + pc * PIECE + tn * 32 * 16);
   };
 
   load_a(0, A[0]);
@@ -196,7 +204,8 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
 #elif OU_SPLIT_SCHED == 2
       __builtin_amdgcn_sched_barrier(0);             // (experiment: loads AND the staging work in front of the MFMAs)
 #endif
-      // hi.hi | hi.mid, mid.hi | hi.lo, mid.mid, lo.hi -- two independent accumulators alternate
+      // hi.hi | hi.mid, mid.hi | hi.lo, mid.mid, lo.hi -- two independent accumulators alternate (per product all 2 TNW
+      // accumulators in turn instead: the same within 2 %, profiles/r05_split_ubench_mfma_order.txt)
 #pragma unroll
       for (int tn = 0; tn < TNW; tn++) {
 #pragma unroll
@@ -330,7 +339,7 @@ struct SplitCfg {
 };
 template <int KW, int WM, int TNW>
 constexpr SplitCfg split_cfg() {
-  return {KW, WM, TNW, conv_split_kernel<KW, WM, TNW>, (size_t)2 * 3 * ((4 / WM) * 32 * TNW + KW) * 32};
+  return {KW, WM, TNW, conv_split_kernel<KW, WM, TNW>, (size_t)2 * 3 * 2 * (((((4 / WM) * 32 * TNW + KW) + 7) / 16) * 16 + 24) * 16};  // (>= the kernel's 2 BUF; see ROWS16)
 }
 const SplitCfg kSplitCfgs[] = {
     split_cfg<3, 1, 4>(), split_cfg<3, 2, 4>(), split_cfg<3, 4, 4>(), split_cfg<3, 1, 2>(), split_cfg<3, 2, 2>(), split_cfg<3, 4, 2>(),
