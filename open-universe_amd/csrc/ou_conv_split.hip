@@ -44,19 +44,25 @@ namespace ou {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// two fp32 values -> three dwords of packed bf16 pairs (element 0 in the low half)
+// two fp32 values -> three dwords of packed bf16 pairs (element 0 in the low half).  Packed conversion FIRST, the fp32 value of a
+// piece re-read from the packed dword (a shift / a mask): 11 instructions per pair -- written through `__bf16` scalars the compiler
+// converts every element twice (once alone for the residual, once in the pair): 17, and every VALU instruction beside the MFMAs
+// costs about four cycles of the matrix pipe.
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, bf16x2{(__bf16)a, (__bf16)b});  // v_cvt_pk_bf16_f32 (round to nearest even)
+}
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& H, unsigned& M, unsigned& L) {
-  const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
-  const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;  // exact
-  const __bf16 m0 = (__bf16)r0, m1 = (__bf16)r1;
-  const float q0 = r0 - (float)m0, q1 = r1 - (float)m1;  // exact
-  H = __builtin_bit_cast(unsigned, bf16x2{h0, h1});
-  M = __builtin_bit_cast(unsigned, bf16x2{m0, m1});
-  L = __builtin_bit_cast(unsigned, bf16x2{(__bf16)q0, (__bf16)q1});
+  H = pack_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(H << 16), r1 = x1 - __uint_as_float(H & 0xFFFF0000u);  // exact
+  M = pack_bf16(r0, r1);
+  const float q0 = r0 - __uint_as_float(M << 16), q1 = r1 - __uint_as_float(M & 0xFFFF0000u);  // exact
+  L = pack_bf16(q0, q1);
 }
 
 // (TNW = 2: two blocks per CU -- the other block's MFMAs cover this one's barriers, fragment latencies, staging and epilogue)
-template <int KW, int WM, int TNW>
+// (ACT: the PReLU of the operand path, 6 VALU instructions per staged pair -- most layers of a ConvBlock get their input already
+// activated by the producer's epilogue, out_act, and run the variant without it)
+template <int KW, int WM, int TNW, bool ACT>
 __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split_kernel(ConvArgs p) {
   constexpr int WN = 4 / WM, WTN = 32 * TNW, BN = WN * WTN, PAD = (KW - 1) / 2;
   constexpr int R = BN + KW - 1;          // staged samples per channel and chunk
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
   const int n0 = ct * BN, m0 = rg * (64 * WM) + wm * 64;
   const int Tin = p.Tin, Cin = p.Cin;
   const int NCH = Cin >> 4, MT = p.Mp >> 5;
-  const float alpha = p.act ? p.alpha_val : 1.0f;
+  const float alpha = p.alpha_val;
   const float* xb = p.x + (size_t)b * Cin * Tin;
 
   // ---- staging of the activation tile
@@ -129,7 +135,8 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
     for (int j = 0; j <= NMAIN; j++) {
       const int row = j < NMAIN ? row0 + 32 * j : (tid < 8 * (KW - 1) ? BN + row0 : R);
       unsigned H, M, Lo;
-      split_pair(prelu(sx[j][0], alpha), prelu(sx[j][1], alpha), H, M, Lo);
+      if constexpr (ACT) split_pair(prelu(sx[j][0], alpha), prelu(sx[j][1], alpha), H, M, Lo);
+      else split_pair(sx[j][0], sx[j][1], H, M, Lo);
       *reinterpret_cast<unsigned*>(base + row * 16) = H;
       *reinterpret_cast<unsigned*>(base + PIECE + row * 16) = M;
       *reinterpret_cast<unsigned*>(base + 2 * PIECE + row * 16) = Lo;
@@ -334,12 +341,15 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
 namespace {
 struct SplitCfg {
   int KW, WM, TNW;
-  void (*kern)(ConvArgs);
+  void (*kern)(ConvArgs);      // operand path without PReLU
+  void (*kern_act)(ConvArgs);  // ... with it
   size_t lds;
 };
 template <int KW, int WM, int TNW>
 constexpr SplitCfg split_cfg() {
-  return {KW, WM, TNW, conv_split_kernel<KW, WM, TNW>, (size_t)2 * 3 * 2 * (((((4 / WM) * 32 * TNW + KW) + 7) / 16) * 16 + 24) * 16};  // (>= the kernel's 2 BUF; see ROWS16)
+  // two staging buffers of three pieces, two K-half planes each (>= the kernel's 2 BUF; see ROWS16)
+  return {KW, WM, TNW, conv_split_kernel<KW, WM, TNW, false>, conv_split_kernel<KW, WM, TNW, true>,
+          (size_t)2 * 3 * 2 * (((((4 / WM) * 32 * TNW + KW) + 7) / 16) * 16 + 24) * 16};
 }
 const SplitCfg kSplitCfgs[] = {
     split_cfg<3, 1, 4>(), split_cfg<3, 2, 4>(), split_cfg<3, 4, 4>(), split_cfg<3, 1, 2>(), split_cfg<3, 2, 2>(), split_cfg<3, 4, 2>(),
@@ -350,6 +360,8 @@ const SplitCfg kSplitCfgs[] = {
 hipError_t init_split_kernels() {
   for (const SplitCfg& c : kSplitCfgs) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern_act), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
@@ -383,7 +395,7 @@ hipError_t launch_conv_split(const ConvArgs& a, int num_cu, hipStream_t stream, 
   aa.grid_n = (int)((a.Nq + bn - 1) / bn);
   const long total8 = ((long)aa.grid_n * a.B + 7) / 8 * 8;
   if (cfg_out) *cfg_out = 800 + (tnw == 2 ? 100 : 0) + 10 * (wm == 4 ? 2 : (wm == 2 ? 1 : 0)) + a.KW;
-  hipLaunchKernelGGL(c->kern, dim3((unsigned)(total8 * aa.grid_m)), dim3(256), c->lds, stream, aa);
+  hipLaunchKernelGGL(a.act ? c->kern_act : c->kern, dim3((unsigned)(total8 * aa.grid_m)), dim3(256), c->lds, stream, aa);
   return hipGetLastError();
 }
 

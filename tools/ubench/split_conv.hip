@@ -50,7 +50,8 @@ int main(int argc, char** argv) {
   CHK(hipGetDeviceProperties(&pr, 0));
   ou::ConvArgs a;
   a.x = dx; a.wsplit = dw; a.bias = db; a.y = dy; a.res = dr; a.res_scale = 0.70710678f;
-  a.act = 1; a.alpha_val = 0.25f;
+  const int act = argc > 9 ? atoi(argv[9]) : 1;  // PReLU in the operand path (the variant without it: layers whose producer activated)
+  a.act = act; a.alpha_val = 0.25f;
   a.B = B; a.Cin = Cin; a.Tin = T; a.Cout = M; a.M = M; a.Mp = Mp; a.KW = KW; a.pad = (KW - 1) / 2; a.Nq = T; a.Tout = T;
   a.force_cfg = force;
   a.dbg = argc > 8 ? atoi(argv[8]) : 0;  // tuning: 1 = no epilogue (wrong results), 16 / 32 + 256 x us = every second block starts late
@@ -78,7 +79,7 @@ int main(int argc, char** argv) {
         const int tt = t + k - (KW - 1) / 2;
         if (tt < 0 || tt >= T) continue;
         float xv = x[((size_t)b * Cin + ci) * T + tt];
-        xv = xv >= 0.f ? xv : 0.25f * xv;
+        if (act) xv = xv >= 0.f ? xv : 0.25f * xv;
         const float wv = W[((size_t)m * Cin + ci) * KW + k];
         acc += (double)wv * (double)xv;
         accf = fmaf(wv, xv, accf);
@@ -90,8 +91,8 @@ int main(int argc, char** argv) {
     ref2 += ref * ref;
     worst = std::fmax(worst, std::fabs(y[idx] - ref));
   }
-  printf("M=%d Cin=%d KW=%d T=%d B=%d cfg=%d: SNR vs double %.1f dB (plain fp32 fmaf chain on the same samples: %.1f dB), worst abs err %.3g\n",
-         M, Cin, KW, T, B, cfg, 10 * std::log10(ref2 / (e_split + 1e-300)), 10 * std::log10(ref2 / (e_f32 + 1e-300)), worst);
+  printf("M=%d Cin=%d KW=%d T=%d B=%d cfg=%d act=%d: SNR vs double %.1f dB (plain fp32 fmaf chain on the same samples: %.1f dB), worst abs err %.3g\n",
+         M, Cin, KW, T, B, cfg, act, 10 * std::log10(ref2 / (e_split + 1e-300)), 10 * std::log10(ref2 / (e_f32 + 1e-300)), worst);
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
   for (int i = 0; i < 3; i++) CHK(ou::launch_conv_split(a, pr.multiProcessorCount, 0, nullptr));
