@@ -491,13 +491,13 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
   // (many blocks of 64 x 128 per CU without splitting K) stay on the LDS-tiled configs.
   // Stride-1 k3 / k5 layers with enough work per launch to feed the BF16 matrix pipe: the bf16-split kernel (conv_split_kernel,
   // six bf16 products per fp32 product).  Rule from tools/ubench/split_conv.hip against the per-layer tables of the fp32 kernels and
-  // from A / B runs of the product (profiles/r05_split_*): rows a multiple of 256 (four waves stacked along the rows, each weight
-  // fragment fetched once per block) and a whole device's worth of 256 x 128 output blocks -- PP16 / OR16: the 256-channel level
-  // from B = 16 -- or half a device's worth on short rows (the 401-frame level, on the split-K fp32 kernels otherwise: the
-  // 512-channel convs from B = 16).  Below that the minimal-filtering fp32 kernels are ahead or level (B = 8: 24.8 vs 24.9 ms).
+  // from A / B runs of the product (profiles/r05_split_*, r05_late_*): rows a multiple of 256 (four waves stacked along the rows, each
+  // weight fragment fetched once per block) and a whole device's worth of 256 x 128 output blocks, half a device's worth for the k5
+  // layers and on short rows (the 401-frame level, on the split-K fp32 kernels otherwise) -- PP16 / OR16: the 256- and 512-channel
+  // levels from B = 16, the 256-channel k5 convs from B = 8 (24.2 -> 24.05 ms per call there; k3 at B = 8: level, stays).
   if (a.wsplit && a.split != 0 && (a.force_cfg < 0 || (a.force_cfg >= 800 && a.force_cfg < 1100))) {
     const double tiles = (double)(a.M / 64) * ((a.Nq + 127) / 128) * a.B / 4.0;  // 256 x 128 blocks' worth of output
-    const bool rule = a.M >= 256 && a.M % 256 == 0 && tiles >= (a.Nq < 1024 ? 0.45 : 0.9) * num_cu;
+    const bool rule = a.M >= 256 && a.M % 256 == 0 && tiles >= ((a.Nq < 1024 || a.KW == 5) ? 0.45 : 0.9) * num_cu;
     if (a.split == 1 || a.force_cfg >= 800 || rule) {
       hipError_t e = launch_conv_split(a, num_cu, stream, cfg_out);
       if (e != hipErrorInvalidConfiguration) return e;
