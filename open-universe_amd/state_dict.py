@@ -223,11 +223,14 @@ def buffer_value(key: str, shape) -> torch.Tensor:
     raise KeyError(key)
 
 
-def synthetic_state_dict(spec: ModelSpec, seed: int = 0, gain: float = 1.0) -> Dict[str, torch.Tensor]:
+def synthetic_state_dict(spec: ModelSpec, seed: int = 0, gain: float = 1.0, tail: float = 0.0) -> Dict[str, torch.Tensor]:
     """Seeded random weights with the reference key schema, scaled so that activations stay O(1) through
     the whole stack (a random net with default init collapses to ~0 and would make parity trivial).
-    Deterministic given (spec, seed): a recipe, not data.  `gain` > 1 gives the "stress" set."""
+    Deterministic given (spec, seed): a recipe, not data.  `gain` > 1 gives the "stress" set; `tail` > 0 makes the
+    per-channel weight-norm gains heavy-tailed (log-normal factor exp(tail * N(0, 1)) from a generator of its own, so the
+    other draws of a seed do not move): a few output channels several times louder than the rest, as trained nets have."""
     gen = torch.Generator().manual_seed(seed)
+    gen_tail = torch.Generator().manual_seed(7919 + seed)
     sd: Dict[str, torch.Tensor] = {}
 
     def rn(*shape):
@@ -247,6 +250,8 @@ def synthetic_state_dict(spec: ModelSpec, seed: int = 0, gain: float = 1.0) -> D
             v = 0.05 * rn(*shape)
         elif leaf == "weight_g":
             v = gain * (1.25 + 0.1 * rn(*shape)).abs()
+            if tail > 0.0:
+                v = v * torch.exp(tail * torch.randn(*shape, generator=gen_tail) - 0.5 * tail * tail)
             if key in aa_convs:
                 v = v / 4.0  # the unit-RMS binomial FIR has a DC gain of 4..8
         elif "prelu.weight" in key or key.endswith(".prelu.weight"):

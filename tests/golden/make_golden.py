@@ -19,7 +19,13 @@ Fixtures are DATA only: inputs are regenerated from seeds, outputs are stored as
     loud_<cfg>.npz       inputs loud enough that the peak guard (universe.py:356-357) divides: row 0 at the usual level, row 1
                          60 x louder; with keep_rms (the RMS restore puts row 1 far above full scale, the guard fires on that row
                          only) and without (normalize_batch removes the level; the guard's state is asserted, not assumed)
-Run:  python tests/golden/make_golden.py [base] [stress] [configs] [transform] [loud]      (default: base)
+    fullstress_<cfg>.npz FULL-WIDTH models (PP16, OR16) on three hard weight draws -- s3g13 (seed 3, gain 1.3), s5g15 / s5g14 (seed 5,
+                         gain 1.5 / 1.4: the harshest that stays finite in the reference), s7g12t4 (seed 7, gain 1.2, heavy-tailed
+                         weight-norm gains) --, 4 s, 8 steps, two utterances (the HIP tests
+                         run row 0 alone = the batch-1 dispatch, and rows 0-1 inside a batch of 16 = the throughput dispatch).
+                         Beside every output the REFERENCE'S OWN SELF-AGREEMENT on those weights as scalars: 1 thread vs 8
+                         threads and fp32 vs fp64 (SI-SDR / SNR in dB, row 0) -- the yardstick for the HIP path's figures
+Run:  python tests/golden/make_golden.py [base] [stress] [configs] [transform] [loud] [fullstress]      (default: base)
 """
 import json
 import os
@@ -49,7 +55,7 @@ def varlen_lengths(fs=24000, n=8, seed=5):
     return sorted((int(fs * (1.0 + 7.0 * float(v))) for v in u), reverse=True)
 
 
-def build(name, seed=0, gain=1.0):
+def build(name, seed=0, gain=1.0, tail=0.0):
     base, over = SMALL.get(name, (name, {}))
     ov = {}
     for k, v in over.items():
@@ -57,7 +63,7 @@ def build(name, seed=0, gain=1.0):
         ov[k.replace("score_model", "condition_model")] = v
     m, cfg = R.build_reference_model(REF_CFG[base], ov)
     spec = get_spec(name)
-    sd = S.synthetic_state_dict(spec, seed=seed, gain=gain)
+    sd = S.synthetic_state_dict(spec, seed=seed, gain=gain, tail=tail)
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all(k.startswith("loss_") for k in missing)
     if m.ema is not None:
@@ -120,6 +126,52 @@ def make_configs():
                         row0=enh[0, :lens[0]].numpy().astype(np.float32),
                         row7=enh[7, :lens[7]].numpy().astype(np.float32))
     print("C5", lens, enh.shape, float(enh.std()))
+
+
+# (gain 1.6 overflows in the reference itself at full width; OR16 -- no weight-norm, no EDM pre-conditioning -- already at 1.5)
+FULL_STRESS = {"PP16": {"s3g13": dict(seed=3, gain=1.3), "s5g15": dict(seed=5, gain=1.5), "s7g12t4": dict(seed=7, gain=1.2, tail=0.4)},
+               "OR16": {"s3g13": dict(seed=3, gain=1.3), "s5g14": dict(seed=5, gain=1.4), "s7g12t4": dict(seed=7, gain=1.2, tail=0.4)}}
+
+
+def _db(ref, est):
+    """(SI-SDR, plain SNR) in dB of est against ref, float64."""
+    r, e = ref.double().flatten(), est.double().flatten()
+    a = float((r * e).sum() / (r * r).sum())
+    si = 10 * np.log10(float(((a * r) ** 2).sum() / ((e - a * r) ** 2).sum().clamp(min=1e-300)))
+    sn = 10 * np.log10(float((r ** 2).sum() / ((e - r) ** 2).sum().clamp(min=1e-300)))
+    return si, sn
+
+
+def make_fullstress():
+    """Full-width stress goldens + the reference's self-agreement ('what's weak' 1(i)-(ii))."""
+    T, N, B = 64000, 8, 2
+    for name in ("PP16", "OR16"):
+        out = {"T": T, "B": B, "n_steps": N}
+        for tag, kw in FULL_STRESS[name].items():
+            m, spec, sd = build(name, **kw)
+            Tp = T + (spec.tot_ds - T % spec.tot_ds)
+            mix = synth_mix(spec, B, T)
+            nz = noise_list(2100 + kw["seed"], N, B, Tp)
+            torch.set_num_threads(8)
+            enh = enhance_with_noise(m, mix, nz, n_steps=N)
+            assert torch.isfinite(enh).all()
+            out[tag + "_enh"] = enh.numpy().astype(np.float32)
+            # self-agreement of the reference on row 0: 8 threads vs 1 thread, batch of 2 vs alone, fp32 vs fp64
+            nz0 = [z[:1] for z in nz]
+            one8 = enhance_with_noise(m, mix[:1], nz0, n_steps=N)
+            torch.set_num_threads(1)
+            one1 = enhance_with_noise(m, mix[:1], nz0, n_steps=N)
+            torch.set_num_threads(8)
+            m64 = m.double()
+            one64 = enhance_with_noise(m64, mix[:1].double(), [z.double() for z in nz0], n_steps=N)
+            m.float()
+            out[tag + "_self_threads"] = np.array(_db(one8, one1))
+            out[tag + "_self_batch"] = np.array(_db(one8, enh[:1]))
+            out[tag + "_self_fp64"] = np.array(_db(one64, one8))
+            print("fullstress", name, tag, "std", float(enh.std()), "peak", float(enh.abs().max()),
+                  "threads", out[tag + "_self_threads"], "batch", out[tag + "_self_batch"], "fp64", out[tag + "_self_fp64"],
+                  flush=True)
+        np.savez_compressed(os.path.join(HERE, f"fullstress_{name}.npz"), **out)
 
 
 LOUD_GAINS = (1.0, 60.0)
@@ -198,6 +250,8 @@ def main():
         make_configs()
     if "loud" in what:
         make_loud()
+    if "fullstress" in what:
+        make_fullstress()
     if "base" not in what:
         return
     # ---- key schema
