@@ -317,6 +317,8 @@ def parse_args(argv=None):
     ap.add_argument("--in-flight", default="4",
                     help="lanes of the ragged-set leg (32 utterances of 32 different lengths through "
                          "distributed.enhance_sharded, serial loop vs K calls in flight); '' = off")
+    ap.add_argument("--ragged-batch", default="8,16,32",
+                    help="batch sizes of the ragged-set leg's exact-batching runs (ou_enhance_var); empty: skip")
     ap.add_argument("--batch-sweep", default="1,4,8,16",
                     help="also time these per-GPU batch sizes (short loops after the main one): one invocation gives the "
                          "utterances/s curve of configs[1] (batch 1) and of the batched throughput mode; '' = off")
@@ -537,9 +539,28 @@ def main():
             in_flight[f"lanes_{k}"] = {"utterances_per_s": n_utt / tk, "ms_per_utterance": 1e3 * tk / n_utt,
                                        "real_time_factor": sum(lens) / spec.fs / tk,
                                        "bit_identical_to_serial": all(torch.equal(ref[i], ok_[i]) for i in ref)}
-        in_flight["note"] = ("distributed.enhance_sharded on ONE GPU, 32 utterances of 32 different lengths (cannot be batched "
-                             "without changing their result): one call at a time vs K calls in flight on K streams "
-                             "(open_universe_amd/lanes.py), every call the same launches as in the serial loop")
+        # ... and the same set through EXACT batching (ou_enhance_var: every row keeps its own padding, statistics, conv zero
+        # padding and GRU length -- the result of the file-by-file loop to fp32 round-off, at the batched kernels' rate)
+        def snr_db(a, b):
+            a, b = a.double(), b.double()
+            return float(10 * torch.log10(a.square().sum() / (a - b).square().sum().clamp(min=1e-300)))
+
+        for bs in [int(v) for v in args.ragged_batch.split(",") if v.strip()]:
+            best, ob = None, None
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ob = D.enhance_sharded(model, sigs, seed=3, gather=False, batch_size=bs, n_steps=args.n_steps)
+                torch.cuda.synchronize()
+                best = time.perf_counter() - t0
+            in_flight[f"exact_batch_{bs}"] = {"utterances_per_s": n_utt / best, "ms_per_utterance": 1e3 * best / n_utt,
+                                              "real_time_factor": sum(lens) / spec.fs / best,
+                                              "worst_row_snr_db_vs_serial": min(snr_db(ref[i], ob[i]) for i in ref)}
+        in_flight["note"] = ("distributed.enhance_sharded on ONE GPU, 32 utterances of 32 different lengths: one call at a time vs K "
+                             "calls in flight on K streams (open_universe_amd/lanes.py; every call the same launches as in the "
+                             "serial loop) vs exact batching with per-row lengths (exact_batch_N: N utterances per ou_enhance_var "
+                             "call, length-sorted neighbours; same per-utterance generators, plain SNR of the worst row against "
+                             "the serial loop's output)")
         step()
 
     # ---- host side: time to ENQUEUE one enhance (no sync), eager walk of the network vs one hipGraph replay ----

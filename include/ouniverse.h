@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OU_ABI_VERSION 4 /* 4: the packed blob carries a bf16-split weight copy (conv_split_kernel); 3: a Winograd-domain copy (round 5), ou_set_lane_batch, ou_lane_capacity */
+#define OU_ABI_VERSION 5 /* 5: ou_enhance_var (batches whose rows have lengths of their own), workspace header carries the per-row geometry; 4: the packed blob carries a bf16-split weight copy (conv_split_kernel); 3: a Winograd-domain copy (round 5), ou_set_lane_batch, ou_lane_capacity */
 
 enum {
   OU_OK = 0,
@@ -155,6 +155,24 @@ int ou_aux_to_wav(ou_handle* h, float* wav_out, int32_t B, int32_t T, void* ws, 
 int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, int32_t B, int32_t T_raw,
                int32_t n_steps, double epsilon, const float* sigma_host, int32_t warm_start, uint32_t flags,
                void* ws, size_t ws_bytes, ou_stream_t stream);
+
+/* The same for a batch whose rows have lengths of their OWN ("exact batching"; extension).  The reference has no such call:
+ * its CLI runs a directory one file at a time (bin/enhance.py:173-192) and its collator zero-pads a batch WITHOUT a mask
+ * (datasets/datamodule.py:24-42), so that the padding takes part in the normalisation, the mel norm, the conv halos and the GRU
+ * -- every row then differs from what the file would give alone.  Here row b IS the call on that utterance alone, batched:
+ * its own pad() split (universe.py:219-223: pad_b = tot_ds - t_raw[b] % tot_ds, pad_b / 2 in front), its own mean / std
+ * (utils/norm.py:47-87) and mel norm (condition.py:105-106) over its own padded length, 'same' zero padding of every conv /
+ * FIR right behind its own last sample on every level, GRU passes over its own frames (the backward pass starts at its own
+ * last frame with h = 0), its own RMS restore and peak guard.  Results agree with the one-by-one loop to fp32 round-off
+ * (the kernels a batch selects differ from the batch-1 ones; tests: >= 100 dB).
+ *   mix, out : (B, T_raw_max) device; row b holds t_raw[b] samples, the rest of the row is ignored (mix) / zeroed (out)
+ *   t_raw    : B lengths on the HOST, 1 <= t_raw[b] <= T_raw_max = max_b t_raw[b]
+ *   noise    : (n_steps - warm_start, B, T_pad_max) device, T_pad_max = T_raw_max + (tot_ds - T_raw_max % tot_ds); row b
+ *              uses its first t_raw[b] + pad_b columns (what a call on that row alone would draw), the rest is ignored
+ *   workspace: as for ou_enhance with (B, T_pad_max).  A batch whose rows all have T_raw_max samples takes the plain path. */
+int ou_enhance_var(ou_handle* h, const float* mix, float* out, const float* noise, int32_t B, int32_t T_raw_max,
+                   const int32_t* t_raw, int32_t n_steps, double epsilon, const float* sigma_host, int32_t warm_start,
+                   uint32_t flags, void* ws, size_t ws_bytes, ou_stream_t stream);
 
 /* One sampler update on caller-owned buffers, for bindings that keep the reference's Python loop
  * (universe.py:339 `x = x + s_now^2 * eta * score + beta * z`, :343 `x = x + s_last^2 * score`):

@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 OU_MAX_RATES = 8
-OU_ABI_VERSION = 4
+OU_ABI_VERSION = 5
 OU_OK, OU_EINVAL, OU_ENOTIMPL, OU_EMISSING, OU_ESHAPE, OU_EHIP, OU_ENOMEM, OU_ESYNC = 0, -1, -2, -3, -4, -5, -6, -7
 OU_KIND_UNIVERSE, OU_KIND_UNIVERSE_GAN = 0, 1
 OU_ACT_NONE, OU_ACT_PRELU, OU_ACT_SNAKE = 0, 1, 2
@@ -94,6 +94,7 @@ def load():
         "ou_score": (i32, [vp, vp, POINTER(c_float), vp, i32, i32, vp, sz, vp]),
         "ou_aux_to_wav": (i32, [vp, vp, i32, i32, vp, sz, vp]),
         "ou_enhance": (i32, [vp, vp, vp, vp, i32, i32, i32, c_double, POINTER(c_float), i32, c_uint32, vp, sz, vp]),
+        "ou_enhance_var": (i32, [vp, vp, vp, vp, i32, i32, POINTER(i32), i32, c_double, POINTER(c_float), i32, c_uint32, vp, sz, vp]),
         "ou_check_device_status": (i32, [vp, vp]),
         "ou_plan_json": (c_char_p, [vp]),
         "ou_packer_plan_json": (c_char_p, [vp]),
@@ -128,7 +129,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "ou_version", "ou_last_error", "ou_packer_last_error", "ou_packer_create", "ou_packer_set", "ou_packer_finish",
     "ou_packer_destroy", "ou_packed_bytes", "ou_create", "ou_destroy", "ou_workspace_bytes", "ou_schedule",
-    "ou_condition", "ou_score", "ou_aux_to_wav", "ou_enhance", "ou_check_device_status", "ou_plan_json",
+    "ou_condition", "ou_score", "ou_aux_to_wav", "ou_enhance", "ou_enhance_var", "ou_check_device_status", "ou_plan_json",
     "ou_packer_plan_json", "ou_tensor", "ou_launch_stats", "ou_workspace_init", "ou_sampler_step",
     "ou_set_gru_publish_mode", "ou_get_gru_publish_mode", "ou_set_lanes", "ou_set_lane_batch", "ou_lane_capacity",
     "ou_transform_frames", "ou_transform_forward", "ou_transform_inverse",

@@ -45,17 +45,31 @@ def _flac_info(raw):
     return L, buf, fs.value, ch.value, bps.value, total.value, bytes(md5)
 
 
-def _flac_info_header(raw):
-    """channel count from the header bytes alone"""
-    from . import _lib
-
-    L = _lib.load()
-    buf = (ctypes.c_uint8 * len(raw)).from_buffer_copy(raw)
-    ch = ctypes.c_int32()
-    rc = L.ou_flac_info(buf, len(raw), None, ctypes.byref(ch), None, None, None)
-    if rc != 0:
-        raise RuntimeError((L.ou_flac_last_error() or b"FLAC decoding failed").decode())
-    return int(ch.value)
+def _flac_channels(path):
+    """Channel count of a FLAC file from its STREAMINFO block alone: the metadata block headers are walked with seeks, so
+    neither the audio frames nor large metadata blocks (cover art) are read."""
+    with open(path, "rb") as f:
+        head = f.read(10)
+        off = 0
+        if head[:3] == b"ID3" and len(head) == 10:  # ID3v2 tag in front of the stream: sync-safe size
+            sz = ((head[6] & 0x7F) << 21) | ((head[7] & 0x7F) << 14) | ((head[8] & 0x7F) << 7) | (head[9] & 0x7F)
+            off = 10 + sz + (10 if head[5] & 0x10 else 0)
+        f.seek(off)
+        if f.read(4) != b"fLaC":
+            raise RuntimeError("not a FLAC stream (no fLaC marker)")
+        while True:
+            h = f.read(4)
+            if len(h) < 4:
+                raise RuntimeError("FLAC: truncated metadata")
+            last, typ, ln = h[0] & 0x80, h[0] & 0x7F, int.from_bytes(h[1:4], "big")
+            if typ == 0:
+                s = f.read(ln)
+                if len(s) < 34 or ln < 34:
+                    raise RuntimeError("FLAC: short STREAMINFO")
+                return ((s[12] >> 1) & 7) + 1
+            f.seek(ln, 1)
+            if last:
+                raise RuntimeError("FLAC: no STREAMINFO block")
 
 
 def load_flac(path):
@@ -64,7 +78,14 @@ def load_flac(path):
     raw = Path(path).read_bytes()
     try:
         L, buf, fs, ch, bps, total, md5 = _flac_info(raw)
-        out = np.zeros((ch, max(total, 1)), dtype=np.int32)
+        # STREAMINFO is untrusted input (36 bits of sample count x up to 8 channels): a frame of a few bytes can stand for a
+        # whole block of 65 535 constant samples per channel, nothing can stand for more
+        if total > max(1, len(raw)) * 16384:
+            raise RuntimeError(f"FLAC: STREAMINFO claims {total} samples per channel, more than {len(raw)} bytes can encode")
+        try:
+            out = np.zeros((ch, max(total, 1)), dtype=np.int32)
+        except MemoryError:
+            raise RuntimeError(f"FLAC: cannot hold {ch} x {total} samples in memory") from None
         done = ctypes.c_int64()
         rc = L.ou_flac_decode(buf, len(raw), out.ctypes.data_as(ctypes.c_void_p), out.shape[1], ctypes.byref(done))
         if rc != 0:
@@ -142,9 +163,8 @@ def channels(path):
     if ta is not None:
         return int(ta.info(str(path)).num_channels)
     if Path(path).suffix.lower() == ".flac":
-        raw = Path(path).read_bytes()  # (the metadata may hold blocks of any size -- cover art -- in front of the first frame)
         try:
-            return _flac_info_header(raw)
+            return _flac_channels(path)
         except RuntimeError as e:
             raise RuntimeError(f"{path}: {e}") from None
     with open(path, "rb") as f:

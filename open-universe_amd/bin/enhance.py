@@ -14,12 +14,14 @@ Extensions (not in the reference, whose loop is serial on one device, one file p
   generator state left by files 0..k-1, a sharded run cannot reproduce the serial noise; with `--per-file-seed` (forced
   when N > 1) file k uses its own generator seeded with `seed + k` (k = index in the sorted file list), which makes the
   result of a file independent of how the list was sharded;
-* `--batch-size K`: up to K consecutive files (in processing order) of the same sample rate and length share one
-  `enhance` call (`Universe.enhance_many`; the channels of a file stay rows of the batch).  The noise is drawn file by
-  file in processing order with the shapes of the serial loop, so the shared generator advances exactly as in the
-  reference and every file gets the noise it would get alone; `--pad-batch` also groups files of different lengths,
-  right-zero-padded to the longest like the reference's `max_collator` (datasets/datamodule.py:24-42; no mask: the
-  padding takes part in the normalisation, as in a reference batch).
+* `--batch-size K`: up to K consecutive files (in processing order) of the same sample rate -- of ANY lengths -- share
+  one `enhance` call (`Universe.enhance_many`; the channels of a file stay rows of the batch).  Every row keeps the
+  geometry of the call on that file alone (own padding, normalisation, conv zero padding, GRU length: exact batching,
+  ou_enhance_var), and the noise is drawn file by file in processing order with the shapes of the serial loop, so the
+  shared generator advances exactly as in the reference and every file gets the noise -- and, to fp32 round-off, the
+  result -- it would get alone.  `--pad-batch` selects the reference's own batch semantics instead: right-zero-padded to
+  the longest like `max_collator` (datasets/datamodule.py:24-42; no mask: the padding takes part in the normalisation,
+  as in a reference batch).
 """
 import argparse
 import os
@@ -80,26 +82,28 @@ def build_parser():
                         help="Seed the generator of file k with seed + k instead of sharing one generator across files "
                              "(always on when the files are sharded over several processes)")
     parser.add_argument("--batch-size", type=int, default=1,
-                        help="Enhance up to this many consecutive files of equal rate and length in one call")
+                        help="Enhance up to this many consecutive files of equal sample rate (any lengths) in one call; "
+                             "every file gets the result it would get alone")
     parser.add_argument("--in-flight", type=int, default=1,
                         help="Keep this many enhance calls in flight side by side on the device (one stream and workspace "
-                             "each, 1..8): the mode for directories of files of DIFFERENT lengths -- same result as the "
-                             "file-by-file loop, bit for bit, at a multiple of its throughput")
+                             "each, 1..8): same result as the file-by-file loop, bit for bit, at a multiple of its "
+                             "throughput (--batch-size reaches a higher rate, equal to fp32 round-off)")
     parser.add_argument("--pad-batch", action="store_true",
-                        help="With --batch-size: also batch files of different lengths, zero-padded to the longest "
-                             "(reference batch semantics: the padding is not masked)")
+                        help="With --batch-size: files of different lengths are zero-padded to the longest WITHOUT a mask "
+                             "(the reference's batch semantics: the padding changes every result)")
     return parser
 
 
-def group_files(todo, infos, batch_size, pad_batch):
-    """Consecutive runs of `todo` (in processing order) that may share one enhance call: same sample rate, same number
-    of samples (any length with pad_batch), at most batch_size files.  infos[k] = (fs, n_samples)."""
+def group_files(todo, infos, batch_size, pad_batch=False):
+    """Consecutive runs of `todo` (in processing order) that may share one enhance call: same sample rate (any number of
+    samples: rows keep their own geometry, or are zero-padded with pad_batch), at most batch_size files.
+    infos[k] = (fs, n_samples)."""
     groups, cur = [], []
     for item in todo:
         k = item[0]
         if cur:
             k0 = cur[0][0]
-            same = infos[k][0] == infos[k0][0] and (pad_batch or infos[k][1] == infos[k0][1])
+            same = infos[k][0] == infos[k0][0]
             if not same or len(cur) >= batch_size:
                 groups.append(cur)
                 cur = []
@@ -185,8 +189,9 @@ def main(argv=None, model=None):
         # one call per file, batch size = its channel count: files that differ there put calls of different sizes in flight,
         # and the lanes then have to agree on how their GRU clusters share the device (headers only are read here)
         chans = {channels(path) for _, path in todo}
+        mb = max(chans, default=1)
         with LanePool(model, min(int(args.in_flight), LanePool.MAX_LANES),
-                      max_batch=max(chans) if len(chans) > 1 else 0) as pool:
+                      max_batch=mb if (len(chans) > 1 or mb > 1) else 0) as pool:
             pending = []
             for k, path in todo:
                 output_path = out_path(path)
@@ -227,7 +232,7 @@ def main(argv=None, model=None):
         return done
 
     # --batch-size: files are read in processing order and held only until their group is complete (consecutive files of
-    # equal rate and length, any length with --pad-batch, at most batch_size of them)
+    # equal rate, at most batch_size of them)
     if any(enhance_kwargs.get(key) is not None for key in ("ensemble", "target")):
         raise ValueError("--batch-size cannot be combined with --ensemble (one call per file needed)")
     kw = {key: v for key, v in enhance_kwargs.items() if key not in ("rng", "ensemble", "ensemble_stat", "target",
@@ -259,7 +264,7 @@ def main(argv=None, model=None):
     for k, path in todo:
         audio, fs = load(path)
         if group:
-            same = fs == group[0][3] and (args.pad_batch or audio.shape[-1] == group[0][2].shape[-1])
+            same = fs == group[0][3]
             if not same or len(group) >= args.batch_size:
                 flush(group)
                 group = []

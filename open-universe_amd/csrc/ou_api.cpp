@@ -204,6 +204,27 @@ struct Runner {
     chk(hipEventRecord(e, h->aux[k]), "join record");
     chk(hipStreamWaitEvent(to, e, 0), "join wait");
   }
+  // ---- ragged batch (ou_enhance_var): per-row lengths on every level, see ou_kernels.h
+  bool ragged = false;
+  const int* lens_dev = nullptr;  // [lv.n][B]
+  const RowInfo* rows_dev = nullptr;
+  LevelSpec lv;
+  int level_T[kMaxLenLevels] = {0};
+  // per-row lengths of a (B, C, Tl) tensor (null when all rows are whole)
+  const int* lens_of(int Tl) {
+    if (!ragged) return nullptr;
+    for (int l = 0; l < lv.n; l++)
+      if (level_T[l] == Tl) return lens_dev + (size_t)l * B;
+    if (herr == hipSuccess) { herr = hipErrorInvalidValue; where = "ragged batch: tensor length on no level"; }
+    return nullptr;
+  }
+  // keep the invariant "zero from the row's own length on" after a kernel that does not keep it itself
+  void mask(float* p, int C, int T) {
+    if (!ragged || dry || !ok()) return;
+    const int* ln = lens_of(T);
+    if (ln) chk(launch_mask_tail(p, ln, B, C, T, st), "mask tail");
+  }
+  void mask(const Tensor& t) { mask(t.p, t.C, t.T); }
   bool ok() const { return herr == hipSuccess && !oom; }
   void chk(hipError_t e, const char* w) {
     if (e != hipSuccess && herr == hipSuccess) { herr = e; where = w; }
@@ -232,6 +253,7 @@ struct Runner {
     // leaves in `stored_act` whether the kernel that took the layer did so (else y is stored and the reader keeps its PReLU).
     bool out_act = false;
     float out_alpha = 1.f;
+    bool no_mask = false;  // ragged batch: the caller fills the tail itself (GRU input projections)
   };
   bool stored_act = false;
   bool unsupported = false;
@@ -312,6 +334,7 @@ struct Runner {
     }
     if (a.prof) h->prof.back().cfg = cfg;
     h->last_cfg = cfg;
+    if (!e.no_mask) mask(out);
     if (h->trace)
       std::fprintf(stderr, "OU_TRACE conv %-64s cfg=%d M=%d Nq=%d K=%d(Cin=%d KW=%d CK=%d) stride=%d up=%d B=%d MFLOP=%.1f\n",
                    name.c_str(), cfg, L.M, Nq, L.Cin * L.KW, L.Cin, L.KW, L.CK, L.stride, L.up, B,
@@ -328,6 +351,8 @@ struct Runner {
   int plan_chain(const BlockL& Bk, int T) {
     h->fuse_mode = env.fuse; h->fuse_nc = env.fuse_nc;
     if (h->fuse_mode == 0) return 0;
+    // ragged batch: the fused body keeps conv1 / conv2 tiles in LDS, where nothing zeroes them behind a row's own end
+    if (ragged) return 0;
     // Throughput regime: with >= ~2 wave tiles per SIMD the three convs run unfused on conv_direct3_kernel at 70-100 TFLOP/s
     // each, ahead of the fused body's ~75 (measured end to end: PP16 B = 4 19.2 -> 18.4 ms, OR16 B = 16 57.7 -> 55.5 ms, B = 8
     // even); below that the fused launch wins (B = 1: 24 us for all three convs).
@@ -409,6 +434,7 @@ struct Runner {
             if (ok())
               chk(launch_fir(u.p, W(Bk.rc.fir_off), Bk.rc.fir_len, 0.f, 0, W(Bk.rc.fbias_off), res, kInvSqrt2, hu.p, B,
                              u.C, u.T, st), "fir(up)");
+            mask(hu);
           }
         }
       } else {
@@ -482,7 +508,7 @@ struct Runner {
       // OFF by default (OU_BLOCK3=1): 41.7 / 42.3 us per fused launch (C = 512 / 256) against 44.3 / 44.1 us for the three
       // launches with their gaps, and the enhance as a whole 0.1 ms SLOWER with it.
       bool fused = false;
-      if (!dry && ok() && env.block3 != 0 && B == 1 && st == main_st && block3_bar && !h->profile && !h->tstamps &&
+      if (!dry && ok() && env.block3 != 0 && B == 1 && !ragged && st == main_st && block3_bar && !h->profile && !h->tstamps &&
           h->force_cfg < 0 && env.conv_direct >= 2) {
         std::vector<ConvArgs> cv;
         collect = &cv;
@@ -538,6 +564,7 @@ struct Runner {
         if (!dry && ok())
           chk(launch_fir(v.p, W(Bk.rc.fir_off), Bk.rc.fir_len, h->alphas[Bk.rc.a_off], 1, nullptr, nullptr, 1.f, xf.p, B,
                          v.C, v.T, st), "fir(down)");
+        // (ragged batch: no mask needed -- the k = s = r conv that reads xf has no halo, and its own output is masked)
         Epi e;
         e.act = false;  // PReLU applied by the FIR pass
         o.h_next = conv(Bk.rc, xf, nm + ".h", e);
@@ -553,9 +580,14 @@ struct Runner {
              unsigned* epoch, const float* res, float res_scale) {
     Epi e;
     e.act = false;
+    e.no_mask = true;
     Tensor gx = conv(G.proj, in, nm + ".gx", e);
     Tensor out = alloc(nm, 2 * G.H, in.T);
     if (dry || !ok()) return out;
+    if (ragged) {  // frames behind a row's own end hold the state (z = 1): see launch_gru_tail_fill
+      const int* ln = lens_of(in.T);
+      if (ln) chk(launch_gru_tail_fill(gx.p, ln, B, G.H, in.T, st), "gru tail fill");
+    }
     GruArgs a;
     a.gx = gx.p; a.whh = W(G.whh_off); a.bhn = W(G.bhn_off); a.out = out.p; a.res = res; a.res_scale = res_scale;
     a.xchg = xchg; a.err = errw; a.epoch = epoch; a.B = B; a.T = in.T; a.H = G.H;
@@ -593,6 +625,7 @@ struct Runner {
       if (pre_gru) chk(hipEventRecord(pre_gru, st), "pre-gru record");
     }
     chk(launch_gru(a, h->num_cu, st), G.name.c_str());
+    mask(out);
     return out;
   }
 };
@@ -602,6 +635,8 @@ struct Persist {
   unsigned* status;
   StepCoef* coef;             // [kMaxSteps] or [B]
   float* stats;               // [B][4]
+  RowInfo* rows;              // [B]   ragged batch: per-row geometry
+  int* lens;                  // [kMaxLenLevels][B]   ... and lengths on every level
   unsigned long long* xchg;   // GRU granules (conditioner)
   unsigned long long* xchg2;  // GRU granules (score net; may run concurrently with the conditioner)
   float* mel_scale;           // [B]
@@ -623,6 +658,8 @@ Persist layout_persist(Runner& r, int T) {
   int ncoef = kMaxSteps > r.B ? kMaxSteps : r.B;
   P.coef = (StepCoef*)r.alloc_raw((size_t)ncoef * 8);
   P.stats = r.alloc_raw((size_t)r.B * 4);
+  P.rows = (RowInfo*)r.alloc_raw((size_t)r.B * 4);
+  P.lens = (int*)r.alloc_raw((size_t)r.B * kMaxLenLevels);
   P.xchg = (unsigned long long*)r.alloc_raw(gru_granules(r.B, m.OC / 2) * 2);
   P.xchg2 = (unsigned long long*)r.alloc_raw(gru_granules(r.B, m.OC / 2) * 2);
   P.mel_scale = r.alloc_raw(r.B);
@@ -660,7 +697,8 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
   if (!r.dry && r.ok()) {
     r.chk(launch_mel(mix_norm, r.W(m.mel.win_off), r.W(m.mel.tw_off), r.W(m.mel.fb_off), mel.p, esum, r.B, T,
                      m.mel.n_fft, m.mel.hop, m.mel.pad_left, m.mel.n_freq, m.mel.n_mels, L, r.st), "mel");
-    r.chk(launch_mel_scale(esum, P.mel_scale, r.B, L, r.st), "mel_scale");
+    r.chk(launch_mel_scale(esum, P.mel_scale, r.B, L, r.st, r.lens_of(L)), "mel_scale");
+    r.mask(mel);  // (frames behind a row's end still see its last samples)
   }
   Runner::Epi em;
   em.in_scale = P.mel_scale;  // the global mel normalisation is linear: folded into the conv's input scale
@@ -672,6 +710,7 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
   Tensor e0 = r.alloc("cond.in", m.C0, T);
   if (!r.dry && r.ok())
     r.chk(launch_in_conv(mix_norm, r.W(m.c_in.w_off), r.W(m.c_in.b_off), nullptr, 0, e0.p, r.B, m.C0, T, m.c_in.KW, r.st), "cond.in");
+  r.mask(e0);
   Tensor hcur = e0;
   std::vector<Tensor> outs;
   for (int i = 0; i < m.n_blocks; i++) {
@@ -741,6 +780,7 @@ ScoreEnc run_score_enc(Runner& r, Persist& P, const float* x, const StepCoef* co
   if (!r.dry && r.ok())
     r.chk(launch_in_conv(x, r.W(m.s_in.w_off), r.W(m.s_in.b_off), coef, coef_bs, e0.p, r.B, m.C0, T, m.s_in.KW, r.st),
           "score.in");
+  r.mask(e0);
   Tensor hcur = e0;
   for (int i = 0; i < m.n_blocks; i++) {
     const float* fr = film_row ? film_row + m.film.enc_off[i] : nullptr;
@@ -769,6 +809,7 @@ void run_score_dec(Runner& r, Persist& P, const ScoreEnc& E, const float* x, con
   if (!r.dry && r.ok())
     r.chk(launch_out_conv(y.p, r.W(m.s_out.w_off), r.W(m.s_out.b_off), r.W(m.s_out.a_off), x, noise, out, coef,
                           coef_bs, m.cfg.has_edm, mode, r.B, m.C0, T, m.s_out.KW, r.st), "score.out");
+  r.mask(out, 1, T);
 }
 static bool m_blocks_ok(const Runner& r) { return r.h->m.n_blocks >= 1 && r.h->m.s_dec[0].dir == 0; }
 void run_score(Runner& r, Persist& P, const float* x, const float* noise, float* out, int mode,
@@ -1068,10 +1109,25 @@ int ou_aux_to_wav(ou_handle* h, float* wav_out, int32_t B, int32_t T, void* ws, 
   return finish(h, r);
 }
 
-int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, int32_t B, int32_t T_raw, int32_t n_steps,
-               double epsilon, const float* sigma_host, int32_t warm_start, uint32_t flags, void* ws, size_t ws_bytes,
-               ou_stream_t stream) {
+}  // extern "C"
+
+namespace {
+// ou_enhance / ou_enhance_var.  `t_raw`: host array of B row lengths (max = T_raw) or null (every row T_raw samples long).
+int enhance_impl(ou_handle* h, const float* mix, float* out, const float* noise, int32_t B, int32_t T_raw,
+                 const int32_t* t_raw, int32_t n_steps, double epsilon, const float* sigma_host, int32_t warm_start,
+                 uint32_t flags, void* ws, size_t ws_bytes, ou_stream_t stream) {
   if (!h || !mix || !out || !ws || B < 1 || T_raw < 1) return fail(h, OU_EINVAL, "bad argument");
+  if (t_raw) {
+    int mx = 0;
+    bool all_whole = true;
+    for (int b = 0; b < B; b++) {
+      if (t_raw[b] < 1 || t_raw[b] > T_raw) return fail(h, OU_EINVAL, "ou_enhance_var: 1 <= t_raw[b] <= T_raw_max");
+      mx = t_raw[b] > mx ? t_raw[b] : mx;
+      all_whole = all_whole && t_raw[b] == T_raw;
+    }
+    if (mx != T_raw) return fail(h, OU_EINVAL, "ou_enhance_var: T_raw_max must be the length of the longest row");
+    if (all_whole) t_raw = nullptr;  // nothing ragged about this batch: the plain path (and its fused kernels)
+  }
   const bool use_aux = (flags & OU_ENH_USE_AUX_SIGNAL) != 0;
   const bool saved_overlap = h->overlap;
   struct OverlapGuard { ou_handle* h; bool v; ~OverlapGuard() { h->overlap = v; } } overlap_guard{h, saved_overlap};
@@ -1107,8 +1163,32 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
     rows.push_back(make_coef(m.cfg, sigma[n], n == n_steps - 1, eta, beta, n + 1 < n_steps ? sigma[n + 1] : 0.f));
   upload_coefs(r, P.coef, rows);
 
+  if (t_raw) {
+    // per-row geometry and the rows' lengths on every level of the network: T, 2 T (the decoupling layer's up-sampled grid)
+    // and T / (r_0 .. r_i).  By value through kernel arguments: capturable, no host memory involved.
+    LevelSpec& lv = r.lv;
+    lv.n = 0;
+    auto add_level = [&](int num, int den) {
+      lv.num[lv.n] = num; lv.den[lv.n] = den; r.level_T[lv.n] = (int)((long long)T * num / den); lv.n++;
+    };
+    add_level(1, 1);
+    add_level(2, 1);
+    int cum = 1;
+    for (int i = 0; i < m.cfg.score.n_rates && lv.n < kMaxLenLevels; i++) { cum *= m.cfg.score.rate_factors[i]; add_level(1, cum); }
+    if (cum != tot) return fail(h, OU_EINVAL, "internal: rate factors do not multiply to the total down-sampling factor");
+    for (int off = 0; off < B; off += 64) {
+      RowBlock blk;
+      const int n = B - off < 64 ? B - off : 64;
+      for (int i = 0; i < 64; i++) blk.t_raw[i] = i < n ? t_raw[off + i] : 1;
+      r.chk(launch_upload_rows(P.rows, P.lens, blk, n, off, B, tot, lv, st), "upload rows");
+    }
+    r.ragged = true;
+    r.lens_dev = P.lens;
+    r.rows_dev = P.rows;
+  }
   const float level = (float)std::pow(10.0, (double)m.cfg.level_db / 20.0);
-  r.chk(launch_pad_normalize(mix, P.mixn.p, P.stats, B, T_raw, T, pad_left, level, st), "normalize");
+  if (r.ragged) r.chk(launch_pad_normalize_var(mix, P.mixn.p, P.stats, P.rows, B, T_raw, T, level, st), "normalize");
+  else r.chk(launch_pad_normalize(mix, P.mixn.p, P.stats, B, T_raw, T, pad_left, level, st), "normalize");
   const size_t nBT = (size_t)B * T;
   const int keep_rms = (flags & OU_ENH_KEEP_RMS) ? 1 : 0;
   const int peak = (flags & OU_ENH_NO_PEAK_GUARD) ? 0 : 1;
@@ -1145,6 +1225,7 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
     if (warm_start < 0 && h->overlap && gru_fit) {
       r.gru_shared = true;
       r.chk(launch_init_x(noise, nullptr, sigma[n_start], P.x.p, nBT, st), "init x");  // universe.py:325-327
+      r.mask(P.x);
       const size_t save = r.off;
       r.fork(st, 2);
       r.st = h->aux[2];
@@ -1159,22 +1240,30 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
   run_condition(r, P, P.mixn.p, T);
   r.gru_shared = false;
   if (!r.dry && r.ok() && r.off != mark) return fail(h, OU_EINVAL, "internal: workspace layout mismatch");
-  h->cond_B = B;
+  h->cond_B = r.ragged ? 0 : B;  // (the operator seams ou_score / ou_aux_to_wav take whole batches only)
   h->cond_T = T;
 
   if (need_wav) {
     float* tmp = r.alloc_raw((size_t)B * m.C0 * 2 * T);
     if (r.ok())
       r.chk(launch_decoupling(P.aux.p, r.W(m.dec.alpha_off), r.W(m.dec.up_off), r.W(m.dec.down_off),
-                              r.W(m.dec.conv.w_off), r.W(m.dec.conv.b_off), tmp, P.wav.p, B, m.C0, T, st), "decoupling");
+                              r.W(m.dec.conv.w_off), r.W(m.dec.conv.b_off), tmp, P.wav.p, B, m.C0, T, st, r.lens_of(T),
+                              r.lens_of(2 * T)), "decoupling");
   }
+  auto post = [&](const float* x) {
+    if (!r.ok()) return;
+    if (r.ragged) r.chk(launch_post_var(x, P.stats, out, P.rows, B, T_raw, T, keep_rms, peak, st), "post");
+    else r.chk(launch_post(x, P.stats, out, B, T_raw, T, pad_left, keep_rms, peak, st), "post");
+  };
   if (use_aux) {
-    if (r.ok()) r.chk(launch_post(P.wav.p, P.stats, out, B, T_raw, T, pad_left, keep_rms, peak, st), "post");
+    post(P.wav.p);
     return finish(h, r);
   }
   // universe.py:325-331
-  if (!have_e0)
+  if (!have_e0) {
     r.chk(launch_init_x(noise, warm_start >= 0 ? P.wav.p : nullptr, sigma[n_start], P.x.p, nBT, st), "init x");
+    r.mask(P.x);
+  }
   const size_t step_mark = r.off;
   for (int n = n_start; n < n_steps; n++) {
     const bool last = n == n_steps - 1;
@@ -1191,8 +1280,26 @@ int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, i
     }
     if (!r.ok()) break;
   }
-  if (r.ok()) r.chk(launch_post(P.x.p, P.stats, out, B, T_raw, T, pad_left, keep_rms, peak, st), "post");
+  post(P.x.p);
   return finish(h, r);
+}
+}  // namespace
+
+extern "C" {
+
+int ou_enhance(ou_handle* h, const float* mix, float* out, const float* noise, int32_t B, int32_t T_raw, int32_t n_steps,
+               double epsilon, const float* sigma_host, int32_t warm_start, uint32_t flags, void* ws, size_t ws_bytes,
+               ou_stream_t stream) {
+  return enhance_impl(h, mix, out, noise, B, T_raw, nullptr, n_steps, epsilon, sigma_host, warm_start, flags, ws, ws_bytes,
+                      stream);
+}
+
+int ou_enhance_var(ou_handle* h, const float* mix, float* out, const float* noise, int32_t B, int32_t T_raw_max,
+                   const int32_t* t_raw, int32_t n_steps, double epsilon, const float* sigma_host, int32_t warm_start,
+                   uint32_t flags, void* ws, size_t ws_bytes, ou_stream_t stream) {
+  if (!t_raw) return fail(h, OU_EINVAL, "ou_enhance_var: t_raw must be given (ou_enhance takes batches of equal lengths)");
+  return enhance_impl(h, mix, out, noise, B, T_raw_max, t_raw, n_steps, epsilon, sigma_host, warm_start, flags, ws, ws_bytes,
+                      stream);
 }
 
 int ou_transform_frames(int32_t T, int32_t n_fft, int32_t hop) {

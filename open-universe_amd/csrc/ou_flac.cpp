@@ -239,6 +239,9 @@ int decode(const uint8_t* d, size_t n, const Info& I, int32_t* out, int64_t cap,
     int bps = kBits[ssc];
     if (bps < 0) return flac_fail("FLAC: reserved sample-size code");
     if (bps == 0) bps = I.bps;
+    // (a frame may name its own sample size; the caller scales by the stream-level one, so a frame that disagrees with
+    //  STREAMINFO would come out at the wrong level: refused -- RFC 9639 streams keep one size throughout)
+    if (bps != I.bps) return flac_fail("FLAC: frame sample size differs from STREAMINFO");
     const size_t hdr_bytes = b.pos >> 3;
     const uint8_t c8 = (uint8_t)b.get(8);
     if (b.bad) return flac_fail("FLAC: truncated frame header");

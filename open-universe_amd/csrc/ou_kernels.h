@@ -115,6 +115,33 @@ hipError_t launch_film(const float* g, const float* W, const float* b, float* fi
 struct CoefBlock { StepCoef c[64]; };
 hipError_t launch_upload_coef(StepCoef* dst, const CoefBlock& blk, int n, hipStream_t st);
 
+// ---- batches whose rows have lengths of their own ("ragged": ou_enhance_var) --------------------------------------------
+// Row b of the batch is the utterance it would be in a call of its own: its own pad() split (universe.py:219-223), its own
+// statistics, and 'same' zero padding right behind ITS last sample on every level.  The invariant that carries this through
+// the network: every activation tensor is ZERO from the row's own length on (len_l[b] = t_pad[b] * T_l / T on the level of
+// length T_l), so that a halo read past a row's end sees what the reference's conv padding would supply.  Kernels that take a
+// `lens` pointer keep the invariant themselves (null = all rows have the tensor's length); after the others the runner
+// launches launch_mask_tail.
+struct RowInfo { int t_raw, pad_left, t_pad, _r; };
+constexpr int kMaxLenLevels = 8;
+struct LevelSpec { int n = 0; int num[kMaxLenLevels]; int den[kMaxLenLevels]; };  // len_l[b] = t_pad[b] * num / den
+struct RowBlock { int t_raw[64]; };
+// rows[off .. off + n) <- {t_raw, pad_left, t_pad} (universe.py:219-223) ; lens[l * B + off + i] <- t_pad * num_l / den_l
+hipError_t launch_upload_rows(RowInfo* rows, int* lens, const RowBlock& blk, int n, int off, int B, int tot_ds,
+                              const LevelSpec& lv, hipStream_t st);
+// y[b][c][t] = 0 for t >= lens[b]   (y: (B, C, T))
+hipError_t launch_mask_tail(float* y, const int* lens, int B, int C, int T, hipStream_t st);
+// GRU input projections gx (B, 6H, T) of a ragged batch, t >= lens[b]: 0 in the r / n rows and +1e4 in the z rows of both
+// directions -- z = sigmoid(1e4 + ..) is exactly 1, so h' = (h - n) z + n holds the state: the backward pass reaches the row's
+// last frame with h = 0 exactly, as the reference's pass over that row alone starts (the forward pass's frames past the end
+// are masked afterwards).  The recurrence kernels need no per-row length.
+hipError_t launch_gru_tail_fill(float* gx, const int* lens, int B, int H, int T, hipStream_t st);
+// pad + normalize / unpad + post with per-row geometry (rows: RowInfo[B]); mix and out are (B, T_raw_max), y / x (B, T_pad_max)
+hipError_t launch_pad_normalize_var(const float* mix, float* y, float* stats, const RowInfo* rows, int B, int T_raw_max,
+                                    int T_pad_max, float level, hipStream_t st);
+hipError_t launch_post_var(const float* x, const float* stats, float* out, const RowInfo* rows, int B, int T_raw_max,
+                           int T_pad_max, int keep_rms, int peak_guard, hipStream_t st);
+
 // pad (universe.py:219-223) + normalize_batch (utils/norm.py:47-87).  stats[b] = {mean, gain, mix_rms, 0}
 hipError_t launch_pad_normalize(const float* mix, float* y, float* stats, int B, int T_raw, int T_pad, int pad_left,
                                 float level, hipStream_t st);
@@ -140,7 +167,8 @@ hipError_t launch_stft_inverse(const float* spec, const float* win, float* frame
 // mel front-end (condition.py:92-108): power STFT -> mel fb ; esum[b][frame] = sum_mel mel^2
 hipError_t launch_mel(const float* x, const float* win, const float* tw, const float* fb, float* mel, float* esum,
                       int B, int T, int n_fft, int hop, int pad_left, int n_freq, int n_mels, int L, hipStream_t st);
-hipError_t launch_mel_scale(const float* esum, float* scale, int B, int L, hipStream_t st);
+// (`lens`: frames per row of a ragged batch or null -- the mean runs over the row's own frames)
+hipError_t launch_mel_scale(const float* esum, float* scale, int B, int L, hipStream_t st, const int* lens = nullptr);
 
 // space-to-depth + PReLU for the conditioner's strided "st" convs: y[b][ci*R + k][q] = prelu(x[b][ci][q*R + k])
 hipError_t launch_s2d(const float* x, const float* alpha, float* y, int B, int C, int T, int R, hipStream_t st);
@@ -224,8 +252,9 @@ int gru_ring_batch_cap(int H, int num_cu, int share, int force_upw, int B, int l
 inline size_t gru_granules(int B, int H) { return (size_t)2 * B * (2 * H + 64); }
 
 // Alias-free Snake + Conv1d(C -> 1, k3)  (universe_gan.py:117-126,145-149)
+// (`lens` / `lens2`: per-row lengths of a ragged batch on the T and 2T grids, or null)
 hipError_t launch_decoupling(const float* aux, const float* alpha_exp, const float* up_k, const float* down_k,
                              const float* w, const float* bias, float* tmp_up, float* out, int B, int C, int T,
-                             hipStream_t st);
+                             hipStream_t st, const int* lens = nullptr, const int* lens2 = nullptr);
 
 }  // namespace ou

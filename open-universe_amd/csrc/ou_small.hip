@@ -709,16 +709,18 @@ hipError_t launch_mel(const float* x, const float* win, const float* tw, const f
   return hipGetLastError();
 }
 // condition.py:105-106: scale = 1 / max(sqrt(mean_frames(sum_mel mel^2)), 1e-5)
-__global__ __launch_bounds__(256) void mel_scale_kernel(const float* __restrict__ esum, float* scale, int L) {
+__global__ __launch_bounds__(256) void mel_scale_kernel(const float* __restrict__ esum, float* scale, int L,
+                                                        const int* __restrict__ lens) {
   __shared__ double shd[4];
   const int b = blockIdx.x;
+  const int Lb = lens ? lens[b] : L;  // ragged batch: the row's own frames (same elements per thread, same order as alone)
   double s = 0;
-  for (int f = threadIdx.x; f < L; f += 256) s += esum[(size_t)b * L + f];
+  for (int f = threadIdx.x; f < Lb; f += 256) s += esum[(size_t)b * L + f];
   s = block_sum(s, shd);
-  if (threadIdx.x == 0) scale[b] = 1.0f / fmaxf((float)sqrt(s / L), 1e-5f);
+  if (threadIdx.x == 0) scale[b] = 1.0f / fmaxf((float)sqrt(s / Lb), 1e-5f);
 }
-hipError_t launch_mel_scale(const float* esum, float* scale, int B, int L, hipStream_t st) {
-  hipLaunchKernelGGL(mel_scale_kernel, dim3(B), dim3(256), 0, st, esum, scale, L);
+hipError_t launch_mel_scale(const float* esum, float* scale, int B, int L, hipStream_t st, const int* lens) {
+  hipLaunchKernelGGL(mel_scale_kernel, dim3(B), dim3(256), 0, st, esum, scale, L, lens);
   return hipGetLastError();
 }
 
@@ -902,10 +904,11 @@ hipError_t launch_sum(const float* a, const float* b, const float* c, const floa
 // =========================================================================================================
 __global__ __launch_bounds__(256) void snake_up_kernel(const float* __restrict__ aux, const float* __restrict__ alpha_exp,
                                                        const float* __restrict__ up_k, float* __restrict__ u, int C,
-                                                       int T) {
+                                                       int T, const int* __restrict__ lens2) {
   const int c = blockIdx.y, b = blockIdx.z;
   const int i = blockIdx.x * 256 + threadIdx.x;  // index in the 2T up-sampled signal
   if (i >= 2 * T) return;
+  if (lens2 && i >= lens2[b]) { u[((size_t)b * C + c) * 2 * T + i] = 0.f; return; }  // ragged batch: past the row's end
   const float* xr = aux + ((size_t)b * C + c) * T;
   const int q = i >> 1, ph = i & 1;
   float acc = 0.f;
@@ -921,13 +924,17 @@ __global__ __launch_bounds__(256) void snake_up_kernel(const float* __restrict__
 }
 __global__ __launch_bounds__(256) void snake_down_conv_kernel(const float* __restrict__ u, const float* __restrict__ down_k,
                                                               const float* __restrict__ w, const float* __restrict__ bias,
-                                                              float* __restrict__ out, int C, int T) {
+                                                              float* __restrict__ out, int C, int Tfull,
+                                                              const int* __restrict__ lens) {
   const int b = blockIdx.y;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= T) return;
+  if (t >= Tfull) return;
+  // ragged batch: the k3 conv's zero padding begins right behind the ROW's last sample
+  const int T = lens ? lens[b] : Tfull;
+  if (t >= T) { out[(size_t)b * Tfull + t] = 0.f; return; }
   float acc = 0.f;
   for (int c = 0; c < C; c++) {
-    const float* ur = u + ((size_t)b * C + c) * 2 * T;
+    const float* ur = u + ((size_t)b * C + c) * 2 * Tfull;
 #pragma unroll
     for (int k3 = 0; k3 < 3; k3++) {
       int tt = t + k3 - 1;
@@ -942,15 +949,136 @@ __global__ __launch_bounds__(256) void snake_down_conv_kernel(const float* __res
       acc = fmaf(w[c * 3 + k3], d, acc);
     }
   }
-  out[(size_t)b * T + t] = acc + bias[0];
+  out[(size_t)b * Tfull + t] = acc + bias[0];
 }
 hipError_t launch_decoupling(const float* aux, const float* alpha_exp, const float* up_k, const float* down_k,
                              const float* w, const float* bias, float* tmp_up, float* out, int B, int C, int T,
-                             hipStream_t st) {
-  hipLaunchKernelGGL(snake_up_kernel, dim3((2 * T + 255) / 256, C, B), dim3(256), 0, st, aux, alpha_exp, up_k, tmp_up, C, T);
+                             hipStream_t st, const int* lens, const int* lens2) {
+  hipLaunchKernelGGL(snake_up_kernel, dim3((2 * T + 255) / 256, C, B), dim3(256), 0, st, aux, alpha_exp, up_k, tmp_up, C, T,
+                     lens2);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(snake_down_conv_kernel, dim3((T + 255) / 256, B), dim3(256), 0, st, tmp_up, down_k, w, bias, out, C, T);
+  hipLaunchKernelGGL(snake_down_conv_kernel, dim3((T + 255) / 256, B), dim3(256), 0, st, tmp_up, down_k, w, bias, out, C, T,
+                     lens);
+  return hipGetLastError();
+}
+
+// =========================================================================================================
+// ragged batches (ou_enhance_var): per-row geometry, tail masks, per-row pad / normalise / post
+// =========================================================================================================
+__global__ void upload_rows_kernel(RowInfo* rows, int* lens, RowBlock blk, int n, int off, int B, int tot_ds, LevelSpec lv) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  const int t_raw = blk.t_raw[i];
+  const int pad = tot_ds - t_raw % tot_ds;  // universe.py:219-223 (a full block when already a multiple)
+  RowInfo r;
+  r.t_raw = t_raw; r.pad_left = pad / 2; r.t_pad = t_raw + pad; r._r = 0;
+  rows[off + i] = r;
+  for (int l = 0; l < lv.n; l++) lens[l * B + off + i] = (int)((long long)r.t_pad * lv.num[l] / lv.den[l]);
+}
+hipError_t launch_upload_rows(RowInfo* rows, int* lens, const RowBlock& blk, int n, int off, int B, int tot_ds,
+                              const LevelSpec& lv, hipStream_t st) {
+  hipLaunchKernelGGL(upload_rows_kernel, dim3(1), dim3(64), 0, st, rows, lens, blk, n, off, B, tot_ds, lv);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void mask_tail_kernel(float* __restrict__ y, const int* __restrict__ lens, int C, int T) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  float* yr = y + ((size_t)b * C + c) * T;
+  for (int t = lens[b] + threadIdx.x; t < T; t += 256) yr[t] = 0.f;
+}
+hipError_t launch_mask_tail(float* y, const int* lens, int B, int C, int T, hipStream_t st) {
+  hipLaunchKernelGGL(mask_tail_kernel, dim3(C, B), dim3(256), 0, st, y, lens, C, T);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gru_tail_fill_kernel(float* __restrict__ gx, const int* __restrict__ lens, int H, int T) {
+  const int row = blockIdx.x, b = blockIdx.y;  // row = dir * 3H + gate * H + unit
+  const float v = (row / H) % 3 == 1 ? 1e4f : 0.f;
+  float* yr = gx + ((size_t)b * 6 * H + row) * T;
+  for (int t = lens[b] + threadIdx.x; t < T; t += 256) yr[t] = v;
+}
+hipError_t launch_gru_tail_fill(float* gx, const int* lens, int B, int H, int T, hipStream_t st) {
+  hipLaunchKernelGGL(gru_tail_fill_kernel, dim3(6 * H, B), dim3(256), 0, st, gx, lens, H, T);
+  return hipGetLastError();
+}
+
+// pad_normalize_kernel's general loops with the row's own (T_raw, pad_left, T_pad): same elements per thread and the same
+// order of the double sums as the call on that row alone; the row is ZERO (not the padding value) from its own T_pad on
+__global__ __launch_bounds__(1024) void pad_normalize_var_kernel(const float* __restrict__ mix, float* __restrict__ y,
+                                                                 float* __restrict__ stats, const RowInfo* __restrict__ rows,
+                                                                 int T_raw_max, int T_pad_max, float level) {
+  __shared__ double shd[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const RowInfo ri = rows[b];
+  const int T_raw = ri.t_raw, T_pad = ri.t_pad, pad_left = ri.pad_left;
+  const float* xb = mix + (size_t)b * T_raw_max;
+  float* yb = y + (size_t)b * T_pad_max;
+  double s = 0, sq = 0;
+  for (int t = tid; t < T_raw; t += 1024) { const double d = xb[t]; s += d; sq += d * d; }
+  s = block_sum(s, shd);
+  sq = block_sum(sq, shd);
+  const float mean = (float)(s / T_pad);  // norm.py:62  (mean over the padded signal)
+  double ss = 0;
+  for (int t = tid; t < T_raw; t += 1024) { const double d = (double)(xb[t] - mean); ss += d * d; }
+  ss = block_sum(ss, shd);
+  ss += (double)(T_pad - T_raw) * (double)(0.f - mean) * (double)(0.f - mean);
+  float sd = (float)sqrt(ss / (double)(T_pad - 1));  // unbiased std, norm.py:22-23
+  sd = fmaxf(sd, 1e-5f);
+  const float gain = level / sd;
+  for (int t = tid; t < T_pad_max; t += 1024) {
+    const int tr = t - pad_left;
+    const float v = (tr >= 0 && tr < T_raw) ? xb[tr] : 0.f;
+    yb[t] = t < T_pad ? (v - mean) * gain : 0.f;
+  }
+  if (tid == 0) {
+    stats[b * 4 + 0] = mean;
+    stats[b * 4 + 1] = gain;
+    stats[b * 4 + 2] = (float)sqrt(sq / T_raw);  // mix_rms, universe.py:259
+    stats[b * 4 + 3] = 0.f;
+  }
+}
+hipError_t launch_pad_normalize_var(const float* mix, float* y, float* stats, const RowInfo* rows, int B, int T_raw_max,
+                                    int T_pad_max, float level, hipStream_t st) {
+  hipLaunchKernelGGL(pad_normalize_var_kernel, dim3(B), dim3(1024), 0, st, mix, y, stats, rows, T_raw_max, T_pad_max, level);
+  return hipGetLastError();
+}
+// post_kernel with the row's own geometry; out (B, T_raw_max), 0 behind the row's own T_raw
+__global__ __launch_bounds__(1024) void post_var_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                        float* __restrict__ out, const RowInfo* __restrict__ rows,
+                                                        int T_raw_max, int T_pad_max, int keep_rms, int peak_guard) {
+  __shared__ double shd[16];
+  __shared__ float shf[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const RowInfo ri = rows[b];
+  const int T_raw = ri.t_raw;
+  const float* xb = x + (size_t)b * T_pad_max + ri.pad_left;
+  float g = 1.f;
+  if (keep_rms) {  // universe.py:352-354
+    double sq = 0;
+    for (int t = tid; t < T_raw; t += 1024) {
+      double v = xb[t];
+      sq += v * v;
+    }
+    sq = block_sum(sq, shd);
+    float x_rms = fmaxf((float)sqrt(sq / T_raw), 1e-5f);
+    g = stats[b * 4 + 2] / x_rms;
+  }
+  float mx = 0.f;
+  for (int t = tid; t < T_raw; t += 1024) mx = fmaxf(mx, fabsf(xb[t] * g));
+  mx = block_max(mx, shf);
+  const bool div = peak_guard && mx > 1.0f;  // universe.py:356-357
+  for (int t = tid; t < T_raw_max; t += 1024) {
+    float v = t < T_raw ? xb[t] : 0.f;
+    if (keep_rms) v = v * g;
+    if (div) v = v / mx;
+    out[(size_t)b * T_raw_max + t] = v;
+  }
+}
+hipError_t launch_post_var(const float* x, const float* stats, float* out, const RowInfo* rows, int B, int T_raw_max,
+                           int T_pad_max, int keep_rms, int peak_guard, hipStream_t st) {
+  hipLaunchKernelGGL(post_var_kernel, dim3(B), dim3(1024), 0, st, x, stats, out, rows, T_raw_max, T_pad_max, keep_rms,
+                     peak_guard);
   return hipGetLastError();
 }
 

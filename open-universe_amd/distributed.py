@@ -186,19 +186,21 @@ def utterance_generator(device, seed, index):
     return g
 
 
-def plan_batches(lengths, indices, batch_size, pad_batch=False):
+def plan_batches(lengths, indices, batch_size, pad_batch=False, equal_only=False):
     """Group the utterances `indices` (of raw lengths `lengths[i]`) into `enhance` calls of at most `batch_size` rows.
 
-    pad_batch=False: only utterances of EQUAL raw length share a call (same pad, same normalisation window: every row
-    is exactly the utterance it would be alone).  pad_batch=True: the reference's batch semantics for ragged sets
-    (`max_collator`, datasets/datamodule.py:24-42) -- neighbours in length order share a call and are right-zero-padded
-    to the longest of them; the reference has no mask, so the padding is seen by the normalisation, the mel norm and
-    the GRU, and a row is NOT the utterance it would be alone.
-    Deterministic: a pure function of (lengths, indices, batch_size, pad_batch)."""
+    Neighbours in length order share a call (longest first: the padding a batch wastes is the difference to its longest
+    member).  pad_batch=False (default): EXACT batching -- every row keeps its own geometry (`Universe.enhance_many`,
+    ou_enhance_var) and is the utterance it would be alone, whatever it shares the call with.  pad_batch=True: the
+    reference's batch semantics for ragged sets (`max_collator`, datasets/datamodule.py:24-42): right-zero-padded to the
+    longest of the call without a mask, so the padding is seen by the normalisation, the mel norm and the GRU (SURVEY.md
+    8(d), C5), and a row is NOT the utterance it would be alone.  equal_only=True: only utterances of EQUAL raw length
+    share a call (the rule before exact batching existed; a call then never carries per-row lengths).
+    Deterministic: a pure function of the arguments."""
     batch_size = max(1, int(batch_size))
     order = sorted(indices, key=lambda i: (-int(lengths[i]), i))
     groups = []
-    if pad_batch:
+    if pad_batch or not equal_only:
         for k in range(0, len(order), batch_size):
             groups.append(order[k:k + batch_size])
         return groups
@@ -214,7 +216,7 @@ def plan_batches(lengths, indices, batch_size, pad_batch=False):
 
 
 def enhance_sharded(model, signals, seed=1028282, gather=True, batch_size=1, pad_batch=False, in_flight=1,
-                    **enhance_kwargs):
+                    equal_only=False, **enhance_kwargs):
     """Enhance a list of 1-D signals (any lengths) across the ranks of the current process group.
 
     Rank r takes its LPT shard (`shard_utterances`) and walks it in `plan_batches` groups: up to `batch_size`
@@ -223,12 +225,14 @@ def enhance_sharded(model, signals, seed=1028282, gather=True, batch_size=1, pad
     would use, so with pad_batch=False the result of an utterance does not depend on the sharding or the grouping
     beyond fp32 summation order (the conv tilings are chosen from the total column count of a call: batched vs single
     agree to > 100 dB, same grouping = bit-identical; a 1-rank and an N-rank run with batch_size=1 are bit-identical).
+    Utterances of DIFFERENT lengths share a call too (exact batching: every row keeps its own padding, statistics, conv
+    zero padding and GRU length, `Universe.enhance_many`); `equal_only=True` restores the older rule (equal lengths only).
 
     in_flight=K > 1: K calls of the shard are in flight side by side on K streams of this rank's GPU (`lanes.LanePool`:
-    one handle + workspace per lane) -- the mode for RAGGED sets, which cannot be batched without changing their
-    results: every call is exactly the call of the serial loop (same kernels, tilings, summation orders), so the
-    outputs are bit-identical to in_flight=1 while the device overlaps the GRU passes and the small launches of one
-    utterance with the kernels of the others.
+    one handle + workspace per lane): every call is exactly the call of the serial loop (same kernels, tilings, summation
+    orders), so the outputs are bit-identical to in_flight=1 while the device overlaps the GRU passes and the small
+    launches of one utterance with the kernels of the others (batch_size=1: the route for ragged sets before exact
+    batching, 143 -> 238 utt/s; batching reaches the batched kernels' rate instead).
 
     Results are gathered on rank 0 in the original order (None on the other ranks; with gather=False every rank
     returns {index: tensor} of its shard)."""
@@ -238,7 +242,7 @@ def enhance_sharded(model, signals, seed=1028282, gather=True, batch_size=1, pad
     mine = shard_utterances(lengths, world)[rank]
     outs = {}
     batched_ok = not any(enhance_kwargs.get(k) is not None for k in ("target", "ensemble"))
-    groups = plan_batches(lengths, mine, batch_size if batched_ok else 1, pad_batch)
+    groups = plan_batches(lengths, mine, batch_size if batched_ok else 1, pad_batch, equal_only)
 
     def run_group(m, group):
         if len(group) == 1:
@@ -253,8 +257,10 @@ def enhance_sharded(model, signals, seed=1028282, gather=True, batch_size=1, pad
         from .lanes import LanePool
 
         sizes = {len(g) for g in groups}
-        # (groups of different sizes in flight side by side: the lanes must agree on the GRU cluster layout -- the pool's largest)
-        with LanePool(model, min(in_flight, LanePool.MAX_LANES), max_batch=max(sizes) if (len(sizes) > 1 or max(sizes) > 1) else 0) as pool:
+        # (groups of different sizes in flight side by side: the lanes must agree on the GRU cluster layout -- the pool's largest;
+        #  a rank whose shard is EMPTY -- fewer utterances than ranks -- has no group to size the pool by: 0 = every call's own)
+        mb = max(sizes, default=0)
+        with LanePool(model, min(in_flight, LanePool.MAX_LANES), max_batch=mb if (len(sizes) > 1 or mb > 1) else 0) as pool:
             for group in groups:
                 _, res = pool.submit(lambda m, g=group: run_group(m, g))
                 for i, o in zip(group, res):

@@ -449,7 +449,9 @@ class Universe:
 
     @torch.no_grad()
     def _enhance(self, mix, n_steps, epsilon, target, fake_score_snr, rng, use_aux_signal, keep_rms, ensemble,
-                 ensemble_stat, warm_start, noise):
+                 ensemble_stat, warm_start, noise, t_raw=None):
+        """`t_raw`: per-row lengths of a batch whose rows are utterances of different lengths (enhance_many, exact
+        batching -> ou_enhance_var); `mix` is then (B, 1, max length) and `noise` a (n, B, 1, T) tensor."""
         self._poll_deferred_status()
         if epsilon is None:
             epsilon = self.diff_kwargs.epsilon
@@ -486,7 +488,13 @@ class Universe:
             sigma = self.get_std_dev(time).to(torch.float32).contiguous()
             n_start = 0 if warm_start is None else int(warm_start)
             n_noise = 0 if use_aux_signal else n_steps - n_start
-            if noise is None:
+            if t_raw is not None:
+                if ensemble is not None:
+                    raise ValueError("per-row lengths and `ensemble` do not combine (call enhance per input)")
+                noise_t = noise
+                if n_noise and (noise_t is None or tuple(noise_t.shape) != (n_noise, B, 1, T)):
+                    raise ValueError(f"noise must be a tensor of shape {(n_noise, B, 1, T)}")
+            elif noise is None:
                 # draw order of the reference: x0, then z_n for n = n_start .. N-2 (universe.py:326,330,338)
                 draws = [torch.randn((B, 1, T), dtype=torch.float32, device=self.device, generator=rng)
                          for _ in range(n_noise)]
@@ -499,13 +507,24 @@ class Universe:
             ws = self._workspace(B, T)
             flags = (_lib.OU_ENH_KEEP_RMS if keep_rms else 0) | (_lib.OU_ENH_USE_AUX_SIGNAL if use_aux_signal else 0)
             with torch.cuda.device(self.device):
-                _lib.check(self._L.ou_enhance(
-                    self._handle, c_void_p(mix.data_ptr()), c_void_p(out.data_ptr()),
-                    c_void_p(noise_t.data_ptr()) if noise_t is not None else None, B, mix_len, int(n_steps),
-                    float(epsilon), ctypes.cast(sigma.data_ptr(), ctypes.POINTER(c_float)),
-                    -1 if warm_start is None else int(warm_start), flags, c_void_p(ws.data_ptr()),
-                    c_size_t(ws.numel()), self._stream()), self._handle)
-            self._cond_key = (B, T)
+                if t_raw is not None:
+                    if len(t_raw) != B:
+                        raise ValueError("t_raw must have one entry per row of the batch")
+                    rows_len = (c_int32 * B)(*[int(v) for v in t_raw])
+                    _lib.check(self._L.ou_enhance_var(
+                        self._handle, c_void_p(mix.data_ptr()), c_void_p(out.data_ptr()),
+                        c_void_p(noise_t.data_ptr()) if noise_t is not None else None, B, mix_len, rows_len, int(n_steps),
+                        float(epsilon), ctypes.cast(sigma.data_ptr(), ctypes.POINTER(c_float)),
+                        -1 if warm_start is None else int(warm_start), flags, c_void_p(ws.data_ptr()),
+                        c_size_t(ws.numel()), self._stream()), self._handle)
+                else:
+                    _lib.check(self._L.ou_enhance(
+                        self._handle, c_void_p(mix.data_ptr()), c_void_p(out.data_ptr()),
+                        c_void_p(noise_t.data_ptr()) if noise_t is not None else None, B, mix_len, int(n_steps),
+                        float(epsilon), ctypes.cast(sigma.data_ptr(), ctypes.POINTER(c_float)),
+                        -1 if warm_start is None else int(warm_start), flags, c_void_p(ws.data_ptr()),
+                        c_size_t(ws.numel()), self._stream()), self._handle)
+            self._cond_key = (B, T) if t_raw is None else None
             self._status()
             x = out
 
@@ -542,7 +561,10 @@ class Universe:
         The noise of entry i is drawn from its generator entry by entry, step by step, with the shapes a call on that
         entry alone would use ((C_i, 1, T), x0 first) -- with a shared generator the draws come in exactly the order
         of the serial loop, so its state advances as the reference's does.
-        pad_batch=False: all entries must have the same length (every row is the signal it would be alone).
+        pad_batch=False (default): EXACT batching -- entries may have any lengths, and every row is the signal it would be in
+        a call of its own (own pad() split, own normalisation and mel norm, zero padding of every conv right behind its own
+        last sample, GRU passes over its own frames: ou_enhance_var); the noise of entry i has the shape of that call,
+        (C_i, 1, L_i + pad_i).  Agrees with the one-by-one loop to fp32 round-off (the kernels a batch selects differ).
         pad_batch=True: right-zero-padded to the longest entry like `max_collator` (datasets/datamodule.py:24-42);
         the reference has no mask, the padding takes part in the normalisation / mel norm / GRU; outputs are cropped.
         Returns the list of enhanced signals, each with the shape of its input."""
@@ -563,13 +585,35 @@ class Universe:
             dims.append(s.ndim)
             rows.append(self._prep(s if s.ndim == 2 else s[None, :]))
         lens = [int(r.shape[-1]) for r in rows]
+        if min(lens) < 1:
+            raise ValueError("enhance_many: empty input signal")
         l_max = max(lens)
-        if not pad_batch and any(n != l_max for n in lens):
-            raise ValueError("enhance_many: inputs of different lengths need pad_batch=True (reference batch semantics)")
         n_steps = self.diff_kwargs.n_steps if n_steps is None else int(n_steps)
         T = l_max + (self.tot_ds - l_max % self.tot_ds)
         n_start = 0 if warm_start is None else int(warm_start)
         n_noise = 0 if use_aux_signal else n_steps - n_start
+        if not pad_batch and any(n != l_max for n in lens):
+            # exact batching of different lengths: per-row geometry through the whole path
+            B = sum(r.shape[0] for r in rows)
+            noise_t = torch.zeros((n_noise, B, 1, T), dtype=torch.float32, device=self.device) if n_noise else None
+            t_raw, r0 = [], 0
+            for i, (r, n) in enumerate(zip(rows, lens)):
+                g = rngs[i] if isinstance(rngs, (list, tuple)) else rngs
+                Ti = n + (self.tot_ds - n % self.tot_ds)
+                for k in range(n_noise):  # the draws of the call on this entry alone, in its order (x0 first)
+                    noise_t[k, r0:r0 + r.shape[0], :, :Ti] = torch.randn((r.shape[0], 1, Ti), dtype=torch.float32,
+                                                                         device=self.device, generator=g)
+                t_raw += [n] * r.shape[0]
+                r0 += r.shape[0]
+            mix = torch.cat([torch.nn.functional.pad(r, (0, l_max - r.shape[-1])) for r in rows], dim=0)[:, None, :]
+            out = self._enhance(mix, n_steps, epsilon, None, None, None, use_aux_signal, keep_rms, None, "median",
+                                warm_start, noise_t, t_raw=t_raw)
+            res, r0 = [], 0
+            for r, nd, n in zip(rows, dims, lens):
+                o = out[r0:r0 + r.shape[0], 0, :n]
+                r0 += r.shape[0]
+                res.append(o[0] if nd == 1 else o)
+            return res
         per_entry = []
         for i, r in enumerate(rows):
             g = rngs[i] if isinstance(rngs, (list, tuple)) else rngs

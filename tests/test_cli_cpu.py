@@ -165,12 +165,14 @@ def test_cli_sharding_covers_every_file_once(tmp_path):
     assert cli.plan_files(files, 1, 0) == list(enumerate(files))
 
 
-def test_cli_groups_consecutive_files_of_equal_rate_and_length():
+def test_cli_groups_consecutive_files_of_equal_rate_any_length():
+    """--batch-size groups consecutive files of one sample rate whatever their lengths (exact batching keeps every row's own
+    geometry; --pad-batch only changes what the call does with them)."""
     from open_universe_amd.bin import enhance as cli
 
     todo = [(k, f"f{k}") for k in range(6)]
     infos = {0: (16000, 5), 1: (16000, 5), 2: (16000, 5), 3: (16000, 7), 4: (8000, 7), 5: (8000, 7)}
     g = cli.group_files(todo, infos, 2, False)
-    assert [[k for k, _ in grp] for grp in g] == [[0, 1], [2], [3], [4, 5]]
-    g = cli.group_files(todo, infos, 4, True)   # --pad-batch: any length, same rate
+    assert [[k for k, _ in grp] for grp in g] == [[0, 1], [2, 3], [4, 5]]
+    g = cli.group_files(todo, infos, 4, True)
     assert [[k for k, _ in grp] for grp in g] == [[0, 1, 2, 3], [4, 5]]

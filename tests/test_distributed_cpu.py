@@ -76,8 +76,7 @@ class _StubModel:
 
     def enhance_many(self, sigs, rngs, pad_batch=False, **kw):
         self.calls.append(len(sigs))
-        if not pad_batch:
-            assert len({int(s.shape[-1]) for s in sigs}) == 1
+        self.ragged_calls = getattr(self, "ragged_calls", 0) + int(len({int(s.shape[-1]) for s in sigs}) > 1)
         return [s + torch.randn(s.shape, generator=g) for s, g in zip(sigs, rngs)]
 
 
@@ -100,8 +99,8 @@ def _sharded_worker(rank, world, port, q):
 
 
 def test_enhance_sharded_batches_and_gathers_world_2():
-    """enhance_sharded(batch_size=4) over two gloo ranks: LPT shards, equal-length groups per rank, per-utterance
-    generators, gather in the original order -- bit-equal to one call per utterance in one process."""
+    """enhance_sharded(batch_size=4) over two gloo ranks: LPT shards, length-sorted groups of ANY lengths per rank (exact
+    batching), per-utterance generators, gather in the original order -- bit-equal to one call per utterance in one process."""
     sys.path.insert(0, ROOT)
     import open_universe_amd  # noqa: F401
     from open_universe_amd import distributed as D
@@ -124,9 +123,51 @@ def test_enhance_sharded_batches_and_gathers_world_2():
         assert torch.equal(torch.from_numpy(a), b)
     assert max(calls) >= 2  # rank 0 really batched something
     # grouping rules
-    assert D.plan_batches([5, 5, 7, 5, 7, 3], range(6), 2) == [[2, 4], [0, 1], [3], [5]]
+    assert D.plan_batches([5, 5, 7, 5, 7, 3], range(6), 2, equal_only=True) == [[2, 4], [0, 1], [3], [5]]
+    assert D.plan_batches([5, 5, 7, 5, 7, 3], range(6), 2) == [[2, 4], [0, 1], [3, 5]]  # exact batching: any lengths
     assert D.plan_batches([5, 5, 7, 5, 7, 3], range(6), 2, pad_batch=True) == [[2, 4], [0, 1], [3, 5]]
     assert D.plan_batches([5, 5, 5], range(3), 1) == [[0], [1], [2]]
+
+
+def test_enhance_sharded_empty_shard_with_calls_in_flight(monkeypatch):
+    """A rank whose shard is empty (fewer utterances than ranks, or no input at all) with in_flight > 1: the pool used to be
+    sized by max() over an empty set of group sizes -- ValueError on that rank while the others wait in the gather."""
+    sys.path.insert(0, ROOT)
+    import open_universe_amd  # noqa: F401
+    from open_universe_amd import distributed as D
+    from open_universe_amd import lanes
+
+    made = []
+
+    class FakePool:
+        MAX_LANES = 8
+
+        def __init__(self, model, n, max_batch=0):
+            made.append(max_batch)
+            self.m = model
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def submit(self, fn):
+            return 0, fn(self.m)
+
+        def synchronize(self):
+            pass
+
+    monkeypatch.setattr(lanes, "LanePool", FakePool)
+    m = _StubModel()
+    m.fork = lambda: m
+    assert D.enhance_sharded(m, [], in_flight=4, batch_size=4, n_steps=3) == []
+    assert made == [0]
+    # ragged shard, batch_size > 1: groups of any lengths, the pool sized by the largest group
+    sigs = [torch.full((n,), float(i)) for i, n in enumerate([700, 300, 500])]
+    outs = D.enhance_sharded(m, sigs, seed=3, in_flight=2, batch_size=2, n_steps=3)
+    ref = D.enhance_sharded(_StubModel(), sigs, seed=3, n_steps=3)
+    assert all(torch.equal(a, b) for a, b in zip(outs, ref)) and made[-1] == 2 and m.ragged_calls == 1
 
 
 def test_pick_backend_uses_the_local_world_size(monkeypatch):
