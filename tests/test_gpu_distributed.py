@@ -18,8 +18,8 @@ from open_universe_amd import state_dict as S
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LENGTHS = [4100, 2900, 3555, 1600, 5200]
-# batched sharded path: groups of equal length exist (3 x 4100, 4 x 2900), plus singletons
-LENGTHS_B = [4100, 2900, 4100, 2900, 3555, 2900, 4100, 2900, 1600]
+# batched sharded path: a RAGGED set (some lengths repeat, most groups mix lengths, one is a multiple of tot_ds = 160)
+LENGTHS_B = [4100, 2900, 4100, 2900, 3555, 2900, 4100, 2880, 1600]
 
 
 def _signals(spec):
@@ -82,10 +82,12 @@ def test_two_ranks_on_one_gpu_equal_single_process():
 
 
 def test_two_ranks_batched_shards():
-    """enhance_sharded(batch_size=4): every rank groups the equal-length utterances of its shard into one `enhance`
-    call (per-utterance generators, the shapes of a single call).  The result of an utterance does not depend on the
-    grouping or the sharding beyond fp32 summation order (the conv tilings are chosen from the total column count of a
-    call): >= 100 dB against the one-call-per-utterance run, and the same grouping is bit-reproducible."""
+    """enhance_sharded(batch_size=4) on a RAGGED set: every rank walks its LPT shard in length-sorted groups of up to four
+    utterances of ANY lengths per `enhance` call -- exact batching: per-rank local max, per-row lengths (ou_enhance_var),
+    per-utterance generators with the shapes of a single call.  The result of an utterance does not depend on the grouping
+    or the sharding beyond fp32 summation order (the conv tilings are chosen from the total column count of a call):
+    >= 100 dB against the one-call-per-utterance run, and the same grouping is bit-reproducible.  This is what each of the
+    eight ranks of a node runs on its shard of a directory."""
     import restatement as O
     from helpers import record
     from open_universe_amd import UniverseGAN
@@ -108,15 +110,20 @@ def test_two_ranks_batched_shards():
     batched = D.enhance_sharded(model, sigs, seed=77, n_steps=3, batch_size=4)   # 1 rank, groups of up to 4
     again = D.enhance_sharded(model, sigs, seed=77, n_steps=3, batch_size=4)
     groups = D.plan_batches(LENGTHS_B, list(range(len(LENGTHS_B))), 4)
-    assert sorted(len(g) for g in groups) == [1, 1, 3, 4]
+    assert sorted(len(g) for g in groups) == [1, 4, 4] and sum(len({LENGTHS_B[i] for i in g}) > 1 for g in groups) == 2
     for i, L in enumerate(LENGTHS_B):
         assert got[i].shape == (L,) and batched[i].shape == (L,)
         assert torch.equal(batched[i], again[i])  # same grouping: bit-identical
         record(f"sharded.batched_vs_single.{i}", O.si_sdr(singles[i].cpu(), batched[i].cpu()), 100)
         record(f"sharded.2rank_batched_vs_single.{i}", O.si_sdr(singles[i].cpu(), torch.from_numpy(got[i])), 100)
-    # ragged mode (reference batch semantics: right zero padding, no mask): runs, keeps lengths, differs from singles
+    # the older rule (equal lengths only) and exact batching agree, whatever shares a call
+    eq = D.enhance_sharded(model, sigs, seed=77, n_steps=3, batch_size=4, equal_only=True)
+    for i in range(len(LENGTHS_B)):
+        record(f"sharded.exact_vs_equal_only.{i}", O.si_sdr(eq[i].cpu(), batched[i].cpu()), 100)
+    # reference batch semantics (right zero padding, no mask): runs, keeps lengths, and is NOT the utterance alone
     padded = D.enhance_sharded(model, sigs, seed=77, n_steps=3, batch_size=4, pad_batch=True)
     assert [int(o.shape[-1]) for o in padded] == LENGTHS_B and all(torch.isfinite(o).all() for o in padded)
+    assert min(float(O.si_sdr(singles[i].cpu(), padded[i].cpu())) for i in (1, 4, 8)) < 60.0
 
 
 def _run(cmd, timeout=900):
@@ -164,9 +171,9 @@ def test_cli_under_two_ranks_equals_one_rank(tmp_path):
 
 
 def test_cli_batch_size_matches_file_by_file(tmp_path):
-    """--batch-size: consecutive files of equal rate and length share one enhance call; the shared generator is drawn
-    from file by file in processing order, so every file sees the noise of the serial loop (bin/enhance.py:147-192) and
-    the outputs agree with the file-by-file run to fp32 summation order."""
+    """--batch-size: consecutive files of equal rate -- of ANY lengths and channel counts -- share one enhance call (exact
+    batching); the shared generator is drawn from file by file in processing order, so every file sees the noise of the
+    serial loop (bin/enhance.py:147-192) and the outputs agree with the file-by-file run to fp32 summation order."""
     import restatement as O
     from helpers import record
     from open_universe_amd import audio as A
