@@ -457,6 +457,20 @@ def main():
     assert torch.isfinite(out).all()
     launches = model.launch_stats()
     rank_ms = per_rank_ms(step, max(2, args.steps // 2), world, device)
+    # ---- N > 1: the same loop on rank 0 ALONE (the other ranks wait at a barrier with idle GPUs) -- the one-GPU figure of THIS
+    # invocation mode (same process layout, host-thread cap, backend), so that a multi-GPU record describes itself
+    solo_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        if rank == 0:
+            k = max(2, args.steps // 2)
+            t0 = time.perf_counter()
+            for _ in range(k):
+                step()
+            torch.cuda.synchronize()
+            solo_ms = 1e3 * (time.perf_counter() - t0) / k
+        torch.distributed.barrier()
 
     # ---- other per-GPU batch sizes, same model / length / step count (short loops; every rank takes part) ----
     batch_sweep = {}
@@ -629,6 +643,7 @@ def main():
         # (1000 + steps).
         gru_recs = [r for r in recs if r[3] >= 1000]
         recs = [r for r in recs if r[3] < 1000]
+        split_launches = sum(1 for r in recs if 800 <= r[3] < 1000)  # conv_split_kernel launches of the timed configuration
         def executed_fraction(cfg):
             """MFMA multiply-adds a launch issues / its algorithmic ones: the minimal-filtering kernels (F(2, KW): KW + 1 products
             per pair of outputs instead of 2 KW) carry KW in their variant code."""
@@ -791,6 +806,13 @@ def main():
             "value": audio_s / dt,
             "unit": "x_realtime",
             "utterances_per_s": args.steps * args.batch * world / dt,
+            "utterances_per_s_per_gpu": args.steps * args.batch / dt,
+            "rank0_alone": None if solo_ms is None else {
+                "ms_per_step": solo_ms, "utterances_per_s": 1e3 * args.batch / solo_ms,
+                "per_gpu_rate_vs_rank0_alone": (args.steps * args.batch / dt) / (1e3 * args.batch / solo_ms),
+                "note": "the same loop on rank 0 while the other ranks wait at a barrier (their GPUs idle), same process layout "
+                        "and host-thread cap: the one-GPU figure of this invocation mode; the ratio is the per-GPU rate of the "
+                        "N-rank loop (MAX over ranks) over it"},
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -799,11 +821,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "dtype_note": "fp32 tensors and fp32 accumulation everywhere; the timed configuration (batch %d) runs %s" % (
-                args.batch, "its k3 / k5 convs of the 256- / 512-channel levels on the BF16 matrix pipe with every fp32 operand as three "
+            "bf16_split_launches_per_enhance": split_launches // max(1, args.profile_steps),
+            "dtype_note": "fp32 tensors and fp32 accumulation everywhere; the timed configuration (batch %d; from the kernel variants "
+                          "recorded in the profiled pass) runs %s" % (
+                args.batch, "some of its k3 / k5 convs of the 256- / 512-channel levels on the BF16 matrix pipe with every fp32 operand as three "
                 "bf16 pieces and six piece products per fp32 product (conv_split_kernel, DESIGN.md 4.1f: fp32-class accuracy, measured "
                 "1 dB better than an fp32 fmaf chain against a double evaluation; OU_SPLIT=0 keeps everything on the f32 MFMAs)"
-                if (args.batch >= 16 and os.environ.get("OU_SPLIT", "-1") != "0") else
+                if split_launches else
                 "every convolution on the f32-input MFMAs (exact fp32 products); from batch 16 -- the '16' entry of batch_sweep -- the "
                 "256- / 512-channel k3 / k5 convs go to conv_split_kernel (three bf16 pieces per fp32 operand on the BF16 pipe, "
                 "fp32-class accuracy, DESIGN.md 4.1f)"),
