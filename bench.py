@@ -317,6 +317,9 @@ def parse_args(argv=None):
     ap.add_argument("--in-flight", default="4",
                     help="lanes of the ragged-set leg (32 utterances of 32 different lengths through "
                          "distributed.enhance_sharded, serial loop vs K calls in flight); '' = off")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="ou_set_option on every model of the run (tuning / A-B runs, e.g. --option split=0 --option no_overlap=1); "
+                         "recorded in the line as `options`")
     ap.add_argument("--ragged-batch", default="8,16,32",
                     help="batch sizes of the ragged-set leg's exact-batching runs (ou_enhance_var); empty: skip")
     ap.add_argument("--batch-sweep", default="1,4,8,16",
@@ -428,6 +431,12 @@ def main():
                  "backend": torch.distributed.get_backend(), "ranks": world}
     rccl = D.rccl_report(device)  # ranks, distinct physical GPUs (UUIDs), backend -- what a SCALE record has to prove
     cls = UniverseGAN if spec.kind == "universe_gan" else Universe
+    forced = {}
+    for kv in args.option:
+        k, _, v = kv.partition("=")
+        forced[k.strip()] = float(v)
+    if forced:
+        Universe.set_default_options(**forced)
     model = cls(spec, packed_weights=blob, device=device)
 
     T = int(args.seconds * spec.fs)
@@ -826,7 +835,7 @@ def main():
                           "recorded in the profiled pass) runs %s" % (
                 args.batch, "some of its k3 / k5 convs of the 256- / 512-channel levels on the BF16 matrix pipe with every fp32 operand as three "
                 "bf16 pieces and six piece products per fp32 product (conv_split_kernel, DESIGN.md 4.1f: fp32-class accuracy, measured "
-                "1 dB better than an fp32 fmaf chain against a double evaluation; OU_SPLIT=0 keeps everything on the f32 MFMAs)"
+                "1 dB better than an fp32 fmaf chain against a double evaluation; option split = 0 keeps everything on the f32 MFMAs)"
                 if split_launches else
                 "every convolution on the f32-input MFMAs (exact fp32 products); from batch 16 -- the '16' entry of batch_sweep -- the "
                 "256- / 512-channel k3 / k5 convs go to conv_split_kernel (three bf16 pieces per fp32 operand on the BF16 pipe, "
@@ -846,6 +855,8 @@ def main():
                 "backend": torch.distributed.get_backend() if grouped else None,
                 "launches_per_enhance": launches[0],
             },
+            "options": {"forced": forced, "note": "ou_set_option values that differ from the defaults in this run (--option); the "
+                                                  "library reads no environment variable"},
             "per_rank_ms_per_step": rank_ms,
             "rccl": rccl,
             "host_threads_per_rank": host_threads,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OU_ABI_VERSION 5 /* 5: ou_enhance_var (batches whose rows have lengths of their own), workspace header carries the per-row geometry; 4: the packed blob carries a bf16-split weight copy (conv_split_kernel); 3: a Winograd-domain copy (round 5), ou_set_lane_batch, ou_lane_capacity */
+#define OU_ABI_VERSION 5 /* 5: ou_enhance_var (batches whose rows have lengths of their own), workspace header carries the per-row geometry; ou_set_option / ou_get_option replace every OU_* environment switch (the library reads no environment variable), ou_config.fir_fold; 4: the packed blob carries a bf16-split weight copy (conv_split_kernel); 3: a Winograd-domain copy (round 5), ou_set_lane_batch, ou_lane_capacity */
 
 enum {
   OU_OK = 0,
@@ -78,6 +78,10 @@ typedef struct ou_config {
   ou_net_config cond;
   int32_t has_edm_data_level; /* edm.data_level_db given (universe.py:176-178); 0: sigma_data follows level_db */
   float edm_data_level_db;
+  int32_t fir_fold; /* packing choice, not a reference hyper-parameter: bit 0 / bit 1 = fold the binomial anti-alias FIR of the
+                     * down / up rate-change convs (blocks.py:213-227) into their weights (one launch less per rate change for 3x
+                     * that conv's FLOPs; slower on MI355X, default 0).  The plan and the blob depend on it: same value for the
+                     * packer and ou_create. */
 } ou_config;
 
 typedef struct ou_packer ou_packer;
@@ -242,8 +246,25 @@ int ou_lane_capacity(const ou_handle* h, int32_t max_batch);
  * handle publishes with agent-scope stores from the next call on (see ou_set_gru_publish_mode). */
 int ou_check_device_status(ou_handle* h, void* ws);
 
+/* ---- steering (tests, tuning) ---------------------------------------------------------------------------------
+ * Typed options of a handle.  They replace the ~35 OU_* environment variables earlier ABI versions read: the library reads NO
+ * environment variable any more, so nothing outside the caller's own code can change which kernels run.  Normal use needs
+ * none of them -- the defaults are what the launchers' measured rules pick; the tests use them to force every kernel family
+ * onto every layer it admits, the tools to sweep.  Keys: ou_option_name(0 .. ou_option_count() - 1), each with a one-line
+ * ou_option_doc; integer-valued except `tile_min`.  Options that make a call return WRONG results by design (phase
+ * ablation) exist in `make EXPERIMENTS=1` builds only (OU_ENOTIMPL otherwise).  A forward call works on the values it finds
+ * when it starts; a captured hipGraph keeps the kernels it was captured with.  ou_plan_json echoes the current values. */
+int ou_set_option(ou_handle* h, const char* key, double value); /* OU_EMISSING: no such key; OU_EINVAL: not an integer */
+int ou_get_option(const ou_handle* h, const char* key, double* value);
+int ou_reset_options(ou_handle* h); /* every option back to its default */
+int ou_option_count(void);
+const char* ou_option_name(int32_t index);
+const char* ou_option_doc(int32_t index);
+double ou_option_default(int32_t index);
+
 /* ---- introspection (tests, profiling) ------------------------------------------------------------------- */
-/* JSON description of the packed layers (name, kind, shapes, offsets into the blob). */
+/* JSON description of the packed layers (name, kind, shapes, offsets into the blob); for a handle also "options": the current
+ * value of every ou_set_option key. */
 const char* ou_plan_json(const ou_handle* h);
 const char* ou_packer_plan_json(const ou_packer* p);
 /* Locate a named intermediate of the last ou_condition / ou_score / ou_enhance call in the workspace:

@@ -29,6 +29,10 @@ int ou_profile_read(ou_handle* h, int32_t max_records, float* ms, double* flops,
 int ou_profile_read_ticks(ou_handle* h, int32_t max_records, uint64_t* t_start, uint64_t* t_end, int32_t* cfg,
                           int32_t* n_records);
 
+/* Per-wave phase stamps of the fused ConvBlock kernel for ONE block of the network (its name as in ou_tensor, e.g.
+ * "score.enc0"; NULL / "": off) -- written into the last 16 MB of the workspace (tools/chain_ts.py). */
+int ou_set_stamp_layer(ou_handle* h, const char* block_name);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,7 @@ class Config(Structure):
         ("cond", NetConfig),
         ("has_edm_data_level", c_int32),
         ("edm_data_level_db", c_float),
+        ("fir_fold", c_int32),
     ]
 
 
@@ -96,6 +97,14 @@ def load():
         "ou_enhance": (i32, [vp, vp, vp, vp, i32, i32, i32, c_double, POINTER(c_float), i32, c_uint32, vp, sz, vp]),
         "ou_enhance_var": (i32, [vp, vp, vp, vp, i32, i32, POINTER(i32), i32, c_double, POINTER(c_float), i32, c_uint32, vp, sz, vp]),
         "ou_check_device_status": (i32, [vp, vp]),
+        "ou_set_option": (i32, [vp, c_char_p, c_double]),
+        "ou_get_option": (i32, [vp, c_char_p, POINTER(c_double)]),
+        "ou_reset_options": (i32, [vp]),
+        "ou_option_count": (i32, []),
+        "ou_option_name": (c_char_p, [i32]),
+        "ou_option_doc": (c_char_p, [i32]),
+        "ou_option_default": (c_double, [i32]),
+        "ou_set_stamp_layer": (i32, [vp, c_char_p]),
         "ou_plan_json": (c_char_p, [vp]),
         "ou_packer_plan_json": (c_char_p, [vp]),
         "ou_tensor": (i32, [vp, c_char_p, POINTER(sz), POINTER(i32), POINTER(i32)]),
@@ -129,13 +138,14 @@ def load():
 EXPORTED_SYMBOLS = [
     "ou_version", "ou_last_error", "ou_packer_last_error", "ou_packer_create", "ou_packer_set", "ou_packer_finish",
     "ou_packer_destroy", "ou_packed_bytes", "ou_create", "ou_destroy", "ou_workspace_bytes", "ou_schedule",
-    "ou_condition", "ou_score", "ou_aux_to_wav", "ou_enhance", "ou_enhance_var", "ou_check_device_status", "ou_plan_json",
+    "ou_condition", "ou_score", "ou_aux_to_wav", "ou_enhance", "ou_enhance_var", "ou_check_device_status",
+    "ou_set_option", "ou_get_option", "ou_reset_options", "ou_option_count", "ou_option_name", "ou_option_doc", "ou_option_default", "ou_plan_json",
     "ou_packer_plan_json", "ou_tensor", "ou_launch_stats", "ou_workspace_init", "ou_sampler_step",
     "ou_set_gru_publish_mode", "ou_get_gru_publish_mode", "ou_set_lanes", "ou_set_lane_batch", "ou_lane_capacity",
     "ou_transform_frames", "ou_transform_forward", "ou_transform_inverse",
     "ou_flac_last_error", "ou_flac_info", "ou_flac_decode",
 ]
-TUNING_SYMBOLS = ["ou_profile_enable", "ou_profile_read", "ou_profile_read_ticks", "ou_bench_conv",
+TUNING_SYMBOLS = ["ou_profile_enable", "ou_profile_read", "ou_profile_read_ticks", "ou_bench_conv", "ou_set_stamp_layer",
 ]
 
 _EXC = {OU_EINVAL: ValueError, OU_ENOTIMPL: NotImplementedError, OU_EMISSING: KeyError, OU_ESHAPE: ValueError,
@@ -155,8 +165,19 @@ def check(code, handle=None, packer=None):
     raise _EXC.get(code, RuntimeError)(msg)
 
 
-def make_config(spec):
-    """ModelSpec -> ou_config."""
+def option_names():
+    """Keys of ou_set_option, with their one-line descriptions."""
+    L = load()
+    return {L.ou_option_name(i).decode(): L.ou_option_doc(i).decode() for i in range(L.ou_option_count())}
+
+
+def option_defaults():
+    L = load()
+    return {L.ou_option_name(i).decode(): L.ou_option_default(i) for i in range(L.ou_option_count())}
+
+
+def make_config(spec, fir_fold=0):
+    """ModelSpec -> ou_config.  `fir_fold`: packing choice (ou_config.fir_fold), the same for the packer and ou_create."""
     def net(n):
         c = NetConfig()
         c.n_rates = len(n.rate_factors)
@@ -191,17 +212,18 @@ def make_config(spec):
     data_level = getattr(spec, "edm_data_level_db", None)
     cfg.has_edm_data_level = int(data_level is not None)
     cfg.edm_data_level_db = float(data_level) if data_level is not None else 0.0
+    cfg.fir_fold = int(fir_fold)
     return cfg
 
 
-def pack_weights(spec, state_dict):
+def pack_weights(spec, state_dict, fir_fold=0):
     """Fold + lay out a reference-keyed state dict into the device blob (host side, no GPU needed).
     Returns (torch.FloatTensor blob [CPU], plan_json str)."""
     import numpy as np
     import torch
 
     L = load()
-    cfg = make_config(spec)
+    cfg = make_config(spec, fir_fold)
     packer = c_void_p()
     check(L.ou_packer_create(byref(cfg), byref(packer)))
     try:
@@ -219,9 +241,9 @@ def pack_weights(spec, state_dict):
     return blob, plan
 
 
-def packed_bytes(spec):
+def packed_bytes(spec, fir_fold=0):
     L = load()
-    cfg = make_config(spec)
+    cfg = make_config(spec, fir_fold)
     n = c_size_t()
     check(L.ou_packed_bytes(byref(cfg), byref(n)))
     return n.value

@@ -28,6 +28,18 @@ struct TensorRef {
   size_t off;  // bytes into the workspace
   int C, T;
 };
+// Tuning / test switches of a handle (ou_set_option; the table of keys is kOptions below)
+struct Options {
+  int dbg = 0, xcd_map = -1, conv_direct = 5, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1,
+      d4_force = 0, d4_short = 1, d2_wk = 0, wino = 1, d2_map = -1, unfuse64 = 0, preact = 1;
+  int gru_v = 2, gru_bmax = 0, gru_ts = 0, gru_upw = 0, gru_backoff = 0, gru_agent = -1, gru_dbg = 0;
+  int split = -1;              // ConvArgs::split
+  int dbg_dec0_under_gru = 0;  // measurement only, INVALID results (see run_score); experiments library only
+  int tile_prefetch = 1;
+  int trace = 0, no_overlap = 0, ts = 0, deep_factor = 8, mask_fused = 1;
+  double tile_min = -1.0;      // < 0: the launcher's default
+  std::string chain_ts;        // ou_set_stamp_layer (tuning)
+};
 }  // namespace
 
 struct ou_packer {
@@ -48,6 +60,8 @@ struct ou_handle {
   // geometry of the last ou_condition (consumed by ou_score)
   int cond_B = 0, cond_T = 0;
   bool trace = false;
+  Options opt;                    // ou_set_option
+  std::string plan_with_options;  // ou_plan_json's answer (the plan + the current option values)
   int last_cfg = -1;
   long long* tstamps = nullptr;
   std::map<size_t, float> alphas;  // host copies of the PReLU slopes (blob offset -> value)
@@ -104,48 +118,57 @@ struct Tensor {
 // Bump allocator over the caller's workspace.  In `dry` mode nothing is launched and `base` may be null:
 // the same walk then only measures the footprint (ou_workspace_bytes) -> layout is a pure function of
 // (config, B, T).
-// Tuning / debug switches, read ONCE per C-ABI call: a forward walks ~400 launches and used to call getenv
-// eight times for each of them (a linear scan of the environment: a third of the host time of an enhance call).
-struct EnvCfg {
-  int dbg = 0, xcd_map = -1, conv_direct = 5, fuse = -1, fuse_nc = 0, rate_small = 1, fuse_upfir = 1, block3 = 0, d4_fir = 1, d4_force = 0, d4_short = 1, d2_wk = 0, wino = 1, d2_map = -1, unfuse64 = 0, preact = 1;
-  int gru_v = 2, gru_bmax = 0, gru_ts = 0, gru_upw = 0, gru_backoff = 0, gru_agent = -1, gru_dbg = 0;
-  int split = -1;  // OU_SPLIT (ConvArgs::split)
-  int dbg_dec0_under_gru = 0;  // OU_DBG_DEC0: measurement only, INVALID results (see run_score)
-  double tile_min = -1.0;  // < 0: the launcher's default
-  int tile_prefetch = 1;
-  std::string chain_ts;
-  static int geti(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
-  EnvCfg() {
-    split = geti("OU_SPLIT", -1);
-#ifdef OU_EXPERIMENTS  // switches that make a call return WRONG results by design (phase ablation, the decoder-under-GRU upper bound):
-    // honoured by the experiments library only -- a stray environment variable cannot corrupt the default library's output
-    dbg = geti("OU_DBG", 0);
-#endif
-    xcd_map = geti("OU_XCD_MAP", -1); conv_direct = geti("OU_CONV_DIRECT", 5);
-    fuse = geti("OU_FUSE", -1); fuse_nc = geti("OU_FUSE_NC", 0); rate_small = geti("OU_RATE_SMALL", 1);
-    fuse_upfir = geti("OU_FUSE_UPFIR", 1);
-    d4_fir = geti("OU_D4_FIR", 1);
-    d4_force = geti("OU_D4_FORCE", 0);
-    d4_short = geti("OU_D4_SHORT", 1);
-    d2_wk = geti("OU_D2_WK", 0);
-    wino = geti("OU_WINO", 1);
-    d2_map = geti("OU_D2_MAP", -1);
-    preact = geti("OU_PREACT", 1);  // 0: every PReLU in its consumer's operand path (ConvArgs::out_act never set)
-    unfuse64 = geti("OU_UNFUSE64", 0);
-    block3 = geti("OU_BLOCK3", 0);
-    gru_v = geti("OU_GRU_V", 2); gru_bmax = geti("OU_GRU_BMAX", 0); gru_ts = std::getenv("OU_GRU_TS") ? 1 : 0;
-    gru_upw = geti("OU_GRU_UPW", 0); gru_backoff = geti("OU_GRU_BACKOFF", 0); gru_agent = geti("OU_GRU_AGENT_STORES", -1);
-    gru_dbg = geti("OU_GRU_DBG", 0);
-#ifdef OU_EXPERIMENTS  // measurement-only switch with INVALID results: `make EXPERIMENTS=1` builds only, never in the shipped library
-#ifdef OU_EXPERIMENTS
-    dbg_dec0_under_gru = geti("OU_DBG_DEC0", 0);
-#endif
-#endif
-    { const char* e = std::getenv("OU_TILE_MIN"); if (e) tile_min = std::atof(e); }
-    tile_prefetch = geti("OU_TILE_PREFETCH", 1);
-    { const char* e = std::getenv("OU_CHAIN_TS"); if (e) chain_ts = e; }
-  }
+// Tuning / test switches.  Until ABI 4 these were ~35 OU_* environment variables read by the library; since ABI 5
+// the library reads NO environment variable: every switch is a typed option of the handle (ou_set_option / ou_get_option,
+// include/ouniverse.h), echoed by ou_plan_json, and a forward call works on a copy taken when it starts.
+struct OptDesc {
+  const char* key;
+  int Options::*ip;
+  double Options::*dp;
+  bool experiments_only;  // switches that make a call return WRONG results by design: honoured by `make EXPERIMENTS=1` builds only
+  const char* doc;
 };
+const OptDesc kOptions[] = {
+    {"conv_direct", &Options::conv_direct, nullptr, false, "kernel generations the conv launcher may use (0 .. 5, ConvArgs::direct)"},
+    {"split", &Options::split, nullptr, false, "-1 rule / 0 never / 1 wherever possible: conv_split_kernel (bf16-split operands)"},
+    {"wino", &Options::wino, nullptr, false, "0: never the minimal-filtering (Winograd / Cook-Toom) kernel variants"},
+    {"fuse", &Options::fuse, nullptr, false, "-1 cost model / 0 never / 2 / 3: depth of the fused ConvBlock body (conv_chain kernels)"},
+    {"fuse_nc", &Options::fuse_nc, nullptr, false, "128 / 256: columns per tile of the fused ConvBlock body (0: launcher's choice)"},
+    {"fuse_upfir", &Options::fuse_upfir, nullptr, false, "0: up-path anti-alias FIR always as its own pass"},
+    {"rate_small", &Options::rate_small, nullptr, false, "0: outermost rate-change convs on the generic kernels (no rate_down / rate_up)"},
+    {"preact", &Options::preact, nullptr, false, "0: every PReLU in its consumer's operand path (ConvArgs::out_act never set)"},
+    {"unfuse64", &Options::unfuse64, nullptr, false, "1: 64-channel ConvBlock bodies as three split-K launches"},
+    {"block3", &Options::block3, nullptr, false, "1: the three body convs of a deep-level ConvBlock in one launch (experiments build only)"},
+    {"xcd_map", &Options::xcd_map, nullptr, false, "block -> tile mapping of the LDS-tiled conv kernel (-1: launcher's choice)"},
+    {"d2_map", &Options::d2_map, nullptr, false, "block -> tile mapping of the wide-load split-K kernels (-1: launcher's choice)"},
+    {"d2_wk", &Options::d2_wk, nullptr, false, "4 / 8: K slices of conv_direct2_kernel (0: launcher's rule)"},
+    {"d4_fir", &Options::d4_fir, nullptr, false, "0: up convs with a fusable FIR stay on the first-generation fused kernel"},
+    {"d4_short", &Options::d4_short, nullptr, false, "0: the 401-frame levels at batch 1 stay on the first-generation kernels"},
+    {"d4_force", &Options::d4_force, nullptr, false, "10 TM + log2(WK): that conv_direct4 tile shape wherever a layer admits it"},
+    {"tile_min", nullptr, &Options::tile_min, false, "wave tiles per SIMD from which the no-split-K kernels take a layer (< 0: 1.2)"},
+    {"tile_prefetch", &Options::tile_prefetch, nullptr, false, "0: no LDS prefetch of the epilogue operand in conv_direct3_kernel"},
+    {"deep_factor", &Options::deep_factor, nullptr, false, "blocks of 64 x 128 per CU up to which a layer counts as 'deep' (split-K kernels)"},
+    {"mask_fused", &Options::mask_fused, nullptr, false, "ragged batches: 0 = a separate tail-mask launch after EVERY producer (reference form of the masks)"},
+    {"gru_v", &Options::gru_v, nullptr, false, "2 ring kernel / 1 polling-wave kernel (experiments build)"},
+    {"gru_bmax", &Options::gru_bmax, nullptr, false, "cap on the utterances per GRU launch (forces the chunked path)"},
+    {"gru_upw", &Options::gru_upw, nullptr, false, "hidden units per workgroup of the ring kernel (0: from the batch size)"},
+    {"gru_backoff", &Options::gru_backoff, nullptr, false, "poll back-off experiments of the ring kernel (0: none)"},
+    {"gru_agent_stores", &Options::gru_agent, nullptr, false, "-1 handle's mode / 0 plain / 1 agent-scope publishes"},
+    {"gru_dbg", &Options::gru_dbg, nullptr, false, "bit 0 no republish safety net, bit 1 system-scope publishes, bit 2 FAULT INJECTION (tests)"},
+    {"gru_ts", &Options::gru_ts, nullptr, false, "1: per-wave cycle stamps of the GRU kernel into the end of the workspace (tuning)"},
+    {"ts", &Options::ts, nullptr, false, "1: per-wave phase stamps in ou_bench_conv (tuning)"},
+    {"trace", &Options::trace, nullptr, false, "1: one line per conv launch on stderr"},
+    {"no_overlap", &Options::no_overlap, nullptr, false, "1: no side streams inside a call (every kernel alone on the device)"},
+    {"dbg", &Options::dbg, nullptr, true, "phase ablation switches of the conv kernels: WRONG results by design"},
+    {"dbg_dec0", &Options::dbg_dec0_under_gru, nullptr, true, "first decoder block under the GRU: upper-bound measurement, WRONG results"},
+};
+constexpr int kNumOptions = (int)(sizeof(kOptions) / sizeof(kOptions[0]));
+const OptDesc* find_option(const char* key) {
+  for (int i = 0; i < kNumOptions; i++)
+    if (std::strcmp(kOptions[i].key, key) == 0) return &kOptions[i];
+  return nullptr;
+}
+using EnvCfg = Options;
 
 struct Runner {
   ou_handle* h;
@@ -161,7 +184,11 @@ struct Runner {
   const char* where = "";
 
   Runner(ou_handle* h_, void* ws, size_t cap_, bool dry_, hipStream_t st_, int B_)
-      : h(h_), base((char*)ws), cap(cap_), dry(dry_), st(st_), B(B_), main_st(st_) {}
+      : h(h_), env(h_->opt), base((char*)ws), cap(cap_), dry(dry_), st(st_), B(B_), main_st(st_) {
+#ifndef OU_EXPERIMENTS
+    env.dbg = 0; env.dbg_dec0_under_gru = 0;  // (switches with WRONG results by design: experiments library only)
+#endif
+  }
 
   float* alloc_raw(size_t floats) {
     size_t bytes = (floats * 4 + 255) & ~size_t(255);
@@ -297,7 +324,7 @@ struct Runner {
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
     a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
-    a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct; a.d4_fir_unfused = env.d4_fir; a.d4_force = env.d4_force; a.d4_short = env.d4_short; a.d2_wk = env.d2_wk; a.wino = env.wino; a.d2_map = env.d2_map;
+    a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct; a.d4_fir_unfused = env.d4_fir; a.d4_force = env.d4_force; a.d4_short = env.d4_short; a.deep_factor = env.deep_factor; a.d2_wk = env.d2_wk; a.wino = env.wino; a.d2_map = env.d2_map;
     a.tile_min = env.tile_min; a.tile_prefetch = env.tile_prefetch;
     a.tstamps = h->tstamps;
     if (collect) { collect->push_back(a); return out; }
@@ -950,7 +977,77 @@ int ou_packed_bytes(const ou_config* cfg, size_t* nbytes) {
 }
 
 const char* ou_packer_plan_json(const ou_packer* p) { return p ? p->m.json.c_str() : ""; }
-const char* ou_plan_json(const ou_handle* h) { return h ? h->m.json.c_str() : ""; }
+const char* ou_plan_json(const ou_handle* hc) {
+  if (!hc) return "";
+  ou_handle* h = const_cast<ou_handle*>(hc);
+  // the plan of the packed layers + the current values of the handle's options (ou_set_option)
+  std::string o = "\"options\": {";
+  for (int i = 0; i < kNumOptions; i++) {
+    const OptDesc& d = kOptions[i];
+    char buf[96];
+    if (d.ip) std::snprintf(buf, sizeof buf, "%s\"%s\": %d", i ? ", " : "", d.key, h->opt.*(d.ip));
+    else std::snprintf(buf, sizeof buf, "%s\"%s\": %.9g", i ? ", " : "", d.key, h->opt.*(d.dp));
+    o += buf;
+  }
+  o += "}";
+  const std::string& j = h->m.json;
+  const size_t close = j.rfind('}');
+  h->plan_with_options = close == std::string::npos ? "{" + o + "}" : j.substr(0, close) + ", " + o + j.substr(close);
+  return h->plan_with_options.c_str();
+}
+
+int ou_set_option(ou_handle* h, const char* key, double value) {
+  if (!h || !key) return fail(h, OU_EINVAL, "bad argument");
+  const OptDesc* d = find_option(key);
+  if (!d) return fail(h, OU_EMISSING, std::string("ou_set_option: no such option: ") + key);
+#ifndef OU_EXPERIMENTS
+  if (d->experiments_only && value != 0.0)
+    return fail(h, OU_ENOTIMPL, std::string("ou_set_option: `") + key + "` makes calls return wrong results by design and exists in "
+                "the experiments build (make EXPERIMENTS=1) only");
+#endif
+  if (d->ip) {
+    if (value != std::floor(value) || std::fabs(value) > 2e9) return fail(h, OU_EINVAL, std::string("ou_set_option: `") + key + "` takes an integer");
+    h->opt.*(d->ip) = (int)value;
+  } else {
+    h->opt.*(d->dp) = value;
+  }
+  h->trace = h->opt.trace != 0;
+  h->overlap = h->opt.no_overlap == 0;
+  return OU_OK;
+}
+
+int ou_get_option(const ou_handle* h, const char* key, double* value) {
+  if (!h || !key || !value) return fail(const_cast<ou_handle*>(h), OU_EINVAL, "bad argument");
+  const OptDesc* d = find_option(key);
+  if (!d) return fail(const_cast<ou_handle*>(h), OU_EMISSING, std::string("ou_get_option: no such option: ") + key);
+  *value = d->ip ? (double)(h->opt.*(d->ip)) : h->opt.*(d->dp);
+  return OU_OK;
+}
+
+int ou_reset_options(ou_handle* h) {
+  if (!h) return fail(h, OU_EINVAL, "bad argument");
+  const std::string keep = h->opt.chain_ts;
+  h->opt = Options();
+  h->opt.chain_ts = keep;
+  h->trace = false;
+  h->overlap = true;
+  return OU_OK;
+}
+
+int ou_option_count(void) { return kNumOptions; }
+const char* ou_option_name(int32_t i) { return i >= 0 && i < kNumOptions ? kOptions[i].key : nullptr; }
+const char* ou_option_doc(int32_t i) { return i >= 0 && i < kNumOptions ? kOptions[i].doc : nullptr; }
+double ou_option_default(int32_t i) {
+  if (i < 0 || i >= kNumOptions) return 0.0;
+  const Options d;
+  return kOptions[i].ip ? (double)(d.*(kOptions[i].ip)) : d.*(kOptions[i].dp);
+}
+
+int ou_set_stamp_layer(ou_handle* h, const char* block_name) {
+  if (!h) return fail(h, OU_EINVAL, "bad argument");
+  h->opt.chain_ts = block_name ? block_name : "";
+  return OU_OK;
+}
 
 int ou_create(const ou_config* cfg, const void* weights_dev, size_t nbytes, int32_t device, ou_handle** out) {
   if (!cfg || !weights_dev || !out) return fail(nullptr, OU_EINVAL, "null argument");
@@ -977,7 +1074,7 @@ int ou_create(const ou_config* cfg, const void* weights_dev, size_t nbytes, int3
     return fail(nullptr, OU_EHIP, "libouniverse is built for gfx950 (MI355X) only; device is " + arch);
   }
   h->num_cu = prop.multiProcessorCount;
-  h->trace = std::getenv("OU_TRACE") != nullptr;
+  h->trace = false;
   h->device = device;
   h->W = (const float*)weights_dev;
   (void)hipSetDevice(device);
@@ -1006,7 +1103,7 @@ int ou_create(const ou_config* cfg, const void* weights_dev, size_t nbytes, int3
     he = hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking);
     if (he != hipSuccess) { delete h; return fail(nullptr, OU_EHIP, hipGetErrorString(he)); }
   }
-  h->overlap = std::getenv("OU_NO_OVERLAP") == nullptr;
+  h->overlap = true;
   *out = h;
   return OU_OK;
 }
@@ -1459,7 +1556,7 @@ int ou_bench_conv(ou_handle* h, const char* layer, int32_t B, int32_t Tin, int32
   if (r.oom) return finish(h, r);
   r.chk(hipMemsetAsync(in.p, 0x3c, (size_t)B * L->Cin * Tin * 4, st), "fill");
   h->force_cfg = cfg; h->force_sc = sc < 0 ? 0 : sc;
-  if (std::getenv("OU_TS")) h->tstamps = (long long*)((char*)ws + ws_bytes - (16u << 20));
+  if (h->opt.ts) h->tstamps = (long long*)((char*)ws + ws_bytes - (16u << 20));
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   size_t mark = r.off;

@@ -538,7 +538,7 @@ hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* c
     const bool wide_ok = a.wd && a.direct >= 2 && a.stride == 1 && a.up == 1;
     // up to 8 blocks of 64 x 128 per CU (measured: PP16 B = 8 33.3 -> 32.3 ms, OR16 B = 16 63.4 -> 60.2 ms when the limit
     // goes from 3 to 6-12; beyond that nothing moves: those layers are not direct-capable anyway)
-    static const long deep_factor = [] { const char* e = getenv("OU_DEEP_FACTOR"); return e ? atol(e) : 8L; }();
+    const long deep_factor = a.deep_factor;
     const bool deep = ((a.Nq <= 16384 || wide_ok) && wide < deep_factor * num_cu) || a.force_cfg >= 100;
     if (deep) {
       hipError_t e = launch_conv_direct(a, num_cu, stream, cfg_out);

@@ -52,14 +52,12 @@ std::string finish_conv(ConvL& L, Alloc& a) {
   return "";
 }
 
-// OU_FIR_FOLD (bit 0: down path, bit 1: up path): fold the anti-alias FIRs into the rate-change conv weights.  One
+// ou_config.fir_fold (bit 0: down path, bit 1: up path; until ABI 4 the environment variable OU_FIR_FOLD): fold the anti-alias FIRs into the rate-change conv weights.  One
 // launch and one bandwidth pass less per rate change, for 3x that conv's FLOPs.  Measured on MI355X (PP16, B = 1) the
 // separate 6.5 us FIR pass is cheaper on every level (down: 17-24 vs 21-42 us, up: 17-22 vs 24-38 us), so the default
 // is 0; the plan and the packed blob depend on it, so it has to be the same when packing and when creating the model.
-static int fir_fold() {
-  const char* e = getenv("OU_FIR_FOLD");
-  return e ? atoi(e) : 0;
-}
+static thread_local int g_fir_fold = 0;  // ou_config.fir_fold of the model being built (build_model sets it)
+static int fir_fold() { return g_fir_fold; }
 
 std::string make_conv(ConvL& L, Alloc& a, const std::string& name, int kind, int cin, int cout, int k, int rate,
                       bool aa, bool act) {
@@ -150,6 +148,8 @@ std::string build_model(const ou_config& cfg, Model& m) {
   m = Model();
   m.cfg = cfg;
   if (cfg.abi_version != OU_ABI_VERSION) return "ou_config.abi_version mismatch";
+  if (cfg.fir_fold < 0 || cfg.fir_fold > 3) return "ou_config.fir_fold must be 0 .. 3";
+  g_fir_fold = cfg.fir_fold;
   const ou_net_config& s = cfg.score;
   const ou_net_config& c = cfg.cond;
   if (s.n_rates < 1 || s.n_rates > OU_MAX_RATES) return "bad n_rates";

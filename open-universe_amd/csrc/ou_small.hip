@@ -860,8 +860,7 @@ hipError_t launch_fir(const float* x, const float* taps, int ntaps, float alpha,
                       const float* res, float res_scale, float* y, int B, int C, int T, hipStream_t st) {
   if (ntaps > 39 || !(ntaps & 1)) return hipErrorInvalidValue;
   const dim3 grid((T + FIR_TILE - 1) / FIR_TILE, C, B);
-  static const bool wide = [] { const char* e = getenv("OU_FIR_WIDE"); return !e || atoi(e) != 0; }();
-  if (wide) {  // (dwordx4 accesses at dword alignment: any T)
+  {  // (dwordx4 accesses at dword alignment: any T; the scalar kernel below takes the tap counts without an instantiation)
     void (*k)(const float*, const float*, float, int, const float*, const float*, float, float*, int, int) = nullptr;
     switch (ntaps) {
       case 5: k = fir4_kernel<5>; break;

@@ -15,10 +15,18 @@ import socket
 import subprocess
 import sys
 
-import torch
-import torch.distributed as dist
+# dmabuf IPC only on these hosts (RCCL needs it).  ROCr reads the variable when the runtime loads, i.e. at the first HIP call
+# of the process -- so it is set HERE, at import, before anything of this package can have touched the device; whether that
+# was early enough is recorded (a process that initialised HIP before importing this module keeps what it had).
+_IPC_PRESET = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-from . import _lib
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+_IPC_SET_BEFORE_HIP_INIT = _IPC_PRESET is not None or not torch.cuda.is_initialized()
+
+from . import _lib  # noqa: E402
 
 
 def env_rank():
@@ -53,7 +61,12 @@ def init(backend=None, force=False):
             backend = pick_backend(world)
         if torch.cuda.is_available():
             torch.cuda.set_device(local_device(local_rank))
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+        if not _IPC_SET_BEFORE_HIP_INIT and world > 1 and backend == "nccl":
+            import warnings
+
+            warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY was not in the environment when HIP was initialised in this process; "
+                          "export HSA_ENABLE_IPC_MODE_LEGACY=0 before the launcher if RCCL fails with hipIpcGetMemHandle errors",
+                          RuntimeWarning)
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
         if "MASTER_PORT" not in os.environ:
@@ -102,6 +115,7 @@ def rccl_report(device):
         pass
     return {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "distinct_device_uuids": len(set(ids)),
             "rccl_version": ver, "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+            "ipc_mode_set_before_hip_init": bool(_IPC_SET_BEFORE_HIP_INIT),
             "per_rank": every}
 
 

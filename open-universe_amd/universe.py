@@ -15,7 +15,8 @@ without a GPU construction fails.
 """
 import ctypes
 import math
-from ctypes import byref, c_float, c_int32, c_size_t, c_void_p
+import weakref
+from ctypes import byref, c_double, c_float, c_int32, c_size_t, c_void_p
 from typing import Optional
 
 import torch
@@ -33,7 +34,15 @@ def randn(x, sigma, rng=None):
 class Universe:
     """MI355X-native stand-in for the reference's `Universe` / `UniverseGAN` inference object."""
 
-    def __init__(self, spec: ModelSpec, state_dict=None, device=None, packed_weights=None):
+    # Steering (tests / tuning only; the library reads no environment variable): options every NEW model object starts
+    # with, and the live objects -- `set_default_options` reaches both, the way an environment variable used to.
+    default_options = {}
+    _live = weakref.WeakSet()
+    # tools/ only (each sets it explicitly): before every call, OU_<OPTION>=value environment variables are translated into
+    # ou_set_option calls -- the sweep scripts of earlier rounds steer that way.  The library itself reads no environment.
+    steer_from_env = False
+
+    def __init__(self, spec: ModelSpec, state_dict=None, device=None, packed_weights=None, fir_fold=0):
         if device is None:
             device = "cuda"
         device = torch.device(device)
@@ -66,11 +75,12 @@ class Universe:
         self._status_event = None
         self._status_ws = None
         self.training = False
-        self._cfg = _lib.make_config(spec)
+        self._fir_fold = int(fir_fold)
+        self._cfg = _lib.make_config(spec, self._fir_fold)
         if packed_weights is None:
             if state_dict is None:
                 raise ValueError("either state_dict or packed_weights is required")
-            packed_weights, _ = _lib.pack_weights(spec, state_dict)
+            packed_weights, _ = _lib.pack_weights(spec, state_dict, self._fir_fold)
         self._weights = packed_weights.to(device=device, dtype=torch.float32).contiguous()
         self._handle = c_void_p()
         with torch.cuda.device(device):
@@ -82,13 +92,67 @@ class Universe:
         self._ws_need = {}
         self._cond_key = None
         self._lanes = (1, 0)
+        for k, v in type(self).default_options.items():
+            self.set_option(k, v)
+        Universe._live.add(self)
+        self._env_seen = None
+        self._sync_env()
+
+    def _sync_env(self):
+        if not Universe.steer_from_env:
+            return
+        import os
+
+        snap = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("OU_")))
+        if snap == self._env_seen:
+            return
+        self._env_seen = snap
+        env = dict(snap)
+        for key, dflt in _lib.option_defaults().items():
+            v = env.get("OU_" + key.upper())
+            if key in ("trace", "gru_ts", "ts", "no_overlap") and v is not None:
+                v = "1" if v == "" or not v.lstrip("-").isdigit() else v  # (these used to be presence flags)
+            self.set_option(key, dflt if v is None else float(v))
+        _lib.check(self._L.ou_set_stamp_layer(self._handle, env.get("OU_CHAIN_TS", "").encode()), self._handle)
+
+    # ---- steering through the C ABI (ou_set_option): tests force kernel families, tools sweep; never needed for normal use ----
+    def set_option(self, key, value):
+        """One typed option of this model's handle (keys: `_lib.option_names()`); takes effect from the next call on."""
+        _lib.check(self._L.ou_set_option(self._handle, str(key).encode(), float(value)), self._handle)
+        self._ws_need.clear()  # (options may change what a walk allocates)
+
+    def get_option(self, key):
+        v = c_double()
+        _lib.check(self._L.ou_get_option(self._handle, str(key).encode(), byref(v)), self._handle)
+        return v.value
+
+    def options(self):
+        return {k: self.get_option(k) for k in _lib.option_names()}
+
+    def reset_options(self):
+        _lib.check(self._L.ou_reset_options(self._handle), self._handle)
+        self._ws_need.clear()
+
+    @classmethod
+    def set_default_options(cls, **kw):
+        """Set options on every live model object AND on those created from now on (value None: back to the default)."""
+        defaults = _lib.option_defaults()
+        for k, v in kw.items():
+            if v is None:
+                Universe.default_options.pop(k, None)
+            else:
+                Universe.default_options[k] = v
+            for m in list(Universe._live):
+                m.set_option(k, defaults[k] if v is None else v)
 
     # ---- several enhance calls in flight in one process -----------------------------------------------------------
     def fork(self):
         """A second model object on the SAME packed weights (no copy) with a handle, workspace and status record of its
         own: what one lane of `LanePool` runs on.  A handle is not re-entrant; several handles side by side are fine."""
-        twin = type(self)(self.spec, packed_weights=self._weights, device=self.device)
+        twin = type(self)(self.spec, packed_weights=self._weights, device=self.device, fir_fold=self._fir_fold)
         twin.check_status = self.check_status
+        for k, v in self.options().items():  # a lane runs what its primary model would run
+            twin.set_option(k, v)
         if self.gru_agent_scope:
             twin.gru_agent_scope = True
             _lib.check(twin._L.ou_set_gru_publish_mode(twin._handle, 1), twin._handle)
@@ -348,6 +412,7 @@ class Universe:
 
     def bench_conv(self, layer, B, Tin, cfg=-1, sc=-1, with_res=False, iters=20):
         """Tuning aid: ms per launch of one packed conv layer (see ou_bench_conv)."""
+        self._sync_env()
         ws = torch.empty(max(1 << 28, 64 * B * Tin * 4 * 64), dtype=torch.uint8, device=self.device)
         ms, used = c_float(), c_int32()
         _lib.check(self._L.ou_bench_conv(self._handle, layer.encode(), B, Tin, cfg, sc, int(with_res), iters,
@@ -378,6 +443,7 @@ class Universe:
     def condition_model(self, x, x_wav=None, train=False):
         """condition.py:346-377.  x: (B,1,T) normalised, T % tot_ds == 0.  Returns conditions or, with
         train=True, (conditions, aux_signal, latent) -- views into the workspace, valid until the next call."""
+        self._sync_env()
         x = self._prep(x)
         if x.ndim != 3 or x.shape[1] != 1:
             raise ValueError("condition_model expects (B, 1, T)")
@@ -398,6 +464,7 @@ class Universe:
 
     def score_model(self, x, sigma, cond=None):
         """universe.py:197-209 / score.py:277-297: score(x, sigma | cond of the last condition_model call)."""
+        self._sync_env()
         x = self._prep(x)
         B, _, T = x.shape
         if self._cond_key != (B, T):
@@ -452,6 +519,7 @@ class Universe:
                  ensemble_stat, warm_start, noise, t_raw=None):
         """`t_raw`: per-row lengths of a batch whose rows are utterances of different lengths (enhance_many, exact
         batching -> ou_enhance_var); `mix` is then (B, 1, max length) and `noise` a (n, B, 1, T) tensor."""
+        self._sync_env()
         self._poll_deferred_status()
         if epsilon is None:
             epsilon = self.diff_kwargs.epsilon

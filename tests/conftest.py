@@ -36,3 +36,30 @@ def built_lib():
 
         __graft_entry__.build()
     return _lib.load()
+
+
+class _Steer:
+    """Forces kernel choices through the C ABI (ou_set_option) on every live model object and on those created later -- what the
+    OU_* environment variables did until ABI 4, without the library reading the environment.  Undone at the end of the test."""
+
+    def __init__(self):
+        self.touched = set()
+
+    def set(self, **kw):
+        from open_universe_amd.universe import Universe
+
+        Universe.set_default_options(**kw)
+        self.touched |= set(kw)
+
+    def unset(self, *keys):
+        from open_universe_amd.universe import Universe
+
+        Universe.set_default_options(**{k: None for k in keys})
+
+
+@pytest.fixture
+def steer():
+    s = _Steer()
+    yield s
+    if s.touched:
+        s.unset(*s.touched)

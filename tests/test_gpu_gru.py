@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.skipif(not experiments_built(), reason="round 1's polling-wave kernel is in `make EXPERIMENTS=1` builds only")
 @pytest.mark.parametrize("name,B", [("PP16", 1), ("PP16", 2), ("PP24", 1), ("PP24s", 2), ("PP16m", 9)])
-def test_ring_kernel_matches_polling_wave_kernel(name, B, monkeypatch):
-    """OU_GRU_V=1: first-generation kernel (one polling wave, LDS hand-over, memset per launch); OU_GRU_V=2: ring kernel
+def test_ring_kernel_matches_polling_wave_kernel(name, B, steer):
+    """option gru_v = 1: first-generation kernel (one polling wave, LDS hand-over, memset per launch); option gru_v = 2: ring kernel
     (every wave gathers from L2, epoch tags; the default at batch 1).  Same recurrence, different summation order
     inside a row.  B = 9 covers batches that are not a multiple of the 8 XCDs, PP24 the 24-workgroup clusters."""
     model, spec, sd = get_model(name)
@@ -23,10 +23,10 @@ def test_ring_kernel_matches_polling_wave_kernel(name, B, monkeypatch):
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(29, 3, B, Tp)
-    monkeypatch.setenv("OU_GRU_V", "1")
+    steer.set(gru_v=1)
     model.reset_workspace()  # the two generations lay the exchange area out differently: fresh (cleared) workspace each
     ref = run_enhance(model, mix, nz, n_steps=3)
-    monkeypatch.setenv("OU_GRU_V", "2")
+    steer.set(gru_v=2)
     model.reset_workspace()
     out = run_enhance(model, mix, nz, n_steps=3)
     out2 = run_enhance(model, mix, nz, n_steps=3)
@@ -36,8 +36,8 @@ def test_ring_kernel_matches_polling_wave_kernel(name, B, monkeypatch):
 
 
 @pytest.mark.parametrize("name,B", [("PP16", 1), ("PP16", 3), ("PP24", 1)])
-def test_ring_kernel_gather_layouts_agree(name, B, monkeypatch):
-    """The ring kernel's gather layouts and cluster splits against each other (OU_GRU_UPW: 17 = round-2 layout, every unit's
+def test_ring_kernel_gather_layouts_agree(name, B, steer):
+    """The ring kernel's gather layouts and cluster splits against each other (option gru_upw: 17 = round-2 layout, every unit's
     16 lanes hold all H columns; 16 / 8 = wide layout -- a lane holds its granule pairs for all units of the wave, partial
     sums folded with v_permlane32/16_swap -- with 16 / 8 units per workgroup; 0 = the launcher's choice).  Same recurrence;
     the summation order inside a row differs."""
@@ -46,22 +46,22 @@ def test_ring_kernel_gather_layouts_agree(name, B, monkeypatch):
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(37, 3, B, Tp)
-    monkeypatch.setenv("OU_GRU_UPW", "17")
+    steer.set(gru_upw=17)
     model.reset_workspace()
     ref = run_enhance(model, mix, nz, n_steps=3)
     # (8 units per workgroup at H = 384 are 48-workgroup clusters: more than an XCD's 32 CUs, not offered by the launcher)
     for code in ("16", "8", "0") if name != "PP24" else ("16", "0"):
-        monkeypatch.setenv("OU_GRU_UPW", code)
+        steer.set(gru_upw=float(code))
         out = run_enhance(model, mix, nz, n_steps=3)
         assert torch.equal(out, run_enhance(model, mix, nz, n_steps=3))
         record(f"gru.layout_vs_round2.{name}.b{B}.upw{code}", O.si_sdr(ref, out), 90)
     model.reset_workspace()
 
 
-def test_ring_kernel_epoch_wrap(monkeypatch):
+def test_ring_kernel_epoch_wrap(steer):
     """Tags are epoch + step with a device-side epoch that only grows; near 2^31 the last block of a launch clears the
     exchange area and restarts.  Poke the stored epochs close to the limit and run across it."""
-    monkeypatch.setenv("OU_GRU_V", "2")
+    steer.set(gru_v=2)
     model, spec, sd = get_model("PP16m")
     model.reset_workspace()
     B, T = 2, spec.tot_ds * 25
@@ -82,8 +82,8 @@ def test_ring_kernel_epoch_wrap(monkeypatch):
     model.reset_workspace()
 
 
-def test_ring_kernel_recovers_a_lost_publish(monkeypatch):
-    """Fault injection (OU_GRU_DBG=4): one workgroup of every cluster drops its publishes of step 50.  The safety net --
+def test_ring_kernel_recovers_a_lost_publish(steer):
+    """Fault injection (option gru_dbg = 4): one workgroup of every cluster drops its publishes of step 50.  The safety net --
     every waiting wave repeats its last publish as a system-scope store after 256 poll rounds and keeps publishing that
     way for the rest of the launch -- has to bring the pass to the same result, bit for bit, without a timeout.  A publish
     that was never stored looks like a LATE member to the probe (no kind of load sees it): counted as a recovery, not as a
@@ -93,9 +93,9 @@ def test_ring_kernel_recovers_a_lost_publish(monkeypatch):
     nz = noise_list(61, 2, 1, 32160)
     ref = run_enhance(model, mix, nz, n_steps=2)
     base = model.gru_exchange_stats()
-    monkeypatch.setenv("OU_GRU_DBG", "4")
+    steer.set(gru_dbg=4)
     out = run_enhance(model, mix, nz, n_steps=2)
-    monkeypatch.delenv("OU_GRU_DBG")
+    steer.unset("gru_dbg")
     after = model.gru_exchange_stats()
     assert torch.equal(ref, out)
     assert after["recoveries"] > base["recoveries"] and after["system_scope"] > base["system_scope"]

@@ -286,7 +286,7 @@ def test_variable_length_batch_is_padded_batch_semantics():
 
 
 @pytest.mark.parametrize("mode", [("3", ""), ("2", ""), ("3", "128"), ("2", "256"), ("-1", "")])
-def test_fused_convblock_matches_unfused(mode, monkeypatch):
+def test_fused_convblock_matches_unfused(mode, steer):
     """The fused ConvBlock body (conv_chain_kernel: depth 3 / depth 2, 128- / 256-column tiles) against the three
     generic launches on the full-size model (C = 32 and C = 64 levels), a ragged length and B = 2: tile edges, halo
     recompute, zero padding at both ends of the signal, FiLM / cond-add / residual epilogues, the c1 tap of the
@@ -296,14 +296,14 @@ def test_fused_convblock_matches_unfused(mode, monkeypatch):
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     noise = noise_list(11, 3, B, Tp)
-    monkeypatch.setenv("OU_FUSE", "0")
-    monkeypatch.delenv("OU_FUSE_NC", raising=False)
+    steer.set(fuse=0)
+    steer.unset("fuse_nc")
     ref = run_enhance(model, mix, noise, n_steps=3)
     ref_launches = model.launch_stats()
     model._ws.zero_()
-    monkeypatch.setenv("OU_FUSE", mode[0])
+    steer.set(fuse=float(mode[0]))
     if mode[1]:
-        monkeypatch.setenv("OU_FUSE_NC", mode[1])
+        steer.set(fuse_nc=float(mode[1]))
     out = run_enhance(model, mix, noise, n_steps=3)
     assert model.launch_stats()[0] < ref_launches[0], "the fused path did not run"
     for b in range(B):
@@ -406,18 +406,18 @@ def test_oracle_score_mode_vs_oracle_with_shared_noise(monkeypatch):
 
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 2, 23517), ("PP24", 1, 30011), ("OR16", 3, 9000)])
-def test_direct_conv_kernels_match_lds_kernels(name, B, T, monkeypatch):
+def test_direct_conv_kernels_match_lds_kernels(name, B, T, steer):
     """The register-direct split-K kernels (stride 1: k1 / k3 / k5 and the phase GEMMs of the up convs with their fused
-    FIR epilogue; strided: k = s = r) against the LDS-tiled kernel on the same packed weights (OU_CONV_DIRECT=0): same K
+    FIR epilogue; strided: k = s = r) against the LDS-tiled kernel on the same packed weights (option conv_direct = 0): same K
     split over the 8 waves, different order inside a wave's slice -- fp32 rounding apart.
     Ragged lengths put partial tiles and the zero-padded halo at both ends of every level."""
     model, spec, sd = get_model(name)
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(37, 3, B, Tp)
-    monkeypatch.setenv("OU_CONV_DIRECT", "0")
+    steer.set(conv_direct=0)
     ref = run_enhance(model, mix, nz, n_steps=3)
-    monkeypatch.delenv("OU_CONV_DIRECT")
+    steer.unset("conv_direct")
     out = run_enhance(model, mix, nz, n_steps=3)
     for b in range(B):
         record(f"direct_vs_lds.{name}.{b}", O.si_sdr(ref[b], out[b]), 100)
@@ -425,62 +425,62 @@ def test_direct_conv_kernels_match_lds_kernels(name, B, T, monkeypatch):
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 2, 23517), ("PP24", 1, 30011), ("PP16", 1, 32000), ("PP16", 3, 777),
                                       ("OR16", 2, 9000)])
-def test_wide_load_direct_kernel_is_bit_identical_to_the_dword_one(name, B, T, monkeypatch):
+def test_wide_load_direct_kernel_is_bit_identical_to_the_dword_one(name, B, T, steer):
     """conv_direct2_kernel (one 16-byte load per operand feeds all taps, taps-innermost weight copy, interleaved output
-    columns) vs conv_direct_kernel (OU_CONV_DIRECT=1): same K order per output element, so the whole enhance is
+    columns) vs conv_direct_kernel (option conv_direct = 1): same K order per output element, so the whole enhance is
     bit-identical.  Ragged / tiny lengths exercise the shifted and masked windows of the first and last column tiles."""
     model, spec, sd = get_model(name)
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(47, 2, B, Tp)
-    monkeypatch.setenv("OU_CONV_DIRECT", "1")
+    steer.set(conv_direct=1)
     ref = run_enhance(model, mix, nz, n_steps=2)
-    monkeypatch.setenv("OU_CONV_DIRECT", "2")  # (level 4 would move the 1x1 / rate-change layers to conv_direct4_kernel)
+    steer.set(conv_direct=2)  # (level 4 would move the 1x1 / rate-change layers to conv_direct4_kernel)
     out = run_enhance(model, mix, nz, n_steps=2)
     assert torch.equal(ref, out)  # (T <= 32 768: both generations take the same layers)
 
 
-def test_wide_load_direct_kernel_at_the_headline_size(monkeypatch):
+def test_wide_load_direct_kernel_at_the_headline_size(steer):
     """4 s at 16 kHz: the wide-load kernel also takes the 64-channel k5 convs at T/2 = 32 080 (LDS kernel otherwise)."""
     model, spec, sd = get_model("PP16")
     mix = synth_mix(spec, 1, 64000)
     nz = noise_list(49, 2, 1, 64160)
-    monkeypatch.setenv("OU_CONV_DIRECT", "1")
+    steer.set(conv_direct=1)
     ref = run_enhance(model, mix, nz, n_steps=2)
-    monkeypatch.setenv("OU_CONV_DIRECT", "2")
+    steer.set(conv_direct=2)
     out = run_enhance(model, mix, nz, n_steps=2)
     record("direct2_vs_direct1.PP16.64000", O.si_sdr(ref[0], out[0]), 100)
 
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 1, 64000), ("PP16", 2, 23517), ("PP16", 3, 777), ("OR16", 2, 9000)])
-def test_four_slice_wide_load_kernel_vs_eight_slices(name, B, T, monkeypatch):
+def test_four_slice_wide_load_kernel_vs_eight_slices(name, B, T, steer):
     """conv_direct2_kernel with the reduction split over FOUR waves (256-thread blocks, round 5) against the eight-slice form:
     the same per-wave order over twice as long a K slice, four partial sums instead of eight -- fp32 rounding apart; and the
-    2-D XCD ownerships (OU_XCD_MAP 3 / 4: the same tiles dealt to other blocks) are bit-identical to the default mapping."""
+    2-D XCD ownerships (option xcd_map = 3 / 4: the same tiles dealt to other blocks) are bit-identical to the default mapping."""
     model, spec, sd = get_model(name)
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(53, 2, B, Tp)
-    monkeypatch.setenv("OU_D2_WK", "8")
+    steer.set(d2_wk=8)
     ref = run_enhance(model, mix, nz, n_steps=2)
     for mp in ("3", "4"):
-        monkeypatch.setenv("OU_XCD_MAP", mp)
+        steer.set(xcd_map=float(mp))
         assert torch.equal(run_enhance(model, mix, nz, n_steps=2), ref), mp
-    monkeypatch.delenv("OU_XCD_MAP")
-    monkeypatch.setenv("OU_D2_WK", "4")
+    steer.unset("xcd_map")
+    steer.set(d2_wk=4)
     out = run_enhance(model, mix, nz, n_steps=2)
     for b in range(B):
         record(f"direct2_wk4_vs_wk8.{name}.T{T}.{b}", O.si_sdr(ref[b], out[b]), 100)
-    monkeypatch.setenv("OU_XCD_MAP", "3")
+    steer.set(xcd_map=3)
     assert torch.equal(run_enhance(model, mix, nz, n_steps=2), out)
 
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 1, 64000), ("PP16", 2, 23517), ("PP16", 3, 777), ("OR16", 2, 9000), ("PP24", 1, 30011),
                                       ("PP16", 1, 161), ("PP16", 8, 16000), ("PP24", 4, 8000)])
-def test_activation_in_the_producer_epilogue_is_bit_identical(name, B, T, monkeypatch):
+def test_activation_in_the_producer_epilogue_is_bit_identical(name, B, T, steer):
     """Inside a ConvBlock (blocks.py:395-399) conv1's and conv2's outputs are read by the next PReLU_Conv only: the epilogue that
     produces them stores prelu(y) (ConvArgs::out_act) and the reader's operand path has no PReLU -- the same fp32 operation on the
-    same values, once per element instead of once per (row group, overlapping window).  Against OU_PREACT=0 (every PReLU in the
+    same values, once per element instead of once per (row group, overlapping window).  Against option preact = 0 (every PReLU in the
     consumer's loop) over whole enhance calls: bit-identical at every batch size / kernel family (split-K kernels at small batch,
     the no-split-K ones from batch 4), ragged and tiny lengths included; with the edge windows read from in front of the row
     and masked (first column tile) instead of shifted."""
@@ -488,10 +488,10 @@ def test_activation_in_the_producer_epilogue_is_bit_identical(name, B, T, monkey
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(67, 2, B, Tp)
-    monkeypatch.setenv("OU_PREACT", "0")
+    steer.set(preact=0)
     ref = run_enhance(model, mix, nz, n_steps=2)
     n_ref = model.launch_stats()
-    monkeypatch.delenv("OU_PREACT")
+    steer.unset("preact")
     out = run_enhance(model, mix, nz, n_steps=2)
     assert model.launch_stats() == n_ref
     assert torch.equal(out, ref)
@@ -499,32 +499,32 @@ def test_activation_in_the_producer_epilogue_is_bit_identical(name, B, T, monkey
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 1, 64000), ("PP16", 2, 23517), ("PP16", 3, 777), ("OR16", 2, 9000), ("PP24", 1, 30011),
                                       ("PP16", 1, 4001)])
-def test_minimal_filtering_kernels_vs_plain_summation(name, B, T, monkeypatch):
+def test_minimal_filtering_kernels_vs_plain_summation(name, B, T, steer):
     """conv_direct2w_kernel (Winograd / Cook-Toom F(2, 3) and F(2, 5): KW + 1 instead of 2 KW products per pair of adjacent
     outputs, weights transformed by the packer, samples transformed on the fly) against the plain wide-load kernel
-    (OU_CONV_DIRECT=4) through a whole enhance, and against the oracle.  Different arithmetic by construction (fp32 rounding
+    (option conv_direct = 4) through a whole enhance, and against the oracle.  Different arithmetic by construction (fp32 rounding
     of the transforms: -2 dB per k3 layer, -9 dB per k5 layer against a double evaluation); ragged / tiny lengths put the shifted and
     masked windows of the first and last column tiles under the input transform."""
     model, spec, sd = get_model(name)
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(59, 2, B, Tp)
-    monkeypatch.setenv("OU_CONV_DIRECT", "4")
+    steer.set(conv_direct=4)
     ref = run_enhance(model, mix, nz, n_steps=2)
     n_ref = model.launch_stats()
-    monkeypatch.delenv("OU_CONV_DIRECT")
+    steer.unset("conv_direct")
     out = run_enhance(model, mix, nz, n_steps=2)
     assert model.launch_stats() == n_ref
     for b in range(B):
         record(f"wino_vs_plain.{name}.T{T}.{b}", O.si_sdr(ref[b], out[b]), 85)
     e_ref = O.enhance(sd, spec.to_dict(), mix, n_steps=2, noise=nz)
     record(f"wino_vs_oracle.{name}.T{T}", O.si_sdr(e_ref, out), 80)
-    monkeypatch.setenv("OU_WINO", "0")
+    steer.set(wino=0)
     assert torch.equal(run_enhance(model, mix, nz, n_steps=2), ref)  # the switch: exactly the plain kernels
 
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 2, 23517), ("PP24", 1, 30011), ("PP16", 1, 64000)])
-def test_fused_up_fir_epilogue_is_bit_identical_to_the_fir_pass(name, B, T, monkeypatch):
+def test_fused_up_fir_epilogue_is_bit_identical_to_the_fir_pass(name, B, T, steer):
     """Up path: FIR + bias + residual fused into the transposed conv's epilogue (overlapping tiles, one halo frame) vs
     the separate bandwidth pass after it: same summation order, so the whole enhance is bit-identical -- with fewer
     launches."""
@@ -534,27 +534,26 @@ def test_fused_up_fir_epilogue_is_bit_identical_to_the_fir_pass(name, B, T, monk
     nz = noise_list(41, 2, B, Tp)
     # (the first-generation split-K kernel is the one with the fused FIR epilogue; by default those up convs now run on
     # conv_direct4_kernel + the FIR pass)
-    monkeypatch.setenv("OU_CONV_DIRECT", "3")
-    monkeypatch.setenv("OU_FUSE_UPFIR", "0")
+    steer.set(conv_direct=3)
+    steer.set(fuse_upfir=0)
     ref = run_enhance(model, mix, nz, n_steps=2)
     n_ref = model.launch_stats()
-    monkeypatch.delenv("OU_FUSE_UPFIR")
+    steer.unset("fuse_upfir")
     out = run_enhance(model, mix, nz, n_steps=2)
     n_out = model.launch_stats()
     assert torch.equal(ref, out)
     assert sum(n_out) < sum(n_ref), (n_out, n_ref)
 
 
-def test_folded_fir_weights_match_separate_fir_pass(monkeypatch):
-    """OU_FIR_FOLD=3: the packer folds the anti-alias FIRs into the rate-change conv weights (3r-tap strided convs, 3-tap
+def test_folded_fir_weights_match_separate_fir_pass():
+    """ou_config.fir_fold = 3: the packer folds the anti-alias FIRs into the rate-change conv weights (3r-tap strided convs, 3-tap
     phase GEMMs); the plan and the blob differ, the arithmetic only in the order of the fp32 sums."""
     model, spec, sd = get_model("PP16")
     B, T = 2, 16000
     mix = synth_mix(spec, B, T)
     nz = noise_list(43, 2, B, T + (spec.tot_ds - T % spec.tot_ds))
     ref = run_enhance(model, mix, nz, n_steps=2)
-    monkeypatch.setenv("OU_FIR_FOLD", "3")
-    folded = type(model)(spec, state_dict=sd, device="cuda:0")
+    folded = type(model)(spec, state_dict=sd, device="cuda:0", fir_fold=3)
     out = run_enhance(folded, mix, nz, n_steps=2)
     assert sum(folded.launch_stats()) < sum(model.launch_stats())
     for b in range(B):
@@ -562,18 +561,18 @@ def test_folded_fir_weights_match_separate_fir_pass(monkeypatch):
 
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 2, 23517), ("PP24", 1, 30011), ("OR16", 1, 64000)])
-def test_fused_first_rate_change_conv_matches_fir_pass_plus_conv(name, B, T, monkeypatch):
+def test_fused_first_rate_change_conv_matches_fir_pass_plus_conv(name, B, T, steer):
     """rate_down_kernel (PReLU -> FIR -> k = s = r conv of the first level in one launch, no split-K) and rate_up_kernel
     (PReLU -> transposed conv -> FIR -> bias -> residual of the last level) vs the FIR passes + the generic convs
-    (OU_RATE_SMALL=0): same filter tap order, different K order in the convs."""
+    (option rate_small = 0): same filter tap order, different K order in the convs."""
     model, spec, sd = get_model(name)
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(53, 2, B, Tp)
-    monkeypatch.setenv("OU_RATE_SMALL", "0")
+    steer.set(rate_small=0)
     ref = run_enhance(model, mix, nz, n_steps=2)
     n_ref = model.launch_stats()
-    monkeypatch.delenv("OU_RATE_SMALL")
+    steer.unset("rate_small")
     out = run_enhance(model, mix, nz, n_steps=2)
     assert sum(model.launch_stats()) < sum(n_ref) or not spec.score.use_antialiasing
     for b in range(B):
@@ -581,20 +580,20 @@ def test_fused_first_rate_change_conv_matches_fir_pass_plus_conv(name, B, T, mon
 
 
 @pytest.mark.parametrize("name,B,T", [("PP16m", 3, 3000), ("PP16", 2, 8000), ("PP24", 1, 9000), ("OR16", 2, 5000)])
-def test_throughput_conv_kernel_matches_split_k_kernels(name, B, T, monkeypatch):
+def test_throughput_conv_kernel_matches_split_k_kernels(name, B, T, steer):
     """conv_direct3_kernel (no split-K, one 16 TM x 64 tile per wave over the whole reduction, 16x16x4 MFMA, stores
-    straight from the accumulators) takes the k3 / k5 layers of launches with many columns.  OU_TILE_MIN=0 forces it
-    onto every layer it fits (Cin % 16 == 0), OU_CONV_DIRECT=2 switches it off: same convolution, different summation
+    straight from the accumulators) takes the k3 / k5 layers of launches with many columns.  option tile_min = 0 forces it
+    onto every layer it fits (Cin % 16 == 0), option conv_direct = 2 switches it off: same convolution, different summation
     order -- and against the oracle like every other path."""
     model, spec, sd = get_model(name)
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(41, 3, B, Tp)
-    monkeypatch.setenv("OU_CONV_DIRECT", "2")
+    steer.set(conv_direct=2)
     ref = run_enhance(model, mix, nz, n_steps=3)
-    monkeypatch.setenv("OU_CONV_DIRECT", "3")
-    monkeypatch.setenv("OU_TILE_MIN", "0")
-    monkeypatch.setenv("OU_FUSE", "0")  # the fused ConvBlock bodies of the wide levels would hide those layers from it
+    steer.set(conv_direct=3)
+    steer.set(tile_min=0)
+    steer.set(fuse=0)  # the fused ConvBlock bodies of the wide levels would hide those layers from it
     out = run_enhance(model, mix, nz, n_steps=3)
     n_conv = model.launch_stats()[1]
     out2 = run_enhance(model, mix, nz, n_steps=3)
@@ -607,20 +606,20 @@ def test_throughput_conv_kernel_matches_split_k_kernels(name, B, T, monkeypatch)
 
 
 @pytest.mark.parametrize("name,B,T", [("PP16m", 3, 3000), ("PP16", 2, 8000), ("PP24", 1, 9000), ("OR16", 2, 5000), ("PP16", 4, 2077)])
-def test_minimal_filtering_throughput_kernel_matches_the_plain_one(name, B, T, monkeypatch):
+def test_minimal_filtering_throughput_kernel_matches_the_plain_one(name, B, T, steer):
     """conv_direct3w_kernel (no split-K, F(2, 3) / F(2, 5): a lane's four adjacent columns are two tile positions, 2 x 2 x (KW + 1)
-    MFMAs per ring slot instead of 2 x 4 x KW) forced onto every layer it fits (OU_TILE_MIN=0, unfused ConvBlock bodies) against
-    conv_direct3_kernel on the same layers (OU_CONV_DIRECT=4) and against the oracle.  Ragged lengths: partial column tiles,
+    MFMAs per ring slot instead of 2 x 4 x KW) forced onto every layer it fits (option tile_min = 0, unfused ConvBlock bodies) against
+    conv_direct3_kernel on the same layers (option conv_direct = 4) and against the oracle.  Ragged lengths: partial column tiles,
     shifted / masked windows under the input transform, rows that are not 16-byte multiples (no prefetched operand)."""
     model, spec, sd = get_model(name)
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(67, 3, B, Tp)
-    monkeypatch.setenv("OU_TILE_MIN", "0")
-    monkeypatch.setenv("OU_FUSE", "0")
-    monkeypatch.setenv("OU_CONV_DIRECT", "4")
+    steer.set(tile_min=0)
+    steer.set(fuse=0)
+    steer.set(conv_direct=4)
     ref = run_enhance(model, mix, nz, n_steps=3)
-    monkeypatch.delenv("OU_CONV_DIRECT")
+    steer.unset("conv_direct")
     out = run_enhance(model, mix, nz, n_steps=3)
     assert torch.equal(out, run_enhance(model, mix, nz, n_steps=3))
     assert not torch.equal(out, ref), "the minimal-filtering kernels did not run"
@@ -630,21 +629,21 @@ def test_minimal_filtering_throughput_kernel_matches_the_plain_one(name, B, T, m
 
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 2, 8000), ("PP24", 1, 9000), ("OR16", 2, 5000), ("PP16", 4, 2077), ("PP16", 1, 64000)])
-def test_bf16_split_kernel_matches_the_fp32_kernels(name, B, T, monkeypatch):
+def test_bf16_split_kernel_matches_the_fp32_kernels(name, B, T, steer):
     """conv_split_kernel (round 5): the stride-1 k3 / k5 convs on the BF16 matrix pipe, every fp32 operand as three bf16 pieces
     and six piece products per fp32 product (fp32-class accuracy: 1 dB BETTER than an fp32 fmaf chain against a double evaluation,
-    tools/ubench/split_conv.hip).  OU_SPLIT=1 forces it onto every layer that has the split weight copy (rows tile by 64; unfused
-    ConvBlock bodies so that the 64-channel levels are included), OU_SPLIT=0 keeps it off: same convolution, different arithmetic
+    tools/ubench/split_conv.hip).  option split = 1 forces it onto every layer that has the split weight copy (rows tile by 64; unfused
+    ConvBlock bodies so that the 64-channel levels are included), option split = 0 keeps it off: same convolution, different arithmetic
     path -- compared with each other and with the oracle.  Ragged lengths: partial column tiles, masked halo samples, rows that
     are not 16-byte multiples; PP24: 96 / 192 / 384 / 768 channels (row tiles of 64 and 128)."""
     model, spec, sd = get_model(name)
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(71, 3, B, Tp)
-    monkeypatch.setenv("OU_FUSE", "0")
-    monkeypatch.setenv("OU_SPLIT", "0")
+    steer.set(fuse=0)
+    steer.set(split=0)
     ref = run_enhance(model, mix, nz, n_steps=3)
-    monkeypatch.setenv("OU_SPLIT", "1")
+    steer.set(split=1)
     model.profile(True)
     out = run_enhance(model, mix, nz, n_steps=3)
     n_split = sum(1 for r in model.profile_read() if 800 <= r[3] < 1100)
@@ -659,11 +658,11 @@ def test_bf16_split_kernel_matches_the_fp32_kernels(name, B, T, monkeypatch):
 
 @pytest.mark.skipif(not experiments_built(), reason="conv_block3_kernel is in `make EXPERIMENTS=1` builds only")
 @pytest.mark.parametrize("T", [64000, 7213])
-def test_fused_deep_convblock_is_bit_identical(T, monkeypatch):
-    """OU_BLOCK3=1: the three body convs (k5, k3, k3) of the 256- / 512-channel ConvBlocks of UNIVERSE++ at batch 1 in ONE
+def test_fused_deep_convblock_is_bit_identical(T, steer):
+    """option block3 = 1: the three body convs (k5, k3, k3) of the 256- / 512-channel ConvBlocks of UNIVERSE++ at batch 1 in ONE
     launch (conv_block3_kernel: one time window per XCD, halo recomputed, a 32-workgroup barrier between the convs; off by
     default -- it is slower than three launches).  Same tile body, same K order: the enhanced signal is
-    bit-identical to the separate launches', with fewer launches; OU_DBG=64 forces the agent-scope release / acquire
+    bit-identical to the separate launches', with fewer launches; option dbg = 64 forces the agent-scope release / acquire
     hand-over that a group spanning XCDs would take."""
     model, spec, sd = get_model("PP16")
     mix = synth_mix(spec, 1, T)
@@ -671,13 +670,13 @@ def test_fused_deep_convblock_is_bit_identical(T, monkeypatch):
     nz = noise_list(43, 2, 1, Tp)
     ref = run_enhance(model, mix, nz, n_steps=2)
     n_ref = sum(model.launch_stats())
-    monkeypatch.setenv("OU_BLOCK3", "1")
+    steer.set(block3=1)
     out = run_enhance(model, mix, nz, n_steps=2)
     n_fused = sum(model.launch_stats())
     assert torch.equal(ref, out)
     if T == 64000:
         assert n_fused < n_ref  # (short signals: windows of < 64 frames are not taken)
-    monkeypatch.setenv("OU_DBG", "64")
+    steer.set(dbg=64)
     assert torch.equal(ref, run_enhance(model, mix, nz, n_steps=2))
 
 
@@ -706,19 +705,19 @@ def _d4_launches(model):
 
 @pytest.mark.parametrize("name,B,T", [("PP16", 1, 64000), ("PP16", 2, 23517), ("PP24", 1, 30011), ("OR16", 3, 9000),
                                       ("PP16m", 2, 3000), ("PP16", 4, 777)])
-def test_wide_load_1x1_kernel_matches_the_first_generation(name, B, T, monkeypatch):
+def test_wide_load_1x1_kernel_matches_the_first_generation(name, B, T, steer):
     """conv_direct4_kernel (16-byte operand loads, 16x16x4 MFMA, split-K over the waves where a layer has few tiles, one
     LDS-staged epilogue with 16-byte stores for every `up`) takes the 1x1 convs, the phase GEMMs of the transposed convs and
-    the k = s = r rate-change convs that conv_direct_kernel / conv_direct_strided_kernel had (OU_CONV_DIRECT=3): same
+    the k = s = r rate-change convs that conv_direct_kernel / conv_direct_strided_kernel had (option conv_direct = 3): same
     convolution, different summation order -- >= 100 dB end to end, and against the oracle like every other path.  Ragged
     lengths put partial column tiles, partial quads and (up = 5, M = 1280) channels that straddle two row tiles into play."""
     model, spec, sd = get_model(name)
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(53, 3, B, Tp)
-    monkeypatch.setenv("OU_CONV_DIRECT", "3")
+    steer.set(conv_direct=3)
     ref = run_enhance(model, mix, nz, n_steps=3)
-    monkeypatch.delenv("OU_CONV_DIRECT")
+    steer.unset("conv_direct")
     model.profile(True)
     out = run_enhance(model, mix, nz, n_steps=3)
     taken = _d4_launches(model)
@@ -735,8 +734,8 @@ def test_wide_load_1x1_kernel_matches_the_first_generation(name, B, T, monkeypat
 
 @pytest.mark.parametrize("shape", [20, 21, 22, 23, 40, 41, 42, 43])
 @pytest.mark.parametrize("name,B,T", [("PP16", 1, 8000), ("PP24", 2, 5000)])
-def test_every_tile_shape_of_the_wide_load_1x1_kernel(name, B, T, shape, monkeypatch):
-    """OU_D4_FORCE = 10 TM + log2(WK): that tile shape on every layer that admits it (channel groups divisible by WK x ring
+def test_every_tile_shape_of_the_wide_load_1x1_kernel(name, B, T, shape, steer):
+    """option d4_force = 10 TM + log2(WK): that tile shape on every layer that admits it (channel groups divisible by WK x ring
     depth), the launcher's own choice elsewhere -- all eight shapes (32 / 64 rows; reduction split over 1 / 2 / 4 / 8 waves)
     against the first-generation kernels on the same inputs."""
     if shape >= 40 and not experiments_built():
@@ -745,13 +744,44 @@ def test_every_tile_shape_of_the_wide_load_1x1_kernel(name, B, T, shape, monkeyp
     mix = synth_mix(spec, B, T)
     Tp = T + (spec.tot_ds - T % spec.tot_ds)
     nz = noise_list(59, 2, B, Tp)
-    monkeypatch.setenv("OU_CONV_DIRECT", "3")
+    steer.set(conv_direct=3)
     ref = run_enhance(model, mix, nz, n_steps=2)
-    monkeypatch.delenv("OU_CONV_DIRECT")
-    monkeypatch.setenv("OU_D4_FORCE", str(shape))
+    steer.unset("conv_direct")
+    steer.set(d4_force=shape)
     model.profile(True)
     out = run_enhance(model, mix, nz, n_steps=2)
     taken = _d4_launches(model)
     model.profile(False)
     assert taken.count(300 + shape) >= 4, (shape, sorted(set(taken)))
     record(f"direct4_shape{shape}_vs_gen1.{name}", O.si_sdr(ref, out), 100)
+
+
+def test_options_are_typed_and_echoed_by_the_plan():
+    """ou_set_option / ou_get_option / ou_reset_options: unknown keys, non-integers and -- in the default build -- the switches
+    that make a call return wrong results by design are refused; ou_plan_json echoes the current values; a fork (lane) inherits
+    its primary model's options."""
+    import json
+
+    from open_universe_amd import _lib
+
+    model, spec, sd = get_model("PP16s")
+    assert model.options() == _lib.option_defaults()
+    with pytest.raises(KeyError):
+        model.set_option("no_such_option", 1)
+    with pytest.raises(ValueError):
+        model.set_option("conv_direct", 1.5)
+    if not experiments_built():
+        for k in ("dbg", "dbg_dec0"):
+            with pytest.raises(NotImplementedError):
+                model.set_option(k, 1)
+    try:
+        model.set_option("split", 0)
+        model.set_option("tile_min", 0.5)
+        plan = json.loads(model._L.ou_plan_json(model._handle).decode())
+        assert plan["options"]["split"] == 0 and plan["options"]["tile_min"] == 0.5 and plan["options"]["conv_direct"] == 5
+        assert len(plan["convs"]) > 50
+        twin = model.fork()
+        assert twin.get_option("split") == 0 and twin.get_option("tile_min") == 0.5
+    finally:
+        model.reset_options()
+    assert model.options() == _lib.option_defaults()

@@ -189,3 +189,30 @@ def test_default_build_carries_no_experiment_kernels(built_lib):
         assert name not in blob, name
     # conv_mfma_kernel<TM, TN, WM, WN, WK, ...>: no instantiation with a 4-way split of the reduction (WK = 4)
     assert b"conv_mfma_kernelILi1ELi2ELi1ELi1ELi4E" not in blob and b"conv_mfma_kernelILi1ELi1ELi1ELi1ELi4E" not in blob
+
+
+def test_library_reads_no_environment_variable(built_lib):
+    """Since ABI 5 every tuning / test switch is a typed option of the handle (ou_set_option, include/ouniverse.h); the shared
+    library does not import getenv at all, so nothing outside the caller's code can change which kernels run or what they
+    compute.  The option table is self-describing: unique keys, a one-line description and a default each."""
+    import os
+    import subprocess
+
+    so = os.path.join(os.path.dirname(__file__), "..", "open-universe_amd", "lib", "libouniverse.so")
+    und = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und and "environ" not in und
+    names = _lib.option_names()
+    dflt = _lib.option_defaults()
+    assert len(names) == built_lib.ou_option_count() >= 25 and set(names) == set(dflt)
+    assert all(len(doc) > 10 for doc in names.values())
+    assert dflt["conv_direct"] == 5 and dflt["split"] == -1 and dflt["wino"] == 1 and dflt["gru_dbg"] == 0 and dflt["dbg"] == 0
+    assert built_lib.ou_option_name(-1) is None and built_lib.ou_option_name(len(names)) is None
+    # the Python side reads exactly two variables of its own, and the rendezvous / launcher variables of torch.distributed
+    pkg = os.path.join(os.path.dirname(__file__), "..", "open-universe_amd")
+    seen = set()
+    import re
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                seen |= set(re.findall(r"[\"'](OU_[A-Z_]+)[\"']", open(os.path.join(root, f)).read()))
+    assert seen <= {"OU_LIBRARY", "OU_UNSAFE_PICKLE", "OU_", "OU_CHAIN_TS"}, seen

@@ -7,6 +7,7 @@ import torch
 from ctypes import byref, c_size_t
 from helpers import get_spec, synth_mix
 from open_universe_amd import Universe, state_dict as S, _lib
+from open_universe_amd.universe import Universe as _U; _U.steer_from_env = True  # tools only: OU_<OPTION>=v env vars -> ou_set_option
 name = sys.argv[1] if len(sys.argv) > 1 else "score.dec3"
 nblk, nw = int(sys.argv[2]), int(sys.argv[3])
 os.environ["OU_CHAIN_TS"] = name

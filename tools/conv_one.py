@@ -8,6 +8,7 @@ import torch
 from ctypes import byref, c_float, c_int32, c_size_t, c_void_p
 from helpers import get_spec
 from open_universe_amd import Universe, state_dict as S, _lib
+from open_universe_amd.universe import Universe as _U; _U.steer_from_env = True  # tools only: OU_<OPTION>=v env vars -> ou_set_option
 layer, Tin, iters = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 name = sys.argv[4] if len(sys.argv) > 4 else "PP16"
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 1

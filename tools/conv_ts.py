@@ -7,6 +7,7 @@ import torch, ctypes
 from ctypes import byref, c_float, c_int32, c_size_t, c_void_p
 from helpers import get_spec
 from open_universe_amd import Universe, state_dict as S, _lib
+from open_universe_amd.universe import Universe as _U; _U.steer_from_env = True  # tools only: OU_<OPTION>=v env vars -> ou_set_option
 spec = get_spec("PP16")
 model = Universe(spec, state_dict=S.synthetic_state_dict(spec, 0), device="cuda:0")
 p = "_edm_model"

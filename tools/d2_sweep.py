@@ -8,6 +8,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import torch
 from helpers import get_spec
 from open_universe_amd import Universe, state_dict as S
+from open_universe_amd.universe import Universe as _U; _U.steer_from_env = True  # tools only: OU_<OPTION>=v env vars -> ou_set_option
 
 name = sys.argv[1] if len(sys.argv) > 1 else "PP16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1

@@ -5,6 +5,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 import torch
 from helpers import get_spec, synth_mix
 from open_universe_amd import Universe, state_dict as S
+from open_universe_amd.universe import Universe as _U; _U.steer_from_env = True  # tools only: OU_<OPTION>=v env vars -> ou_set_option
 name, B, bmax, frames = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
 if bmax != "0":
     os.environ["OU_GRU_BMAX"] = bmax

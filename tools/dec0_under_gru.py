@@ -10,6 +10,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import torch
 from helpers import get_spec
 from open_universe_amd import UniverseGAN, state_dict as S
+from open_universe_amd.universe import Universe as _U; _U.steer_from_env = True  # tools only: OU_<OPTION>=v env vars -> ou_set_option
 spec = get_spec("PP16")
 model = UniverseGAN(spec, state_dict=S.synthetic_state_dict(spec, 0), device="cuda:0")
 T = 64160

@@ -6,6 +6,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import torch
 from helpers import get_spec, synth_mix
 from open_universe_amd import Universe, state_dict as S
+from open_universe_amd.universe import Universe as _U; _U.steer_from_env = True  # tools only: OU_<OPTION>=v env vars -> ou_set_option
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import restatement as O
 

@@ -12,6 +12,7 @@ import torch
 import restatement as O
 from helpers import get_spec, synth_mix
 from open_universe_amd import Universe, state_dict as S
+from open_universe_amd.universe import Universe as _U; _U.steer_from_env = True  # tools only: OU_<OPTION>=v env vars -> ou_set_option
 
 
 def cmp(name, ref, got):

@@ -13,7 +13,7 @@ probe() {  # name, env..., --, command...
 {
 echo "== GPU_MAX_HW_QUEUES = 2 (rc=124: killed by the 90 s timeout, rc=139: segmentation fault)"
 probe hwq2_bench_default        GPU_MAX_HW_QUEUES=2 timeout 90 python bench.py $BQ
-probe hwq2_bench_no_overlap     GPU_MAX_HW_QUEUES=2 OU_NO_OVERLAP=1 timeout 90 python bench.py $BQ
+probe hwq2_bench_no_overlap     GPU_MAX_HW_QUEUES=2 timeout 90 python bench.py --option no_overlap=1 $BQ
 probe hwq2_bench_no_graph       GPU_MAX_HW_QUEUES=2 OU_BENCH_NO_GRAPH=1 timeout 90 python bench.py $BQ
 probe hwq1_bench_no_graph       GPU_MAX_HW_QUEUES=1 OU_BENCH_NO_GRAPH=1 timeout 90 python bench.py $BQ
 probe hwq4_bench_default        GPU_MAX_HW_QUEUES=4 timeout 90 python bench.py $BQ

@@ -11,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import torch  # noqa: E402
 from helpers import get_spec, synth_mix  # noqa: E402
 from open_universe_amd import Universe, UniverseGAN, distributed as D, state_dict as S  # noqa: E402
+from open_universe_amd.universe import Universe as _U; _U.steer_from_env = True  # tools only: OU_<OPTION>=v env vars -> ou_set_option
 
 name = sys.argv[1] if len(sys.argv) > 1 else "PP16"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 32

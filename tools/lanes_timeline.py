@@ -12,6 +12,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import torch  # noqa: E402
 from helpers import get_spec, synth_mix  # noqa: E402
 from open_universe_amd import UniverseGAN, distributed as D, state_dict as S  # noqa: E402
+from open_universe_amd.universe import Universe as _U; _U.steer_from_env = True  # tools only: OU_<OPTION>=v env vars -> ou_set_option
 from open_universe_amd.lanes import LanePool  # noqa: E402
 
 K, n = int(sys.argv[1]), int(sys.argv[2])

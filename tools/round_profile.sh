@@ -24,10 +24,10 @@ PY
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- \
   python bench.py --sustained-s 0 --in-flight "" --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_under_rocprof.json 2> $O/rocprof.err
 python tools/kstats.py $O/prof/bench_kernel_trace.csv | head -16 | tee $O/kstats_PP16_B1.txt
-# the same command as ONE serial chain (OU_NO_OVERLAP=1: no side streams inside the call) -- every kernel alone on the device;
+# the same command as ONE serial chain (option no_overlap = 1: no side streams inside the call) -- every kernel alone on the device;
 # the default run above times the first score-encoder pass beside the conditioner, like bench.py's own per-launch pass does
-OU_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -o bench -- \
-  python bench.py --sustained-s 0 --in-flight "" --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_under_rocprof_serial.json 2>> $O/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -o bench -- \
+  python bench.py --option no_overlap=1 --sustained-s 0 --in-flight "" --steps 10 --warmup 2 --no-cpu-baseline --batch-sweep "" > $O/bench_under_rocprof_serial.json 2>> $O/rocprof.err
 python tools/kstats.py $O/prof_serial/bench_kernel_trace.csv | head -16 | tee $O/kstats_PP16_B1_serial.txt
 rm -rf $O/prof_serial
 # the other BASELINE configurations (per-GPU shapes): C3 PP16 64 steps B=4, C4 OR16 32 steps B=16, C5 PP24 varlen B=8
@@ -124,7 +124,7 @@ timeout 600 python tools/split_clock.py 4 2>&1 | grep -v amdgpu.ids > $O/split_c
 Q="--sustained-s 0 --in-flight= --no-cpu-baseline --batch-sweep= --profile-steps 0"
 for s in 0 -1 0 -1; do
   for cfg in "--batch 16 --steps 5 --warmup 1" "--batch 32 --steps 3 --warmup 1" "--model OR16 --batch 16 --n_steps 32 --steps 3 --warmup 1"; do
-    echo "OU_SPLIT=$s $cfg: $(OU_SPLIT=$s timeout 600 python bench.py $Q $cfg 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print("%.2f ms per step, %.1f utt/s" % (d["ms_per_step"], d["utterances_per_s"]))')"
+    echo "OU_SPLIT=$s $cfg: $(timeout 600 python bench.py --option split=$s $Q $cfg 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print("%.2f ms per step, %.1f utt/s" % (d["ms_per_step"], d["utterances_per_s"]))')"
   done
 done > $O/split_ab.txt 2>&1; cat $O/split_ab.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/cumask_probe tools/ubench/cumask_probe.hip 2>> $O/rocprof.err && timeout 120 /tmp/cumask_probe > $O/cumask_probe.txt 2>&1
