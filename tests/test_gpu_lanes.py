@@ -230,11 +230,11 @@ def test_lanes_with_groups_of_different_batch_sizes_full_size(lanes):
     model, spec, sd = get_model("PP16")
     lens = [32000] * 4 + [24000] * 2 + [28000] + [20000] * 4 + [16000] * 2 + [12000] + [36000] * 4 + [8000] * 2 + [10000]
     sigs = [synth_mix(spec, 1, n, seed=700 + i)[0] for i, n in enumerate(lens)]
-    groups = D.plan_batches([int(s.shape[-1]) for s in sigs], list(range(len(sigs))), 4)
-    assert sorted({len(g) for g in groups}) == [1, 2, 4]
-    serial = D.enhance_sharded(model, sigs, seed=6, n_steps=2, batch_size=4)
-    flying = D.enhance_sharded(model, sigs, seed=6, n_steps=2, batch_size=4, in_flight=lanes)   # raises on a time-out
-    again = D.enhance_sharded(model, sigs, seed=6, n_steps=2, batch_size=4, in_flight=lanes)
+    groups = D.plan_batches([int(s.shape[-1]) for s in sigs], list(range(len(sigs))), 4, equal_only=True)
+    assert sorted({len(g) for g in groups}) == [1, 2, 4]  # (equal_only: the grouping that yields calls of three sizes)
+    serial = D.enhance_sharded(model, sigs, seed=6, n_steps=2, batch_size=4, equal_only=True)
+    flying = D.enhance_sharded(model, sigs, seed=6, n_steps=2, batch_size=4, in_flight=lanes, equal_only=True)   # raises on a time-out
+    again = D.enhance_sharded(model, sigs, seed=6, n_steps=2, batch_size=4, in_flight=lanes, equal_only=True)
     st = model.gru_exchange_stats()
     assert st["lost"] == 0, st
     from helpers import worst
