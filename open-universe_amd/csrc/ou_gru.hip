@@ -386,6 +386,13 @@ constexpr unsigned GRU_EPOCH_WRAP = 0x7F000000u;  // past this the last block of
 // wave's two stores are acknowledged after ~230 cycles; one isolated 8-byte load, sc1 or plain, quiet or just-written line,
 // takes ~320 cycles; every cycle a wave spends between its publish and its poll comes back one-to-one in everybody's step
 // time -- the clusters run in lock step, the step is compute + one store latency + one load latency + the skew of 64-128 waves.)
+// Gate pre-activations are carried PRE-SCALED through the ring kernel: S (a) for the sigmoids, T (y) for the tanh, with
+//   sigmoid(a) = 1 / (1 + 2^(S a)),  S = -log2(e);    tanh(y) = 1 - 2 / (1 + 2^(T y)),  T = 2 log2(e)
+// -- the recurrent weights and b_hn are scaled once per launch when they are gathered into registers, the input projections when
+// a chunk is staged into LDS, and x_r / x_z / b_hn enter as the INITIAL VALUE of the fin lane's partial sums: the serial
+// chain of a step behind the gather (it is instruction latency, one wave per SIMD: 505 cycles in round 5) loses the scale
+// multiplies, the bias adds and -- with explicit fmas -- three more dependent operations.
+constexpr float kGateS = -1.44269504088896341f, kGateT = 2.88539008177792681f;
 template <int HB, int UPW, bool WIDE = false>
 __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters) {
   constexpr int H = 64 * HB, NT = 256, LPU = NT / UPW, NC = WIDE ? HB : H / LPU, NI = WIDE ? HB / 2 : NC / 4, NWG = H / UPW;
@@ -429,8 +436,8 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
           const float2 vr = *reinterpret_cast<const float2*>(wd + 128 * i);
           const float2 vz = *reinterpret_cast<const float2*>(wd + (size_t)H * H + 128 * i);
           const float2 vn = *reinterpret_cast<const float2*>(wd + (size_t)2 * H * H + 128 * i);
-          wrz[u * HB + 2 * i] = f32x2{vr.x, vz.x}; wrz[u * HB + 2 * i + 1] = f32x2{vr.y, vz.y};
-          wn[u * HB + 2 * i] = vn.x; wn[u * HB + 2 * i + 1] = vn.y;
+          wrz[u * HB + 2 * i] = f32x2{vr.x, vz.x} * kGateS; wrz[u * HB + 2 * i + 1] = f32x2{vr.y, vz.y} * kGateS;
+          wn[u * HB + 2 * i] = vn.x * kGateT; wn[u * HB + 2 * i + 1] = vn.y * kGateT;
         }
       }
     } else {
@@ -440,15 +447,15 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
         const float4 vr = *reinterpret_cast<const float4*>(wd + 4 * LPU * i);
         const float4 vz = *reinterpret_cast<const float4*>(wd + (size_t)H * H + 4 * LPU * i);
         const float4 vn = *reinterpret_cast<const float4*>(wd + (size_t)2 * H * H + 4 * LPU * i);
-        wrz[4 * i + 0] = f32x2{vr.x, vz.x}; wrz[4 * i + 1] = f32x2{vr.y, vz.y};
-        wrz[4 * i + 2] = f32x2{vr.z, vz.z}; wrz[4 * i + 3] = f32x2{vr.w, vz.w};
-        wn[4 * i + 0] = vn.x; wn[4 * i + 1] = vn.y; wn[4 * i + 2] = vn.z; wn[4 * i + 3] = vn.w;
+        wrz[4 * i + 0] = f32x2{vr.x, vz.x} * kGateS; wrz[4 * i + 1] = f32x2{vr.y, vz.y} * kGateS;
+        wrz[4 * i + 2] = f32x2{vr.z, vz.z} * kGateS; wrz[4 * i + 3] = f32x2{vr.w, vz.w} * kGateS;
+        wn[4 * i + 0] = vn.x * kGateT; wn[4 * i + 1] = vn.y * kGateT; wn[4 * i + 2] = vn.z * kGateT; wn[4 * i + 3] = vn.w * kGateT;
       }
     }
     // the lane that ends up with the unit's gate sums: any lane of a 8 / 16-lane group (all-reduce), the upper row of a
     // 32-lane group (row_bcast:15 adds the lower row's total into the upper row only)
     const bool fin = cg == (LPU == 32 ? 16 : 0);
-    const float bhn = p.bhn[dir * H + unit];
+    const float bhn = p.bhn[dir * H + unit] * kGateT;
     const float* gxb = p.gx + ((size_t)b * 6 * H + (size_t)dir * 3 * H) * T;
     const size_t orow = ((size_t)b * 2 * H + (size_t)dir * H + unit) * T;
     unsigned long long* xq = p.xchg + (size_t)cluster * CSTRIDE;
@@ -503,14 +510,23 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
         park[j] = (s_src && sidx < T) ? s_src[tt] : 0.f;
       }
     };
+    // (the pre-activations are staged PRE-SCALED for the exp2-based gates -- off the per-step chain: see the gate math below)
+    const float s_scale = s_kind == 3 ? 1.0f : (s_kind == 2 ? kGateT : kGateS);
     auto park_to_lds = [&](int c) {
 #pragma unroll
-      for (int j = 0; j < PER; j++) stage[wv][c & 1][srow][sq * PER + j] = park[j];
+      for (int j = 0; j < PER; j++) stage[wv][c & 1][srow][sq * PER + j] = park[j] * s_scale;
     };
     fetch_chunk(0);
     park_to_lds(0);
     fetch_chunk(1);
     const int ulw = ul - wv * UW;                  // this lane's unit within its wave
+    // 1 on the fin lane of unit u of this wave, 0 on every other lane -- and T b_hn there: what the lane's partial sums start from
+    float sel[WIDE ? UW : 1], inn[WIDE ? UW : 1];
+#pragma unroll
+    for (int u = 0; u < (WIDE ? UW : 1); u++) {
+      sel[u] = (fin && (!WIDE || ulw == u)) ? 1.0f : 0.0f;
+      inn[u] = sel[u] * bhn;
+    }
     float hprev = 0.f;
     int t = dir ? T - 1 : 0;
     const int dt = dir ? -1 : 1;
@@ -530,8 +546,19 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
       float xr = 0.f, xz = 0.f, xn = 0.f, rs = 0.f;
       if (fin) {
         const float* sp = &stage[wv][cidx & 1][ulw * 4][soff];
-        xr = sp[0]; xz = sp[CH]; xn = sp[2 * CH]; rs = sp[3 * CH];
+        xr = sp[0]; xz = sp[CH]; xn = sp[2 * CH]; rs = sp[3 * CH];  // (pre-scaled: S x_r, S x_z, T x_n)
       }
+      // initial values of this lane's partial sums (computed here, under the gather): every lane's partial for unit u ends up
+      // in unit u's total, so the fin lane of unit u contributes S x_r, S x_z and T b_hn through its own
+      f32x2 irz[WIDE ? WU : 1];
+      if constexpr (WIDE) {
+#pragma unroll
+        for (int u = 0; u < WU; u++) irz[u] = f32x2{xr, xz} * sel[u];  // (x 1 on the fin lane of unit u, x 0 elsewhere: exact)
+      } else {
+        irz[0] = f32x2{xr, xz};  // (0 on the lanes that are not fin)
+      }
+#pragma unroll
+      for (int u = 0; u < (WIDE ? WU : 1); u++) asm volatile("" : "+v"(irz[u]));  // pinned in front of the gather's loads
       // ---- h_step: zero at step 0, else gathered from the parity buffer (all granules must carry tag epoch + step)
       u32x4 hv[NC / 2];
       if (step == 0) {
@@ -661,30 +688,35 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
       float hs[3];
       if constexpr (WIDE) {
         // 3 WU partial sums (unit u of the wave x gate) over this lane's HB columns
+        constexpr int HU = WU / 2;
         f32x2 arz[WU];
-        float an[WU];
+        f32x2 an2[HU];  // the n sums of units u and u + HU as one packed pair: half the FMA instructions
 #pragma unroll
-        for (int u = 0; u < WU; u++) { arz[u] = f32x2{0.f, 0.f}; an[u] = 0.f; }
+        for (int u = 0; u < WU; u++) arz[u] = irz[u];
+#pragma unroll
+        for (int u = 0; u < HU; u++) an2[u] = f32x2{inn[u], inn[u + HU]};
 #pragma unroll
         for (int k = 0; k < NC / 2; k++) {
           const float h0 = __uint_as_float(hv[k].x), h1 = __uint_as_float(hv[k].z);
 #pragma unroll
           for (int u = 0; u < WU; u++) {
             arz[u] = __builtin_elementwise_fma(wrz[u * HB + 2 * k], f32x2{h0, h0}, arz[u]);
-            an[u] = fmaf(wn[u * HB + 2 * k], h0, an[u]);
             arz[u] = __builtin_elementwise_fma(wrz[u * HB + 2 * k + 1], f32x2{h1, h1}, arz[u]);
-            an[u] = fmaf(wn[u * HB + 2 * k + 1], h1, an[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < HU; u++) {
+            an2[u] = __builtin_elementwise_fma(f32x2{wn[u * HB + 2 * k], wn[(u + HU) * HB + 2 * k]}, f32x2{h0, h0}, an2[u]);
+            an2[u] = __builtin_elementwise_fma(f32x2{wn[u * HB + 2 * k + 1], wn[(u + HU) * HB + 2 * k + 1]}, f32x2{h1, h1}, an2[u]);
           }
         }
         // fold 64 -> 32 lanes: units u and u + WU / 2 trade halves; lanes < 32 keep the lower units, lanes >= 32 the upper ones
-        constexpr int HU = WU / 2;
         f32x2 rz01[HU];
         float n01[HU];
 #pragma unroll
         for (int u = 0; u < HU; u++) {
           const auto sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(arz[u].x), __float_as_uint(arz[u + HU].x), false, false);
           const auto sz = __builtin_amdgcn_permlane32_swap(__float_as_uint(arz[u].y), __float_as_uint(arz[u + HU].y), false, false);
-          const auto sn = __builtin_amdgcn_permlane32_swap(__float_as_uint(an[u]), __float_as_uint(an[u + HU]), false, false);
+          const auto sn = __builtin_amdgcn_permlane32_swap(__float_as_uint(an2[u].x), __float_as_uint(an2[u].y), false, false);
           rz01[u] = f32x2{__uint_as_float(sr[0]), __uint_as_float(sz[0])} + f32x2{__uint_as_float(sr[1]), __uint_as_float(sz[1])};
           n01[u] = __uint_as_float(sn[0]) + __uint_as_float(sn[1]);
         }
@@ -700,8 +732,8 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
           hs[0] = rz01[0].x; hs[1] = rz01[0].y; hs[2] = n01[0];
         }
       } else {
-        f32x2 arz0 = {0.f, 0.f}, arz1 = {0.f, 0.f};
-        float an0 = 0.f, an1 = 0.f;
+        f32x2 arz0 = irz[0], arz1 = {0.f, 0.f};
+        float an0 = inn[0], an1 = 0.f;
 #pragma unroll
         for (int k = 0; k < NC / 2; k++) {
           const float h0 = __uint_as_float(hv[k].x), h1 = __uint_as_float(hv[k].z);
@@ -722,10 +754,11 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
       }
 
       if (fin) {
-        const float r = sigmoidf_(xr + hs[0]);
-        const float z = sigmoidf_(xz + hs[1]);
-        const float n = tanhf_(xn + r * (hs[2] + bhn));
-        const float hnew = (hprev - n) * z + n;
+        // hs[0] = S (x_r + W_hr h), hs[1] = S (x_z + W_hz h), hs[2] = T (W_hn h + b_hn), xn = T x_n   (see kGateS / kGateT)
+        const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(hs[0]));
+        const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(hs[1]));
+        const float n = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(r, hs[2], xn))), 1.0f);
+        const float hnew = fmaf(hprev - n, z, n);
         hprev = hnew;
         {  // publish first: everybody is waiting on this
           const unsigned long long gran =
