@@ -550,20 +550,26 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
       }
       // initial values of this lane's partial sums (computed here, under the gather): every lane's partial for unit u ends up
       // in unit u's total, so the fin lane of unit u contributes S x_r, S x_z and T b_hn through its own
+      // The lane's partial sums start from these (x 1 on the fin lane of unit u, x 0 elsewhere: exact).  Formed BEHIND the issue
+      // of the gather's loads, under their latency: in front of them the wait for the LDS reads above sits between this wave's
+      // publish and its poll -- measured: +80 cycles per step, the whole gain of the shorter chain and more (round 6, A / B).
       f32x2 irz[WIDE ? WU : 1];
-      if constexpr (WIDE) {
+      auto form_init = [&]() {
+        if constexpr (WIDE) {
 #pragma unroll
-        for (int u = 0; u < WU; u++) irz[u] = f32x2{xr, xz} * sel[u];  // (x 1 on the fin lane of unit u, x 0 elsewhere: exact)
-      } else {
-        irz[0] = f32x2{xr, xz};  // (0 on the lanes that are not fin)
-      }
+          for (int u = 0; u < WU; u++) irz[u] = f32x2{xr, xz} * sel[u];
+        } else {
+          irz[0] = f32x2{xr, xz};  // (0 on the lanes that are not fin)
+        }
 #pragma unroll
-      for (int u = 0; u < (WIDE ? WU : 1); u++) asm volatile("" : "+v"(irz[u]));  // pinned in front of the gather's loads
+        for (int u = 0; u < (WIDE ? WU : 1); u++) asm volatile("" : "+v"(irz[u]));  // pinned between the loads and their wait
+      };
       // ---- h_step: zero at step 0, else gathered from the parity buffer (all granules must carry tag epoch + step)
       u32x4 hv[NC / 2];
       if (step == 0) {
 #pragma unroll
         for (int k = 0; k < NC / 2; k++) hv[k] = u32x4{0u, 0u, 0u, 0u};
+        form_init();
       } else {
         const unsigned want = epoch + (unsigned)step;
         const unsigned long long* src = xq + (size_t)(step & 1) * H + (WIDE ? 2 * lane : cg * 4);
@@ -610,6 +616,7 @@ __global__ __launch_bounds__(256) void gru_ring_kernel(GruArgs p, int nclusters)
                            : "=v"(hv[2 * i + 1]) : "v"(src), "n"(4 * LPU * i * 8 + 16) : "memory");
             }
           }
+          form_init();
           gather_wait(hv);
           // all tags arrived <=> the smallest one is the wanted one: stale granules always carry SMALLER tags (tags are
           // monotonic per exchange area; a larger one could only come from a buffer that ou_workspace_init has not prepared,
