@@ -327,6 +327,8 @@ struct Runner {
     a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct; a.d4_fir_unfused = env.d4_fir; a.d4_force = env.d4_force; a.d4_short = env.d4_short; a.deep_factor = env.deep_factor; a.d2_wk = env.d2_wk; a.wino = env.wino; a.d2_map = env.d2_map;
     a.tile_min = env.tile_min; a.tile_prefetch = env.tile_prefetch;
     a.tstamps = h->tstamps;
+    // ragged batch: the kernel keeps "zero behind the row's own end" in its epilogue where its family can (conv_masks_rows)
+    if (ragged && env.mask_fused && !e.no_mask) a.lens = lens_of(Tout);
     if (collect) { collect->push_back(a); return out; }
     int cfg = -1;
     if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {
@@ -361,7 +363,7 @@ struct Runner {
     }
     if (a.prof) h->prof.back().cfg = cfg;
     h->last_cfg = cfg;
-    if (!e.no_mask) mask(out);
+    if (!e.no_mask && !(a.lens && conv_masks_rows(cfg))) mask(out);
     if (h->trace)
       std::fprintf(stderr, "OU_TRACE conv %-64s cfg=%d M=%d Nq=%d K=%d(Cin=%d KW=%d CK=%d) stride=%d up=%d B=%d MFLOP=%.1f\n",
                    name.c_str(), cfg, L.M, Nq, L.Cin * L.KW, L.Cin, L.KW, L.CK, L.stride, L.up, B,
@@ -459,9 +461,12 @@ struct Runner {
           if (!done) {
             conv(Bk.rc, hin, nm + ".upc", Epi(), &u);
             if (ok())
+            {
+              const int* ln = env.mask_fused ? lens_of(u.T) : nullptr;
               chk(launch_fir(u.p, W(Bk.rc.fir_off), Bk.rc.fir_len, 0.f, 0, W(Bk.rc.fbias_off), res, kInvSqrt2, hu.p, B,
-                             u.C, u.T, st), "fir(up)");
-            mask(hu);
+                             u.C, u.T, st, ln), "fir(up)");
+              if (!ln) mask(hu);
+            }
           }
         }
       } else {
@@ -735,9 +740,12 @@ void run_condition(Runner& r, Persist& P, const float* mix_norm, int T) {
   r.st = main;
   // --- input conv + encoder  condition.py:360, 189-206
   Tensor e0 = r.alloc("cond.in", m.C0, T);
-  if (!r.dry && r.ok())
-    r.chk(launch_in_conv(mix_norm, r.W(m.c_in.w_off), r.W(m.c_in.b_off), nullptr, 0, e0.p, r.B, m.C0, T, m.c_in.KW, r.st), "cond.in");
-  r.mask(e0);
+  {
+    const int* ln = r.env.mask_fused ? r.lens_of(T) : nullptr;
+    if (!r.dry && r.ok())
+      r.chk(launch_in_conv(mix_norm, r.W(m.c_in.w_off), r.W(m.c_in.b_off), nullptr, 0, e0.p, r.B, m.C0, T, m.c_in.KW, r.st, ln), "cond.in");
+    if (!ln) r.mask(e0);
+  }
   Tensor hcur = e0;
   std::vector<Tensor> outs;
   for (int i = 0; i < m.n_blocks; i++) {
@@ -804,10 +812,13 @@ ScoreEnc run_score_enc(Runner& r, Persist& P, const float* x, const StepCoef* co
   ScoreEnc E;
   Tensor e0 = r.alloc("score.in", m.C0, T);
   // the w_in scaling of the EDM wrapper (universe.py:199,202) rides on the input conv
-  if (!r.dry && r.ok())
-    r.chk(launch_in_conv(x, r.W(m.s_in.w_off), r.W(m.s_in.b_off), coef, coef_bs, e0.p, r.B, m.C0, T, m.s_in.KW, r.st),
-          "score.in");
-  r.mask(e0);
+  {
+    const int* ln = r.env.mask_fused ? r.lens_of(T) : nullptr;
+    if (!r.dry && r.ok())
+      r.chk(launch_in_conv(x, r.W(m.s_in.w_off), r.W(m.s_in.b_off), coef, coef_bs, e0.p, r.B, m.C0, T, m.s_in.KW, r.st, ln),
+            "score.in");
+    if (!ln) r.mask(e0);
+  }
   Tensor hcur = e0;
   for (int i = 0; i < m.n_blocks; i++) {
     const float* fr = film_row ? film_row + m.film.enc_off[i] : nullptr;
@@ -833,10 +844,11 @@ void run_score_dec(Runner& r, Persist& P, const ScoreEnc& E, const float* x, con
     auto bo = r.block(m.s_dec[j], y, "score.dec" + std::to_string(j), fr, film_bs, P.sc[j].p, resp);
     y = bo.v;
   }
+  const int* ln = r.env.mask_fused ? r.lens_of(T) : nullptr;
   if (!r.dry && r.ok())
     r.chk(launch_out_conv(y.p, r.W(m.s_out.w_off), r.W(m.s_out.b_off), r.W(m.s_out.a_off), x, noise, out, coef,
-                          coef_bs, m.cfg.has_edm, mode, r.B, m.C0, T, m.s_out.KW, r.st), "score.out");
-  r.mask(out, 1, T);
+                          coef_bs, m.cfg.has_edm, mode, r.B, m.C0, T, m.s_out.KW, r.st, ln), "score.out");
+  if (!ln) r.mask(out, 1, T);
 }
 static bool m_blocks_ok(const Runner& r) { return r.h->m.n_blocks >= 1 && r.h->m.s_dec[0].dir == 0; }
 void run_score(Runner& r, Persist& P, const float* x, const float* noise, float* out, int mode,

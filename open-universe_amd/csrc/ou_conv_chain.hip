@@ -812,10 +812,11 @@ __global__ __launch_bounds__(64 * MT * NWN) void rate_down_kernel(ConvArgs p) {
   // ---- epilogue
   const int q = q0 + 32 * wn + l31;
   if (q < p.Nq) {
+    const bool live = q < ragged_len(p.lens, b);  // (ragged batch: zero behind the row's own end)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int m = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-      if (m < p.M) p.y[((size_t)b * p.Cout + m) * p.Nq + q] = acc[r] + p.bias[m];
+      if (m < p.M) p.y[((size_t)b * p.Cout + m) * p.Nq + q] = live ? acc[r] + p.bias[m] : 0.f;
     }
   }
   if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -898,6 +899,7 @@ __global__ __launch_bounds__(64 * MT * NWN) void rate_up_kernel(ConvArgs p) {
 #pragma unroll
   for (int j = 0; j <= 2 * R; j++) f[j] = fir ? p.fir[j] : 0.f;
   const int Cout = p.Cout;
+  const int rlen = ragged_len(p.lens, b);  // ragged batch: valid output samples of this row
   const int span = BV * R;  // output samples per channel
   const int total = Cout * span;
   // Rows that are 16-byte multiples: four consecutive samples per thread -- one float4 of the residual in, one float4 out
@@ -944,6 +946,7 @@ __global__ __launch_bounds__(64 * MT * NWN) void rate_up_kernel(ConvArgs p) {
         if (p.res) v = (v + rs4[u][s4]) * p.res_scale;
         o[s4] = v;
       }
+      if (p.lens) o = ragged_mask4(o, q0 * R + tl4[u], rlen);
       *reinterpret_cast<f32x4*>(p.y + idx4[u]) = o;
     }
     if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -986,6 +989,7 @@ __global__ __launch_bounds__(64 * MT * NWN) void rate_up_kernel(ConvArgs p) {
       }
       v += p.bias[co_[u]];
       if (p.res) v = (v + rs[u]) * p.res_scale;
+      if (q0 * R + tl_[u] >= rlen) v = 0.f;
       p.y[idx[u]] = v;
     }
   }

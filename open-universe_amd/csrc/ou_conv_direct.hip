@@ -58,6 +58,7 @@ struct DirectEpilogue {
     constexpr int LBN = (BN == 64) ? 6 : 5, MB = (32 / R) * R, NTAP = 2 * R + 1;
     constexpr int SPAN = (BN - 2) * R;             // output samples per channel of this tile
     constexpr int TOTAL = (MB / R) * SPAN, EPT = (TOTAL + NT - 1) / NT;
+    const int rlen = ragged_len(p.lens, (int)(ybase / ((size_t)p.Cout * p.Tout)));  // ragged batch: this row's valid samples
     float f[NTAP];
 #pragma unroll
     for (int j = 0; j < NTAP; j++) f[j] = p.fir[j];
@@ -102,6 +103,7 @@ struct DirectEpilogue {
       }
       acc += bi[k];
       if (p.res) acc = (acc + rs[k]) * p.res_scale;
+      if (p.lens && (long)n0 * R + tl_[k] >= rlen) acc = 0.f;
       p.y[idx[k]] = acc;
     }
   }
@@ -182,6 +184,7 @@ struct DirectEpilogue {
       if (p.add) v = (v + ad) * p.add_scale;
       if (filmb) v = ga * v + be;
       if (p.res) v = (v + rs) * p.res_scale;
+      if (p.lens) v = ragged_mask4(v, n0 + eq, ragged_len(p.lens, b));
       if (vec4) {
         *reinterpret_cast<f32x4u*>(p.y + eidx) = v;
       } else {
@@ -216,6 +219,7 @@ struct DirectEpilogue {
       if (p.add) v = (v + p.add[idx]) * p.add_scale;
       if (filmb) v = filmb[co] * v + filmb[p.Cout + co];
       if (p.res) v = (v + p.res[idx]) * p.res_scale;
+      if (p.lens && t >= ragged_len(p.lens, b)) v = 0.f;
       p.y[idx] = v;
     }
   }
@@ -438,6 +442,7 @@ struct Direct2Epilogue {
 #pragma unroll
         for (int oa = 0; oa < 4; oa++) v[oa] = v[oa] >= 0.f ? v[oa] : p.out_alpha * v[oa];
       }
+      if (p.lens) v = ragged_mask4(v, n0 + eq, ragged_len(p.lens, b));
       if (e_0 == 0 && e_n == 4) {  // 16-byte store at dword alignment (the 401- / 2005-frame levels too)
         *reinterpret_cast<f32x4u*>(p.y + eidx) = v;
       } else {

@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
   int ncol = p.Nq - c0;
   if (ncol > 4) ncol = 4;
   const bool vec4 = ncol == 4;  // (16-byte accesses at dword alignment: rows of 2005 frames too)
+  const int rlen = ragged_len(p.lens, b);  // ragged batch: this row's own length (stride 1: Tout grid == column grid)
   // PRE (chosen by the launcher: an operand exists, rows are 16-byte multiples -- then every lane has a whole quad or none --
   // and the LDS was provided).  A template parameter, not a branch: a branch here would split the control flow while ring
   // loads are in flight, and the copies the compiler places at the join read registers whose data has not landed.
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv_direct3_kernel(ConvArgs p) {
 #pragma unroll
           for (int oa = 0; oa < 4; oa++) v[oa] = v[oa] >= 0.f ? v[oa] : p.out_alpha * v[oa];
         }
+        if (p.lens) v = ragged_mask4(v, c0, rlen);
         if (vec4) {
           *reinterpret_cast<f32x4u*>(p.y + idx) = v;
         } else {
@@ -346,6 +348,7 @@ __device__ __forceinline__ void direct3w_body(const ConvArgs& p) {
   int ncol = p.Nq - c0;
   if (ncol > 4) ncol = 4;
   const bool vec4 = ncol == 4;
+  const int rlen = ragged_len(p.lens, b);  // ragged batch: this row's own length
   const float* pre = p.res ? p.res : p.add;  // the operand that is prefetched (PRE: see conv_direct3_kernel)
   constexpr bool pre_on = PRE;
   float* const slab = smem3 + wv * (NDMA * 256);
@@ -437,6 +440,7 @@ __device__ __forceinline__ void direct3w_body(const ConvArgs& p) {
 #pragma unroll
           for (int oa = 0; oa < 4; oa++) v[oa] = v[oa] >= 0.f ? v[oa] : p.out_alpha * v[oa];
         }
+        if (p.lens) v = ragged_mask4(v, c0, rlen);
         if (vec4) {
           *reinterpret_cast<f32x4u*>(p.y + idx) = v;
         } else {
@@ -578,6 +582,7 @@ __global__ __launch_bounds__(256, 2) void conv_direct3s_kernel(ConvArgs p) {
   int ncol = p.Nq - c0;
   if (ncol > 4) ncol = 4;
   if (ncol <= 0) return;
+  const int rlen = ragged_len(p.lens, b);  // ragged batch: valid output samples of this row
   auto finish = [&](f32x4 v, int co, size_t idx, bool full) {  // 4 consecutive output samples of channel co at idx
     if (p.in_scale) v *= insc;
     v += p.bias[co];
@@ -594,6 +599,7 @@ __global__ __launch_bounds__(256, 2) void conv_direct3s_kernel(ConvArgs p) {
       else { rs = f32x4{0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; e++) if (e < ncol) rs[e] = p.res[idx + e]; }
       v = (v + rs) * p.res_scale;
     }
+    if (p.lens) v = ragged_mask4(v, (int)(idx - (ybase + (size_t)co * p.Tout)), rlen);
     if (full) *reinterpret_cast<f32x4u*>(p.y + idx) = v;
     else for (int e = 0; e < 4; e++) if (e < ncol) p.y[idx + e] = v[e];
   };
@@ -657,6 +663,7 @@ __global__ __launch_bounds__(256, 2) void conv_direct3s_kernel(ConvArgs p) {
           if (p.add) v = (v + p.add[idx]) * p.add_scale;
           if (filmb) v = filmb[co] * v + filmb[p.Cout + co];
           if (p.res) v = (v + p.res[idx]) * p.res_scale;
+          if ((c0 + j) * up + ph >= rlen) v = 0.f;
           p.y[idx] = v;
         }
       }

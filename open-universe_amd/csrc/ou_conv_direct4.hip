@@ -190,6 +190,7 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_direct4_kernel(ConvArgs p) 
   const size_t ybase = (size_t)b * p.Cout * p.Tout;
   const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
   const int nvalid = p.Nq - n0;  // columns of this tile inside the signal (>= 1)
+  const int rlen = ragged_len(p.lens, b);  // ragged batch: valid output samples of this row
   if (p.up == 1) {
     // quad e = (row, four adjacent columns): 16 consecutive lanes = 256 contiguous bytes of one output row
     constexpr int NQ = BM * 16, QPT = (NQ + RNT - 1) / RNT;
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_direct4_kernel(ConvArgs p) 
       if (p.add) v = (v + ad) * p.add_scale;
       if (filmb) v = filmb[m] * v + filmb[p.Cout + m];
       if (p.res) v = (v + rs) * p.res_scale;
+      if (p.lens) v = ragged_mask4(v, n0 + cq, rlen);
       if (full) {
         *reinterpret_cast<f32x4u*>(p.y + idx) = v;
       } else {
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_direct4_kernel(ConvArgs p) 
       if (p.add) v = (v + ad) * p.add_scale;
       if (filmb) v = filmb[co] * v + filmb[p.Cout + co];
       if (p.res) v = (v + rs) * p.res_scale;
+      if (p.lens) v = ragged_mask4(v, n0 * up + tl, rlen);
       if (full) {
         *reinterpret_cast<f32x4u*>(p.y + idx) = v;
       } else {
@@ -498,6 +501,7 @@ __global__ __launch_bounds__(64 * WK) void conv_direct4w_kernel(ConvArgs p) {
 #pragma unroll
       for (int s = 0; s < 4; s++) v[s] = v[s] >= 0.f ? v[s] : p.out_alpha * v[s];
     }
+    if (p.lens) v = ragged_mask4(v, n0 + cq, ragged_len(p.lens, b));
     if (full) {
       *reinterpret_cast<f32x4u*>(p.y + idx) = v;
     } else {

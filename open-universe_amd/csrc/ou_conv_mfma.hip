@@ -377,6 +377,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
         if (p.add) v = (v + addv[k]) * p.add_scale;
         if (filmb) v = ga[k] * v + be[k];
         if (p.res) v = (v + resv[k]) * p.res_scale;
+        if (p.lens) v = ragged_mask4(v, n0 + q, ragged_len(p.lens, (int)blockIdx.z));
         *reinterpret_cast<f32x4*>(p.y + ybase + (size_t)m * Tout + n0 + q) = v;
       }
     }
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvArgs p
       if (p.add) v = (v + p.add[idx]) * p.add_scale;
       if (filmb) v = filmb[co] * v + filmb[Cout + co];
       if (p.res) v = (v + p.res[idx]) * p.res_scale;
+      if (p.lens && t >= ragged_len(p.lens, (int)blockIdx.z)) v = 0.f;
       p.y[idx] = v;
     }
   }
@@ -484,6 +486,10 @@ hipError_t init_conv_kernels() {
   if (e_d3 != hipSuccess) return e_d3;
   return init_chain_kernels();
 }
+
+// Every conv family but the fused ConvBlock bodies (variants 100 .. 199: their conv1 / conv2 tiles live in LDS, where nothing
+// zeroes them behind a row's end -- the runner does not fuse ragged batches) keeps ConvArgs::lens in its epilogue.
+bool conv_masks_rows(int cfg) { return cfg >= 0 && !(cfg >= 100 && cfg < 200); }
 
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
   if (a.Cin % a.CK || a.CK < 2 || (a.CK & (a.CK - 1)) || a.Mp % 64 || a.Nq <= 0) return hipErrorInvalidValue;

@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
   const size_t ybase = (size_t)b * p.Cout * p.Tout;
   const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
   const int tcol = n0 + wn * WTN + (lane & 31);
+  const int rlen = ragged_len(p.lens, b);
   // (all operand loads of a 32-row tile first, with clamped addresses instead of branches: one memory round trip per tile, not
   // one per element -- the first version of this epilogue waited out 128 dependent loads per lane, 95 of its 120 us)
 #pragma unroll
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
         if (filmb) v = ga[r] * v + be[r];
         if (p.res) v = (v + rs[tn][r]) * p.res_scale;
         if (p.out_act) v = v >= 0.f ? v : p.out_alpha * v;
+        if (tcol + tn * 32 >= rlen) v = 0.f;  // (ragged batch: behind the row's own end)
         if (row < p.M && tcol + tn * 32 < p.Nq) p.y[rbase[r] + tcol + tn * 32] = v;
       }
     }

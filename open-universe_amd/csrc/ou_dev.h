@@ -99,6 +99,16 @@ __device__ __forceinline__ u32x4 direct_desc(const void* base, unsigned bytes) {
 
 __device__ __forceinline__ float prelu(float v, float a) { return v >= 0.f ? v : a * v; }
 
+// Ragged batches (ConvArgs::lens, ou_kernels.h): the epilogues that keep the invariant "zero from the row's own length on"
+// themselves.  ragged_len: valid output samples of batch row b (everything when the batch is whole); ragged_mask4: the four
+// consecutive samples t .. t + 3 of a row with the ones at or behind `len` zeroed.
+__device__ __forceinline__ int ragged_len(const int* lens, int b) { return lens ? lens[b] : 0x7fffffff; }
+__device__ __forceinline__ f32x4 ragged_mask4(f32x4 v, int t, int len) {
+  const int n = len - t;
+  v[0] = n > 0 ? v[0] : 0.f; v[1] = n > 1 ? v[1] : 0.f; v[2] = n > 2 ? v[2] : 0.f; v[3] = n > 3 ? v[3] : 0.f;
+  return v;
+}
+
 // Input transform V = B^T d of the minimal-filtering kernels (conv_direct2w_kernel, conv_direct3w_kernel): d = KW + 1 consecutive
 // samples of one channel, V = the KW + 1 values that meet U = G w (ou_model.cpp) in the element-wise products.
 //   F(2, 3), points 0, 1, -1, inf:        rows [1 0 -1 0] [0 1 1 0] [0 -1 1 0] [0 1 0 -1]

@@ -66,6 +66,10 @@ struct ConvArgs {
   // Kernels without the epilogue form return hipErrorNotSupported (the caller stores y and keeps act = 1 downstream).
   int out_act = 0;
   float out_alpha = 1.f;
+  // Ragged batch (ou_enhance_var): valid OUTPUT samples per batch row, [B] on the device, or null (all rows whole).  The kernel
+  // families listed in conv_masks_rows() store 0 from lens[b] on themselves; after the others the runner launches
+  // launch_mask_tail.  (Inputs need nothing: they are zero behind their rows by the same invariant.)
+  const int* lens = nullptr;
   const float* fir = nullptr;
   int fir_len = 0;
   int tile_bm = 32, tile_bn = 0, tile_halo = 0;  // filled by launch_conv_direct: rows / columns a tile advances by, left halo
@@ -76,6 +80,8 @@ struct ConvArgs {
 };
 // returns hipSuccess or the launch error; `cfg_out` (optional) receives the tile configuration index used
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out = nullptr);
+// does the kernel behind variant code `cfg` (launch_conv's cfg_out) honour ConvArgs::lens in its epilogue?
+bool conv_masks_rows(int cfg);
 hipError_t init_conv_kernels();  // raises the dynamic-LDS limit of every instantiation
 double direct3_tiles_per_simd(int M, int Nq, int B, int num_cu);  // wave tiles per SIMD of the no-split-K throughput kernel
 // Small-K rate-change conv of the wide levels with the anti-alias FIR fused: y = conv_{k=s=r}(FIR(prelu(x))) + bias
@@ -98,13 +104,13 @@ enum OutMode { OUT_SCORE = 0, OUT_UPDATE = 1 };
 // Conv1d(1 -> C, k) 'same' on w_in[b]*x (w_in from the coefficient row, 1 when coef == null)
 //   score.py:243-245,284 ; condition.py:295-300,360
 hipError_t launch_in_conv(const float* x, const float* w, const float* bias, const StepCoef* coef, int coef_bstride,
-                          float* y, int B, int C, int T, int KW, hipStream_t s);
+                          float* y, int B, int C, int T, int KW, hipStream_t s, const int* lens = nullptr);
 // PReLU -> PReLU -> Conv1d(C -> 1, k) fused with the EDM score and the sampler update:
 //   net -> score = edm ? (w_skip*x + w_out*net - x)/sig2 : net
 //   OUT_SCORE : out = score ;  OUT_UPDATE : out = x + c1*score + beta*(noise*s_next)   (noise may be null)
 hipError_t launch_out_conv(const float* s, const float* w, const float* bias, const float* alphas, const float* x,
                            const float* noise, float* out, const StepCoef* coef, int coef_bstride, int edm,
-                           int mode, int B, int C, int T, int KW, hipStream_t st);
+                           int mode, int B, int C, int T, int KW, hipStream_t st, const int* lens = nullptr);
 
 // Noise-level embedding for S sigma rows (sigma_block.py) -> g (S, D)
 hipError_t launch_sigma_embed(const StepCoef* coef, int S, const float* params, int simple, int n_rff, int D,
@@ -173,11 +179,13 @@ hipError_t launch_mel_scale(const float* esum, float* scale, int B, int L, hipSt
 
 // space-to-depth + PReLU for the conditioner's strided "st" convs: y[b][ci*R + k][q] = prelu(x[b][ci][q*R + k])
 hipError_t launch_s2d(const float* x, const float* alpha, float* y, int B, int C, int T, int R, hipStream_t st);
+// (`lens` of launch_in_conv / launch_out_conv / launch_fir: per-row valid lengths of a ragged batch or null, see ConvArgs::lens)
 // Binomial anti-alias FIR (blocks.py:119-130, depthwise 'same' conv with 2r+1 taps), bandwidth-bound:
 //   pre  (down path): y = FIR(prelu(x))                       blocks.py:211-215
 //   post (up path)  : y = FIR(u) + bias[c] ; y = res ? (y + res)*res_scale : y     blocks.py:219-225, 374-376
 hipError_t launch_fir(const float* x, const float* taps, int ntaps, float alpha, int act, const float* bias,
-                      const float* res, float res_scale, float* y, int B, int C, int T, hipStream_t st);
+                      const float* res, float res_scale, float* y, int B, int C, int T, hipStream_t st,
+                      const int* lens = nullptr);
 // y = (a + b + c + d + e) * scale   (nulls skipped)   condition.py:202-206
 hipError_t launch_sum(const float* a, const float* b, const float* c, const float* d, const float* e, float scale,
                       float* y, size_t n, hipStream_t st);

@@ -19,10 +19,12 @@ namespace ou {
 constexpr int IN_CONV_CG = 8;
 __global__ __launch_bounds__(256) void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, const StepCoef* coef,
-                                                      int coef_bstride, float* __restrict__ y, int C, int T, int KW) {
+                                                      int coef_bstride, float* __restrict__ y, int C, int T, int KW,
+                                                      const int* __restrict__ lens) {
   const int b = blockIdx.z;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
+  const bool live = t < ragged_len(lens, b);  // ragged batch: 0 behind the row's own end (the bias would stand there)
   const float sc = coef ? coef[(size_t)b * coef_bstride].w_in : 1.f;  // universe.py:199,202
   float xv[7];
   const int pad = (KW - 1) / 2;
@@ -37,15 +39,15 @@ __global__ __launch_bounds__(256) void in_conv_kernel(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 7; k++)
       if (k < KW) acc = fmaf(w[c * KW + k], xv[k], acc);
-    y[((size_t)b * C + c) * T + t] = acc + bias[c];
+    y[((size_t)b * C + c) * T + t] = live ? acc + bias[c] : 0.f;
   }
 }
 
 hipError_t launch_in_conv(const float* x, const float* w, const float* bias, const StepCoef* coef, int coef_bstride,
-                          float* y, int B, int C, int T, int KW, hipStream_t s) {
+                          float* y, int B, int C, int T, int KW, hipStream_t s, const int* lens) {
   if (KW > 7) return hipErrorInvalidValue;
   hipLaunchKernelGGL(in_conv_kernel, dim3((T + 255) / 256, (C + IN_CONV_CG - 1) / IN_CONV_CG, B), dim3(256), 0, s, x, w,
-                     bias, coef, coef_bstride, y, C, T, KW);
+                     bias, coef, coef_bstride, y, C, T, KW, lens);
   return hipGetLastError();
 }
 
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(512) void out_conv_kernel(const float* __restrict__
                                                        const float* __restrict__ bias, const float* __restrict__ alphas,
                                                        const float* x, const float* noise, float* out,
                                                        const StepCoef* coef, int coef_bstride, int edm, int mode, int C,
-                                                       int T, int KW) {
+                                                       int T, int KW, const int* __restrict__ lens) {
   // block = 64 time quads x 8 channel groups (one wave each: at batch 1 the grid is one block per CU, and a wave's
   // channels are a serial chain of loads); 4 consecutive output samples per thread from one aligned float4 + the halo
   // scalars per channel row; the 8 partial sums meet in LDS
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(512) void out_conv_kernel(const float* __restrict__
   // thread (tq, j = cgp < 4) finishes sample t0 + j
   const int j = cgp, t = t0 + j;
   if (j >= 4 || t >= T) return;
+  if (t >= ragged_len(lens, b)) { out[(size_t)b * T + t] = 0.f; return; }  // ragged batch: behind the row's own end
   const float net = (((part[0][tq][j] + part[1][tq][j]) + (part[2][tq][j] + part[3][tq][j])) +
                      ((part[4][tq][j] + part[5][tq][j]) + (part[6][tq][j] + part[7][tq][j]))) + bias[0];
   const StepCoef cf = coef[(size_t)b * coef_bstride];
@@ -128,10 +131,10 @@ __global__ __launch_bounds__(512) void out_conv_kernel(const float* __restrict__
 
 hipError_t launch_out_conv(const float* s, const float* w, const float* bias, const float* alphas, const float* x,
                            const float* noise, float* out, const StepCoef* coef, int coef_bstride, int edm, int mode,
-                           int B, int C, int T, int KW, hipStream_t st) {
+                           int B, int C, int T, int KW, hipStream_t st, const int* lens) {
   if (KW > 7) return hipErrorInvalidValue;
   hipLaunchKernelGGL(out_conv_kernel, dim3((T + 255) / 256, B), dim3(512), 0, st, s, w, bias, alphas, x, noise, out,
-                     coef, coef_bstride, edm, mode, C, T, KW);
+                     coef, coef_bstride, edm, mode, C, T, KW, lens);
   return hipGetLastError();
 }
 
@@ -760,7 +763,7 @@ constexpr int FIR_TILE = 1024;
 __global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, const float* __restrict__ taps, int ntaps,
                                                   float alpha, int act, const float* __restrict__ bias,
                                                   const float* res, float res_scale, float* __restrict__ y, int C,
-                                                  int T) {
+                                                  int T, const int* __restrict__ lens) {
   __shared__ float tile[FIR_TILE + 40];
   __shared__ float tp[40];
   const int c = blockIdx.y, b = blockIdx.z, t0 = blockIdx.x * FIR_TILE, tid = threadIdx.x;
@@ -783,6 +786,7 @@ __global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, c
     for (int j = 0; j < ntaps; j++) acc = fmaf(tp[j], tile[i + j], acc);
     acc += bb;
     if (res) acc = (acc + res[row + t]) * res_scale;
+    if (t >= ragged_len(lens, b)) acc = 0.f;
     y[row + t] = acc;
   }
 }
@@ -793,7 +797,8 @@ __global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, c
 template <int NT>
 __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, const float* __restrict__ taps, float alpha,
                                                    int act, const float* __restrict__ bias, const float* res,
-                                                   float res_scale, float* __restrict__ y, int C, int T) {
+                                                   float res_scale, float* __restrict__ y, int C, int T,
+                                                   const int* __restrict__ lens) {
   constexpr int R = NT >> 1, WIN = 4 + NT - 1, NW4 = (WIN + 3) / 4;
   __shared__ __attribute__((aligned(16))) float tile[FIR_TILE + 2 * R + 8];
   const int c = blockIdx.y, b = blockIdx.z, t0 = blockIdx.x * FIR_TILE, tid = threadIdx.x;
@@ -850,6 +855,7 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
     if (res) acc = (acc + rs[e]) * res_scale;
     o[e] = acc;
   }
+  if (lens) o = ragged_mask4(o, t, lens[b]);
   if (full) *reinterpret_cast<f32x4u*>(y + row + t) = o;
   else {
 #pragma unroll
@@ -857,11 +863,11 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
   }
 }
 hipError_t launch_fir(const float* x, const float* taps, int ntaps, float alpha, int act, const float* bias,
-                      const float* res, float res_scale, float* y, int B, int C, int T, hipStream_t st) {
+                      const float* res, float res_scale, float* y, int B, int C, int T, hipStream_t st, const int* lens) {
   if (ntaps > 39 || !(ntaps & 1)) return hipErrorInvalidValue;
   const dim3 grid((T + FIR_TILE - 1) / FIR_TILE, C, B);
   {  // (dwordx4 accesses at dword alignment: any T; the scalar kernel below takes the tap counts without an instantiation)
-    void (*k)(const float*, const float*, float, int, const float*, const float*, float, float*, int, int) = nullptr;
+    void (*k)(const float*, const float*, float, int, const float*, const float*, float, float*, int, int, const int*) = nullptr;
     switch (ntaps) {
       case 5: k = fir4_kernel<5>; break;
       case 7: k = fir4_kernel<7>; break;
@@ -871,11 +877,11 @@ hipError_t launch_fir(const float* x, const float* taps, int ntaps, float alpha,
       default: break;
     }
     if (k) {
-      hipLaunchKernelGGL(k, grid, dim3(256), 0, st, x, taps, alpha, act, bias, res, res_scale, y, C, T);
+      hipLaunchKernelGGL(k, grid, dim3(256), 0, st, x, taps, alpha, act, bias, res, res_scale, y, C, T, lens);
       return hipGetLastError();
     }
   }
-  hipLaunchKernelGGL(fir_kernel, grid, dim3(256), 0, st, x, taps, ntaps, alpha, act, bias, res, res_scale, y, C, T);
+  hipLaunchKernelGGL(fir_kernel, grid, dim3(256), 0, st, x, taps, ntaps, alpha, act, bias, res, res_scale, y, C, T, lens);
   return hipGetLastError();
 }
 

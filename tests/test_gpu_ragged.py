@@ -190,3 +190,31 @@ def test_exact_batching_full_width_vs_file_by_file_and_oracle(name, secs):
     wa, wo = worst(alone), worst(orc)
     record(f"ragged.{name}.full.worst_row_vs_file_by_file", wa, 100)
     record(f"ragged.{name}.full.worst_row_vs_oracle", wo, 80)
+
+
+@pytest.mark.parametrize("name,B,secs", [("PP16", 8, 2.0), ("PP16", 16, 4.0), ("OR16", 3, 1.0), ("PP24", 8, 1.5), ("PP16m", 5, 0.6)])
+def test_masks_in_the_epilogues_equal_separate_mask_launches(name, B, secs, steer):
+    """The tail masks of a ragged batch live in the epilogues of the conv / FIR / rate-change / in- and out-conv kernels
+    (ConvArgs::lens); option mask_fused = 0 launches a separate tail-mask kernel behind every producer instead -- the reference
+    form.  Same values everywhere a row is valid, zeros elsewhere: bit-identical outputs, fewer launches.  The shapes cover the
+    split-K kernels (batch 3 / 5), the no-split-K family (batch 8) and conv_split_kernel (batch 16 at 4 s)."""
+    model, spec, sd = get_model(name)
+    g = torch.Generator().manual_seed(3)
+    lens = sorted((int(spec.fs * secs * (0.55 + 0.45 * float(torch.rand(1, generator=g)))) for _ in range(B)), reverse=True)
+    lens[-1] = (lens[-1] // spec.tot_ds) * spec.tot_ds  # one row with a whole extra block of padding
+    sigs = _signals(spec, lens)
+    noise = _noise_for(spec, lens, 2, 300)
+    rows, full = _run_ragged(model, spec, sigs, noise, 2)
+    n_fused = sum(model.launch_stats())
+    steer.set(mask_fused=0)
+    rows0, full0 = _run_ragged(model, spec, sigs, noise, 2)
+    n_sep = sum(model.launch_stats())
+    steer.unset("mask_fused")
+    assert torch.equal(full, full0)
+    assert n_fused < n_sep, (n_fused, n_sep)
+    # and the invariant holds in the fused form too: a deep tensor of the last score pass is zero behind every row
+    t = model.tensor("score.dec1.v")
+    T = max(L + (spec.tot_ds - L % spec.tot_ds) for L in lens)
+    for b, L in enumerate(lens):
+        lb = (L + (spec.tot_ds - L % spec.tot_ds)) * t.shape[-1] // T
+        assert not t[b, :, lb:].any() and t[b, :, :lb].abs().max() > 0
