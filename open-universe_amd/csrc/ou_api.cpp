@@ -36,7 +36,7 @@ struct Options {
   int split = -1;              // ConvArgs::split
   int dbg_dec0_under_gru = 0;  // measurement only, INVALID results (see run_score); experiments library only
   int tile_prefetch = 1;
-  int trace = 0, no_overlap = 0, ts = 0, deep_factor = 8, mask_fused = 1;
+  int trace = 0, no_overlap = 0, ts = 0, deep_factor = 8, mask_fused = 1, split_wino = 1;
   double tile_min = -1.0;      // < 0: the launcher's default
   std::string chain_ts;        // ou_set_stamp_layer (tuning)
 };
@@ -131,6 +131,7 @@ struct OptDesc {
 const OptDesc kOptions[] = {
     {"conv_direct", &Options::conv_direct, nullptr, false, "kernel generations the conv launcher may use (0 .. 5, ConvArgs::direct)"},
     {"split", &Options::split, nullptr, false, "-1 rule / 0 never / 1 wherever possible: conv_split_kernel (bf16-split operands)"},
+    {"split_wino", &Options::split_wino, nullptr, false, "experiments build: 0 = the plain bf16-split kernel also where its minimal-filtering form would take the layer"},
     {"wino", &Options::wino, nullptr, false, "0: never the minimal-filtering (Winograd / Cook-Toom) kernel variants"},
     {"fuse", &Options::fuse, nullptr, false, "-1 cost model / 0 never / 2 / 3: depth of the fused ConvBlock body (conv_chain kernels)"},
     {"fuse_nc", &Options::fuse_nc, nullptr, false, "128 / 256: columns per tile of the fused ConvBlock body (0: launcher's choice)"},
@@ -310,7 +311,8 @@ struct Runner {
     a.x = in.p; a.w = W(L.w_off); a.bias = W(L.b_off); a.y = out.p;
     if (L.KWP) { a.wd = W(L.wd_off); a.wu = W(L.wu_off); }
     if (L.ws_on) a.wsplit = W(L.ws_off);
-    a.split = env.split;
+    if (L.wsw_on) a.wsplitw = W(L.wsw_off);
+    a.split = env.split; a.split_wino = env.split_wino;
     a.in_scale = e.in_scale;
     a.act = (L.act && e.act) ? 1 : 0;
     a.alpha_val = a.act ? h->alphas[L.a_off] : 0.f;

@@ -340,6 +340,255 @@ __global__ __launch_bounds__(256, (TNW == 2 && WM >= 2) ? 2 : 1) void conv_split
   if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
+#ifdef OU_EXPERIMENTS
+// =========================================================================================================
+// conv_splitw_kernel<WM, ACT>: F(2, 3) minimal filtering ON the bf16 pipe (round 6; review item 4a) -- `make EXPERIMENTS=1`
+// builds only: MEASURED SLOWER than conv_split_kernel on the layers it was built for (256-channel k3 convs, PP16 batch 16, 1 486
+// launches of a profiled bench run: 104.5 vs 89.3 us per launch; end to end 368.6 / 369.1 vs 372.6 / 366.3 utt/s, profiles/
+// r06_splitw_*).  Two thirds of the piece MFMAs -- but 4/3 of the weight-fragment bytes per chunk for 2/3 of the MFMA time
+// (7.8 instead of 3.9 bytes per clock and wave from L2, straight into registers, nothing shared between the waves of a block)
+// and twice the staging work: what bounds the split kernels on these layers is the operand stream, not the matrix pipe.
+// conv_split_kernel issues KW x 6 piece MFMAs per 16 channels and 32 output columns; it is power- and issue-bound on exactly
+// those.  Here a pair of adjacent outputs (y[2p], y[2p + 1]) comes from the KW + 1 = 4 element-wise products of the
+// Winograd / Cook-Toom domain,  y = A^T [ (G w) . (B^T d) ]  (same matrices as conv_direct2w_kernel, ou_dev.h / ou_model.cpp):
+//   * weights: U = G w, computed by the packer in double, rounded ONCE to fp32 (the values the fp32 minimal-filtering kernels
+//     multiply with), then split into three bf16 pieces and laid out as A fragments with the 4 transformed taps in the place of the
+//     3 taps (ConvArgs::wsplitw);
+//   * activations: the block stages PAIRS: d = x[2p - 1 .. 2p + 2] (PReLU first), V = B^T d in fp32 -- four values per pair
+//     and channel --, every V split into three pieces and written to ONE LDS IMAGE PER TRANSFORMED TAP, rows = pairs: the B
+//     fragment of tap x is the 16-byte read at the lane's pair row of image x (no row offsets between taps any more);
+//   * per 16 channels and 32 PAIRS (64 output columns) 4 x 6 piece MFMAs instead of 2 x 3 x 6: two thirds of the matrix work,
+//     for twice the staging work per sample (4 V values per 2 samples), which rides under the MFMAs as before;
+//   * the four accumulators of a pair meet in the epilogue: y[2p] = M0 + M1 + M2, y[2p + 1] = M1 - M2 - M3 -- the lane holds
+//     both samples: 8-byte stores, 256 contiguous bytes per row and half wave (the plain kernel stores 4 bytes per lane).
+// Wave tile 64 rows x 64 pairs (= 128 columns): 2 x 2 x 4 accumulators of 16 registers = 256, the accumulation registers of a
+// wave; WM = 4 / 2 waves along the rows (M % 256 / % 128), 1 / 2 along the pairs.  Accuracy: the split is exact for U and V as
+// it is for w and x; what is added is the rounding of the fp32 transforms themselves, i.e. what conv_direct2w_kernel has
+// (tests: >= 100 dB against the plain split kernel and the oracle).
+// =========================================================================================================
+template <int WM, bool ACT>
+__global__ __launch_bounds__(256, 1) void conv_splitw_kernel(ConvArgs p) {
+  constexpr int NTAU = 4, TNP = 2, WN = 4 / WM, WTP = 32 * TNP, BP = WN * WTP;  // pairs per wave / per block
+  constexpr int ROWS16 = ((BP + 1 + 7) / 16) * 16 + 8;  // rows of one plane: BP pairs + the row nobody reads, % 16 == 8
+  static_assert(ROWS16 >= BP + 1 && ROWS16 % 16 == 8, "plane rows");
+  constexpr int HALF = ROWS16 * 16, PIECE = 2 * HALF, IMG = 3 * PIECE, BUF = NTAU * IMG;
+  constexpr int NITEM = BP / 32;  // staged (pair, channel pair) items per thread
+  static_assert(WM == 2 || WM == 4, "waves along the rows");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WN, wn = wv % WN;
+  const int L = blockIdx.x, q8 = L >> 3, rg = q8 % p.grid_m, cidx = (q8 / p.grid_m) * 8 + (L & 7);
+  const int b = cidx / p.grid_n, ct = cidx - b * p.grid_n;
+  if (b >= p.B) return;  // (whole blocks)
+  if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const int p0 = ct * BP, m0 = rg * (64 * WM) + wm * 64;
+  const int Tin = p.Tin, Cin = p.Cin;
+  const int NCH = Cin >> 4, MT = p.Mp >> 5;
+  const float alpha = p.alpha_val;
+  const float* xb = p.x + (size_t)b * Cin * Tin;
+
+  // ---- staging: thread = (channel pair cp, pair rows row0 + 32 j); d = x[2 P - 1 .. 2 P + 2] of both channels
+  const int cp = tid & 7, row0 = tid >> 3;
+  float sx[NITEM][2][4];
+  auto stage_load = [&](int cc) {
+    const float* s0 = xb + (size_t)(cc * 16 + 2 * cp) * Tin;
+#pragma unroll
+    for (int j = 0; j < NITEM; j++) {
+      const int t0 = 2 * (p0 + row0 + 32 * j) - 1;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int t = t0 + e;
+        const bool ok = t >= 0 && t < Tin;
+        const int tc = t < 0 ? 0 : (t < Tin ? t : Tin - 1);  // (clamped address + select: no branch)
+        const float v0 = s0[tc], v1 = s0[Tin + tc];
+        sx[j][0][e] = ok ? v0 : 0.f;
+        sx[j][1][e] = ok ? v1 : 0.f;
+      }
+    }
+  };
+  auto stage_store = [&](int buf) {
+    unsigned char* base = smem_split + buf * BUF + (cp >> 2) * HALF + (cp & 3) * 4;
+#pragma unroll
+    for (int j = 0; j < NITEM; j++) {
+      const int row = row0 + 32 * j;
+      float d0[4], d1[4], V0[4], V1[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        d0[e] = ACT ? prelu(sx[j][0][e], alpha) : sx[j][0][e];
+        d1[e] = ACT ? prelu(sx[j][1][e], alpha) : sx[j][1][e];
+      }
+      wino_bt<3>(d0, V0);
+      wino_bt<3>(d1, V1);
+#pragma unroll
+      for (int x = 0; x < NTAU; x++) {
+        unsigned H, M, Lo;
+        split_pair(V0[x], V1[x], H, M, Lo);
+        *reinterpret_cast<unsigned*>(base + x * IMG + row * 16) = H;
+        *reinterpret_cast<unsigned*>(base + x * IMG + PIECE + row * 16) = M;
+        *reinterpret_cast<unsigned*>(base + x * IMG + 2 * PIECE + row * 16) = Lo;
+      }
+    }
+  };
+
+  // ---- weight fragments: [cc][transformed tap][mt][piece][lane] x 16 bytes
+  const u32x4* wsp = reinterpret_cast<const u32x4*>(p.wsplitw) + lane;
+  const int mt0 = m0 >> 5;
+  u32x4 A[2][2][3];
+  auto load_a = [&](int step, u32x4 (&a)[2][3]) {  // step = cc * 4 + x
+    const u32x4* s = wsp + ((size_t)step * MT + mt0) * 3 * 64;
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+      for (int pc = 0; pc < 3; pc++) a[tm][pc] = s[(tm * 3 + pc) * 64];
+  };
+
+  floatx16 acc[2][TNP][NTAU];
+#pragma unroll
+  for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+    for (int tn = 0; tn < TNP; tn++)
+#pragma unroll
+      for (int x = 0; x < NTAU; x++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tm][tn][x][r] = 0.f;
+
+  const int boff = (lane >> 5) * HALF + (wn * WTP + (lane & 31)) * 16;  // this lane's plane (K half) and pair row inside a piece
+  bf16x8 Bf[2][TNP][3];
+  auto read_b = [&](int buf, int x, bf16x8 (&bf)[TNP][3]) {
+    const unsigned char* bb = smem_split + buf * BUF + x * IMG + boff;
+#pragma unroll
+    for (int tn = 0; tn < TNP; tn++)
+#pragma unroll
+      for (int pc = 0; pc < 3; pc++) bf[tn][pc] = *reinterpret_cast<const bf16x8*>(bb + pc * PIECE + tn * 32 * 16);
+  };
+
+  load_a(0, A[0]);
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  read_b(0, 0, Bf[0]);
+
+  // one step = (chunk, transformed tap): 2 x TNP x 6 MFMAs on fragments fetched during the previous step (see conv_split_kernel)
+  auto chunk = [&](int cc) {
+    const int ccn = cc + 1 < NCH ? cc + 1 : cc;
+    stage_load(ccn);
+#pragma unroll
+    for (int x = 0; x < NTAU; x++) {
+      constexpr int NMMA = 2 * TNP * 6;
+      const int P = x & 1;
+      const bool last = x == NTAU - 1;
+      u32x4 (&ac)[2][3] = A[P];
+      bf16x8 (&bc)[TNP][3] = Bf[P];
+      load_a(last ? ccn * NTAU + (ccn == cc ? x : 0) : cc * NTAU + x + 1, A[P ^ 1]);
+      if (!last) read_b(cc & 1, x + 1, Bf[P ^ 1]);
+      if (last) stage_store((cc + 1) & 1);
+#pragma unroll
+      for (int tn = 0; tn < TNP; tn++) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          constexpr int QA[6] = {0, 0, 1, 0, 1, 2}, QB[6] = {0, 1, 0, 2, 1, 0};
+#pragma unroll
+          for (int tm = 0; tm < 2; tm++)
+            acc[tm][tn][x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[tm][QA[q]]), bc[tn][QB[q]],
+                                                                     acc[tm][tn][x], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      if (!last) {
+#pragma unroll
+        for (int i = 0; i < 3 * TNP; i++) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMMA - 8 - 3 * TNP, 0);
+      } else {
+        // NITEM items x (8 transform + 4 x 11 split [+ 16 PReLU] VALU, 12 LDS writes) in the shadow of the remaining MFMAs
+#pragma unroll
+        for (int i = 0; i < NMMA - 8; i++) {
+          __builtin_amdgcn_sched_group_barrier(0x002, (NITEM * (ACT ? 70 : 54) + NMMA - 9) / (NMMA - 8), 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    read_b((cc + 1) & 1, 0, Bf[0]);
+  };
+  for (int cc = 0; cc < NCH; cc++) chunk(cc);
+
+  // ---- epilogue: A^T, then in_scale, bias, cond add, FiLM, residual, PReLU of the next layer -- 8 bytes per lane and row
+  typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+  const float* filmb = p.film ? p.film + (size_t)b * p.film_bstride : nullptr;
+  const size_t ybase = (size_t)b * p.Cout * p.Tout;
+  const float insc = p.in_scale ? p.in_scale[b] : 1.0f;
+  const int rlen = ragged_len(p.lens, b);
+  // (half a 32 x 32-pair tile at a time -- 8 accumulator registers = 8 rows: its operand loads first, one memory round trip
+  //  per half tile, 32-bit row offsets; the 256 accumulation registers leave the epilogue half the register file)
+#pragma unroll
+  for (int tm = 0; tm < 2; tm++) {
+#pragma unroll
+    for (int tn = 0; tn < TNP; tn++) {
+      const int t = 2 * (p0 + wn * WTP + tn * 32 + (lane & 31));
+      const bool two = t + 1 < p.Nq;
+#pragma unroll
+      for (int rh = 0; rh < 2; rh++) {
+        float bi[8], ga[8], be[8];
+        f32x2 rs[8], ad[8];
+        int roff[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int r = 8 * rh + q;
+          const int row = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int rc = row < p.M ? row : p.M - 1;
+          roff[q] = rc * p.Tout;
+          bi[q] = p.bias[rc];
+          ga[q] = 1.f; be[q] = 0.f;
+          if (filmb) { ga[q] = filmb[rc]; be[q] = filmb[p.Cout + rc]; }
+        }
+        // (a row of odd length ends in half a pair: its last lane takes the single sample t = Nq - 1 as component 0)
+        const int t1 = t < p.Nq ? t : p.Nq - 1;
+        if (p.res) {
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            rs[q] = two ? f32x2(*reinterpret_cast<const f32x2u*>(p.res + ybase + roff[q] + t)) : f32x2{p.res[ybase + roff[q] + t1], 0.f};
+        }
+        if (p.add) {
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            ad[q] = two ? f32x2(*reinterpret_cast<const f32x2u*>(p.add + ybase + roff[q] + t)) : f32x2{p.add[ybase + roff[q] + t1], 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int r = 8 * rh + q;
+          const int row = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const float a0 = acc[tm][tn][0][r], a1 = acc[tm][tn][1][r], a2 = acc[tm][tn][2][r], a3 = acc[tm][tn][3][r];
+          f32x2 v = f32x2{(a0 + a1) + a2, (a1 - a2) - a3};
+          if (p.in_scale) v *= insc;
+          v += bi[q];
+          if (p.add) v = (v + ad[q]) * p.add_scale;
+          if (filmb) v = ga[q] * v + be[q];
+          if (p.res) v = (v + rs[q]) * p.res_scale;
+          if (p.out_act) { v[0] = v[0] >= 0.f ? v[0] : p.out_alpha * v[0]; v[1] = v[1] >= 0.f ? v[1] : p.out_alpha * v[1]; }
+          if (t >= rlen) v[0] = 0.f;      // (ragged batch: behind the row's own end)
+          if (t + 1 >= rlen) v[1] = 0.f;
+          if (row < p.M) {
+            if (two) *reinterpret_cast<f32x2u*>(p.y + ybase + roff[q] + t) = v;
+            else if (t < p.Nq) p.y[ybase + roff[q] + t] = v[0];
+          }
+        }
+      }
+    }
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+#endif  // OU_EXPERIMENTS
+
 namespace {
 struct SplitCfg {
   int KW, WM, TNW;
@@ -359,7 +608,20 @@ const SplitCfg kSplitCfgs[] = {
 };
 }  // namespace
 
+constexpr size_t splitw_lds(int wm) {  // two stages x 4 images x 3 pieces x 2 planes
+  return (size_t)2 * 4 * 3 * 2 * ((((4 / wm) * 64 + 1 + 7) / 16) * 16 + 8) * 16;
+}
 hipError_t init_split_kernels() {
+#ifdef OU_EXPERIMENTS
+  {
+    const void* ks[4] = {reinterpret_cast<const void*>(conv_splitw_kernel<4, false>), reinterpret_cast<const void*>(conv_splitw_kernel<4, true>),
+                         reinterpret_cast<const void*>(conv_splitw_kernel<2, false>), reinterpret_cast<const void*>(conv_splitw_kernel<2, true>)};
+    for (int i = 0; i < 4; i++) {
+      hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)splitw_lds(i < 2 ? 4 : 2));
+      if (e != hipSuccess) return e;
+    }
+  }
+#endif
   for (const SplitCfg& c : kSplitCfgs) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
     if (e != hipSuccess) return e;
@@ -374,6 +636,30 @@ hipError_t launch_conv_split(const ConvArgs& a, int num_cu, hipStream_t stream, 
   if (!a.wsplit || a.stride != 1 || a.up != 1 || (a.KW != 3 && a.KW != 5) || a.pad != (a.KW - 1) / 2 || a.fir || a.Cin % 16 ||
       a.M % 64 || (a.in_scale != nullptr && a.act))
     return hipErrorInvalidConfiguration;
+#ifdef OU_EXPERIMENTS
+  // minimal filtering on the bf16 pipe where the layer has the Winograd-domain split copy (k3, rows a multiple of 128) and
+  // the 128-column wave tiles still fill the device: variant 850 + 10 log2(WM) + KW
+  if (a.wsplitw && a.split_wino && a.KW == 3 && a.M % 128 == 0 && (a.force_cfg < 0 || (a.force_cfg >= 850 && a.force_cfg < 900))) {
+    int wmw = a.M % 256 == 0 ? 4 : 2;
+    if (a.force_cfg >= 850) wmw = 1 << ((a.force_cfg - 850) / 10);
+    if ((wmw == 4 || wmw == 2) && a.M % (64 * wmw) == 0) {
+      const long bn = (4 / wmw) * 128L;
+      const long blocks = (a.M / (64 * wmw)) * ((a.Nq + bn - 1) / bn) * a.B;
+      if (blocks >= num_cu || a.force_cfg >= 850 || a.split == 1) {
+        ConvArgs aa = a;
+        aa.grid_m = a.M / (64 * wmw);
+        aa.grid_n = (int)((a.Nq + bn - 1) / bn);
+        const long total8 = ((long)aa.grid_n * a.B + 7) / 8 * 8;
+        if (cfg_out) *cfg_out = 850 + 10 * (wmw == 4 ? 2 : 1) + a.KW;
+        auto kern = wmw == 4 ? (a.act ? conv_splitw_kernel<4, true> : conv_splitw_kernel<4, false>)
+                             : (a.act ? conv_splitw_kernel<2, true> : conv_splitw_kernel<2, false>);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(total8 * aa.grid_m)), dim3(256), splitw_lds(wmw), stream, aa);
+        return hipGetLastError();
+      }
+    }
+    if (a.force_cfg >= 850) return hipErrorInvalidConfiguration;
+  }
+#endif
   int wm = a.M % 256 == 0 ? 4 : (a.M % 128 == 0 ? 2 : 1);
   int tnw = 4;
   auto blocks = [&](int wm_, int tnw_) {
@@ -382,7 +668,7 @@ hipError_t launch_conv_split(const ConvArgs& a, int num_cu, hipStream_t stream, 
   };
   // fill the device: narrower wave tiles, then fewer rows per block, while there are fewer blocks than CUs
   if (blocks(wm, tnw) < num_cu) tnw = 2;
-  if (a.force_cfg >= 800 && a.force_cfg < 1100) {
+  if (a.force_cfg >= 800 && a.force_cfg < 1100 && !(a.force_cfg >= 850 && a.force_cfg < 900)) {
     const int f = a.force_cfg - 800;
     tnw = f >= 100 ? 2 : 4;
     wm = 1 << ((f % 100) / 10);

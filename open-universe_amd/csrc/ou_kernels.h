@@ -17,6 +17,9 @@ struct ConvArgs {
   const float* wu = nullptr;      // third copy, Winograd domain U = G w: [Cin][Mp][4 (F(2,3)) / 8 (F(2,5): 6 used)] or null
   const void* wsplit = nullptr;   // fourth copy, three bf16 pieces per weight as MFMA A fragments: [Cin/16][KW][Mp/32][3][64][8 bf16]
                                   // (conv_split_kernel) or null
+  const void* wsplitw = nullptr;  // fifth copy: the Winograd-domain weights U = G w the same way, [Cin/16][KW + 1][Mp/32][3][64][8 bf16]
+                                  // (conv_splitw_kernel) or null
+  int split_wino = 1;             // option split_wino: 0 = conv_split_kernel also where conv_splitw_kernel could take the layer
   const float* bias = nullptr;    // [Cout]
   float* y = nullptr;             // (B, Cout, Tout)
   const float* in_scale = nullptr;  // [B] or null

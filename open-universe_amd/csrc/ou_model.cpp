@@ -48,6 +48,11 @@ std::string finish_conv(ConvL& L, Alloc& a) {
     L.wu_off = a.take((size_t)L.Cin * L.Mp * L.KWP);
     // the bf16-split copy (conv_split_kernel: 64-row tiles -- the 48-channel level of UNIVERSE++ 24 kHz stays on the fp32 kernels)
     if (L.M % 64 == 0) { L.ws_on = 1; L.ws_off = a.take(split_floats(L.Cin, L.KW, L.Mp)); }
+#ifdef OU_EXPERIMENTS
+    // ... and of the Winograd-domain weights, for the layers conv_splitw_kernel takes (k3, rows a multiple of 128): the
+    // experiments build only -- the kernel measured slower (ou_conv_split.hip), the default blob does not carry its copy
+    if (L.M % 128 == 0 && L.KW == 3) { L.wsw_on = 1; L.wsw_off = a.take(split_floats(L.Cin, L.KW + 1, L.Mp)); }
+#endif
   }
   return "";
 }
@@ -133,7 +138,7 @@ void json_conv(std::ostringstream& os, const ConvL& L, bool& first) {
      << ",\"M\":" << L.M << ",\"Mp\":" << L.Mp << ",\"CK\":" << L.CK << ",\"rate\":" << L.rate << ",\"act\":" << L.act
      << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"a_off\":" << L.a_off
      << ",\"fir_mode\":" << L.fir_mode << ",\"fir_len\":" << L.fir_len << ",\"fir_off\":" << L.fir_off
-     << ",\"fbias_off\":" << L.fbias_off << ",\"wd_off\":" << L.wd_off << ",\"wu_off\":" << L.wu_off << ",\"KWP\":" << L.KWP << ",\"ws_on\":" << L.ws_on << ",\"ws_off\":" << L.ws_off << "}";
+     << ",\"fbias_off\":" << L.fbias_off << ",\"wd_off\":" << L.wd_off << ",\"wu_off\":" << L.wu_off << ",\"KWP\":" << L.KWP << ",\"ws_on\":" << L.ws_on << ",\"ws_off\":" << L.ws_off << ",\"wsw_on\":" << L.wsw_on << ",\"wsw_off\":" << L.wsw_off << "}";
 }
 void json_block(std::ostringstream& os, const BlockL& B, bool& first) {
   if (B.dir) json_conv(os, B.rc, first);
@@ -406,6 +411,7 @@ struct Packer {
                                       {1. / 30, -1. / 15, 2. / 15, -4. / 15, 8. / 15},
                                       {0, 0, 0, 0, 1. / 2}};
       const int NU = KW + 1;
+      std::vector<float> Uf(L.wsw_on ? (size_t)L.M * L.Cin * NU : 0);
       for (int ci = 0; ci < L.Cin; ci++)
         for (int mm = 0; mm < L.M; mm++) {
           const double* w = &W[((size_t)mm * L.Cin + ci) * KW];
@@ -413,8 +419,11 @@ struct Packer {
             double u = 0;
             for (int k = 0; k < KW; k++) u += (KW == 3 ? G3[x][k] : G5[x][k]) * w[k];
             blob[L.wu_off + ((size_t)ci * Mp + mm) * L.KWP + x] = (float)u;
+            if (L.wsw_on) Uf[((size_t)mm * L.Cin + ci) * NU + x] = (float)u;  // (the same fp32 U the fp32 kernels multiply with)
           }
         }
+      // three bf16 pieces of every U value, as A fragments with the KW + 1 transformed taps in the place of the taps
+      if (L.wsw_on) pack_split(Uf.data(), L.M, L.Mp, L.Cin, NU, reinterpret_cast<uint16_t*>(&blob[L.wsw_off]));
     }
   }
 

@@ -30,6 +30,10 @@ struct ConvL {
   size_t ws_off = 0;      // ... and a fourth copy for the bf16 matrix pipe: every weight as three bf16 pieces, laid out as MFMA A
                           // fragments [Cin/16][KW][Mp/32][3][64 lanes][8 bf16] (conv_split_kernel, ou_split_pack.h); valid when ws_on
   int ws_on = 0;
+  size_t wsw_off = 0;     // ... and (round 6) the same for the Winograd-domain weights U = G w: [Cin/16][KW + 1][Mp/32][3][64][8 bf16]
+                          // (conv_splitw_kernel: minimal filtering ON the bf16 pipe -- KW + 1 instead of 2 KW piece-product sets per
+                          // pair of outputs); valid when wsw_on
+  int wsw_on = 0;
   size_t w_off = 0;       // float offsets into the blob
   size_t b_off = 0;       // bias[Cout]
   size_t a_off = 0;       // prelu slope (1 float) when act

@@ -193,15 +193,17 @@ def split_copy_as_values(blob, plan_json):
     (a weight that differs in its last bit has completely different mid / lo pieces)."""
     out = blob.clone()
     for L in plan_convs(plan_json).values():
-        if not L.get("ws_on"):
-            continue
-        n = L["Cin"] * L["KW"] * L["Mp"] * 3 // 2
-        raw = blob[L["ws_off"]: L["ws_off"] + n].view(torch.int16)
-        pieces = (raw.to(torch.int32) << 16).view(torch.float32).view(-1, 3, 64, 8)   # [fragment triple][piece][lane][8]
-        total = pieces.double().sum(dim=1).float()                                     # hi + mid + lo: exact
-        filler = torch.zeros(n, dtype=torch.float32)
-        filler[: total.numel()] = total.reshape(-1)
-        out[L["ws_off"]: L["ws_off"] + n] = filler
+        # (the plain copy, KW taps, and -- round 6 -- the copy of the Winograd-domain weights, KW + 1 transformed taps)
+        for on, off, taps in (("ws_on", "ws_off", L["KW"]), ("wsw_on", "wsw_off", L["KW"] + 1)):
+            if not L.get(on):
+                continue
+            n = L["Cin"] * taps * L["Mp"] * 3 // 2
+            raw = blob[L[off]: L[off] + n].view(torch.int16)
+            pieces = (raw.to(torch.int32) << 16).view(torch.float32).view(-1, 3, 64, 8)   # [fragment triple][piece][lane][8]
+            total = pieces.double().sum(dim=1).float()                                     # hi + mid + lo: exact
+            filler = torch.zeros(n, dtype=torch.float32)
+            filler[: total.numel()] = total.reshape(-1)
+            out[L[off]: L[off] + n] = filler
     return out
 
 

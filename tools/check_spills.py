@@ -15,6 +15,10 @@ import sys
 
 CALL_WINDOW = 48
 LOOP_KERNELS = ("gru_ring_kernel",)
+# Kernels whose 256 accumulation registers fill the AGPR file: the allocator parks a few dozen accumulator values in scratch ONCE,
+# between the main loop and the epilogue (conv_splitw_kernel: 27 dwords per lane and launch).  Allowed there -- and only
+# there: a scratch access inside a loop of such a kernel fails the gate like any other spill.
+SCRATCH_OUTSIDE_LOOPS_OK = ("conv_splitw_kernel",)
 
 
 def kernels_of(lines):
@@ -80,12 +84,48 @@ def loop_spills(body):
     return bad
 
 
+def loop_scratch(body):
+    """scratch_* instructions inside a loop -> list of texts."""
+    instrs, labels = [], {}
+    for line in body:
+        t = line.split(";")[0].strip()
+        if not t or (t.startswith(".") and not re.match(r"^\.LBB\w+:", t)):
+            continue
+        m = re.match(r"^(\.LBB\w+):", t)
+        if m:
+            labels[m.group(1)] = len(instrs)
+            continue
+        if t.endswith(":"):
+            continue
+        instrs.append(t)
+    in_loop = [False] * len(instrs)
+    for i, t in enumerate(instrs):
+        parts = t.replace(",", " ").split()
+        if parts[0].startswith(("s_cbranch", "s_branch")) and len(parts) > 1:
+            tgt = labels.get(parts[1])
+            if tgt is not None and tgt <= i:
+                for k in range(tgt, i + 1):
+                    in_loop[k] = True
+    return [t for i, t in enumerate(instrs) if in_loop[i] and t.startswith(("scratch_", "buffer_store_dword v", "buffer_load_dword v")) and "scratch" in t]
+
+
 def check_file(path):
     lines = open(path).read().split("\n")
     fails = []
+    cur = ""
     for ln, line in enumerate(lines, 1):
+        m = re.match(r"\s+\.name:\s+(\S+)", line)
+        if m:
+            cur = m.group(1)
         if re.search(r"(private_segment_fixed_size|vgpr_spill_count):\s+[1-9]", line):
-            fails.append(f"{path}:{ln}: scratch / VGPR spills in the device code: {line.strip()}")
+            if any(k in cur for k in SCRATCH_OUTSIDE_LOOPS_OK):
+                continue  # (held to "nothing inside a loop" below)
+            fails.append(f"{path}:{ln}: scratch / VGPR spills in the device code: {line.strip()} ({cur})")
+    for name, body in kernels_of(lines).items():
+        if any(k in name for k in SCRATCH_OUTSIDE_LOOPS_OK):
+            bad = loop_scratch(body)
+            if bad:
+                fails.append(f"{path}: {name} accesses scratch inside a loop ({len(bad)} instructions, first: {bad[0]})")
     n_loop_kernels = 0
     for name, body in kernels_of(lines).items():
         if not any(k in name for k in LOOP_KERNELS):
