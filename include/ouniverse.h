@@ -82,6 +82,9 @@ typedef struct ou_config {
                      * down / up rate-change convs (blocks.py:213-227) into their weights (one launch less per rate change for 3x
                      * that conv's FLOPs; slower on MI355X, default 0).  The plan and the blob depend on it: same value for the
                      * packer and ou_create. */
+  int32_t no_split_copy; /* packing choice: 1 = leave the bf16-split weight copy (conv_split_kernel: a quarter of the blob, PP16
+                          * 162 of 648 MB) out -- for handles that never run a batch of 8 or more utterances per call (the
+                          * launcher's rule selects that kernel from batch 8 / 16 on).  Same value for the packer and ou_create. */
 } ou_config;
 
 typedef struct ou_packer ou_packer;

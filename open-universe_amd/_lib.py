@@ -51,6 +51,7 @@ class Config(Structure):
         ("has_edm_data_level", c_int32),
         ("edm_data_level_db", c_float),
         ("fir_fold", c_int32),
+        ("no_split_copy", c_int32),
     ]
 
 
@@ -176,8 +177,9 @@ def option_defaults():
     return {L.ou_option_name(i).decode(): L.ou_option_default(i) for i in range(L.ou_option_count())}
 
 
-def make_config(spec, fir_fold=0):
-    """ModelSpec -> ou_config.  `fir_fold`: packing choice (ou_config.fir_fold), the same for the packer and ou_create."""
+def make_config(spec, fir_fold=0, split_copy=True):
+    """ModelSpec -> ou_config.  `fir_fold`, `split_copy`: packing choices (ou_config.fir_fold / .no_split_copy), the same for the
+    packer and ou_create."""
     def net(n):
         c = NetConfig()
         c.n_rates = len(n.rate_factors)
@@ -213,17 +215,18 @@ def make_config(spec, fir_fold=0):
     cfg.has_edm_data_level = int(data_level is not None)
     cfg.edm_data_level_db = float(data_level) if data_level is not None else 0.0
     cfg.fir_fold = int(fir_fold)
+    cfg.no_split_copy = 0 if split_copy else 1
     return cfg
 
 
-def pack_weights(spec, state_dict, fir_fold=0):
+def pack_weights(spec, state_dict, fir_fold=0, split_copy=True):
     """Fold + lay out a reference-keyed state dict into the device blob (host side, no GPU needed).
     Returns (torch.FloatTensor blob [CPU], plan_json str)."""
     import numpy as np
     import torch
 
     L = load()
-    cfg = make_config(spec, fir_fold)
+    cfg = make_config(spec, fir_fold, split_copy)
     packer = c_void_p()
     check(L.ou_packer_create(byref(cfg), byref(packer)))
     try:
@@ -241,9 +244,9 @@ def pack_weights(spec, state_dict, fir_fold=0):
     return blob, plan
 
 
-def packed_bytes(spec, fir_fold=0):
+def packed_bytes(spec, fir_fold=0, split_copy=True):
     L = load()
-    cfg = make_config(spec, fir_fold)
+    cfg = make_config(spec, fir_fold, split_copy)
     n = c_size_t()
     check(L.ou_packed_bytes(byref(cfg), byref(n)))
     return n.value

@@ -10,6 +10,9 @@
 
 namespace ou {
 
+static thread_local int g_no_split = 0;  // ou_config.no_split_copy of the model being built (build_model sets it)
+
+
 namespace {
 
 struct Alloc {
@@ -47,7 +50,7 @@ std::string finish_conv(ConvL& L, Alloc& a) {
     L.wd_off = a.take((size_t)L.Cin * L.Mp * L.KWP);
     L.wu_off = a.take((size_t)L.Cin * L.Mp * L.KWP);
     // the bf16-split copy (conv_split_kernel: 64-row tiles -- the 48-channel level of UNIVERSE++ 24 kHz stays on the fp32 kernels)
-    if (L.M % 64 == 0) { L.ws_on = 1; L.ws_off = a.take(split_floats(L.Cin, L.KW, L.Mp)); }
+    if (L.M % 64 == 0 && !g_no_split) { L.ws_on = 1; L.ws_off = a.take(split_floats(L.Cin, L.KW, L.Mp)); }
 #ifdef OU_EXPERIMENTS
     // ... and of the Winograd-domain weights, for the layers conv_splitw_kernel takes (k3, rows a multiple of 128): the
     // experiments build only -- the kernel measured slower (ou_conv_split.hip), the default blob does not carry its copy
@@ -155,6 +158,7 @@ std::string build_model(const ou_config& cfg, Model& m) {
   if (cfg.abi_version != OU_ABI_VERSION) return "ou_config.abi_version mismatch";
   if (cfg.fir_fold < 0 || cfg.fir_fold > 3) return "ou_config.fir_fold must be 0 .. 3";
   g_fir_fold = cfg.fir_fold;
+  g_no_split = cfg.no_split_copy != 0;
   const ou_net_config& s = cfg.score;
   const ou_net_config& c = cfg.cond;
   if (s.n_rates < 1 || s.n_rates > OU_MAX_RATES) return "bad n_rates";

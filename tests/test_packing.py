@@ -216,3 +216,19 @@ def test_library_reads_no_environment_variable(built_lib):
             if f.endswith(".py"):
                 seen |= set(re.findall(r"[\"'](OU_[A-Z_]+)[\"']", open(os.path.join(root, f)).read()))
     assert seen <= {"OU_LIBRARY", "OU_UNSAFE_PICKLE", "OU_", "OU_CHAIN_TS"}, seen
+
+
+def test_blob_without_the_split_copy_is_a_quarter_smaller(built_lib):
+    """ou_config.no_split_copy: handles that never run a batch of 8 or more utterances per call leave the bf16-split copy out of
+    the blob (what the RCCL broadcast moves and every rank keeps resident); every other slot keeps its value."""
+    spec = get_spec("PP16m")
+    sd = S.synthetic_state_dict(spec, seed=2)
+    full, plan_f = _lib.pack_weights(spec, sd)
+    lean, plan_l = _lib.pack_weights(spec, sd, split_copy=False)
+    assert full.numel() * 4 == _lib.packed_bytes(spec) and lean.numel() * 4 == _lib.packed_bytes(spec, split_copy=False)
+    assert 0.70 < lean.numel() / full.numel() < 0.80
+    cf, cl = plan_convs(plan_f), plan_convs(plan_l)
+    assert any(c["ws_on"] for c in cf.values()) and not any(c["ws_on"] for c in cl.values())
+    for nm, c in cf.items():
+        n = c["Cin"] * c["KW"] * c["Mp"]
+        assert torch.equal(full[c["w_off"]: c["w_off"] + n], lean[cl[nm]["w_off"]: cl[nm]["w_off"] + n]), nm
