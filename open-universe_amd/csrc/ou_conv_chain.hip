@@ -30,6 +30,7 @@ namespace ou {
 // Addressing: every global access is a buffer instruction -- the per-lane byte offset is computed once, the row
 // (channel) part of the address is a wave-uniform SGPR offset -- so the prologue / epilogues spend their VALU
 // cycles on the arithmetic only (they are a third of a block's time at C = 32).
+#ifdef OU_EXPERIMENTS  // round 3's fused body (37-40 spilled SGPRs, no default rule selects it since conv_chainw_kernel: round 6 retires it to `make EXPERIMENTS=1`)
 template <int MT, int NWV>
 __global__ __launch_bounds__(64 * NWV) void conv_chain_kernel(ChainArgs p, int TN, int ntiles) {
   constexpr int C = 32 * MT, NTN = NWV / MT, NC = 32 * NTN, XS = NC + 4, NTH = 64 * NWV;
@@ -267,6 +268,8 @@ __global__ __launch_bounds__(64 * NWV) void conv_chain_kernel(ChainArgs p, int T
   }
   if (p.prof && tid == 0) atomicMin(p.prof + 16 + (blockIdx.x & 15), ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
+
+#endif  // OU_EXPERIMENTS
 
 // =========================================================================================================
 // conv_chainw_kernel: the fused ConvBlock body of the 32-channel level in MINIMAL-FILTERING form (round 5)
@@ -603,12 +606,17 @@ struct ChainVariant {
   int C, NC, NWV;
   void (*kern)(ChainArgs, int, int);
 };
+#ifdef OU_EXPERIMENTS
 static const ChainVariant kChainVariants[] = {
     {32, 128, 4, conv_chain_kernel<1, 4>},
     {32, 256, 8, conv_chain_kernel<1, 8>},
     {64, 128, 8, conv_chain_kernel<2, 8>},
 };
 constexpr int kNumChainVariants = sizeof(kChainVariants) / sizeof(kChainVariants[0]);
+#else  // the default library fuses with conv_chainw_kernel only (32 channels depth 3, 64 channels depth 2, T % 4 == 0)
+static const ChainVariant kChainVariants[1] = {{0, 0, 0, nullptr}};
+constexpr int kNumChainVariants = 0;
+#endif
 static size_t chain_smem_bytes(const ChainVariant& v) {
   return 4 * ((size_t)2 * v.C * (v.NC + 4) + 2 * 96 * v.C + 5 * v.C);
 }

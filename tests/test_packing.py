@@ -175,7 +175,8 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 def test_default_build_carries_no_experiment_kernels(built_lib):
     """`make` (what __graft_entry__.build() runs) leaves the kernels no default dispatch rule can select out of the library:
-    conv_block3_kernel (one launch per deep ConvBlock: measured slower end to end), round 1's gru_cluster_kernel and the
+    conv_block3_kernel (one launch per deep ConvBlock: measured slower end to end), round 1's gru_cluster_kernel, round 3's
+    conv_chain_kernel (superseded by conv_chainw_kernel), round 6's conv_splitw_kernel (measured slower) and the
     4-wave / 64x64 split-K configs of conv_mfma_kernel are in `make EXPERIMENTS=1` builds only.  The device code objects
     inside the .so name their kernels in clear text."""
     import os
@@ -185,7 +186,7 @@ def test_default_build_carries_no_experiment_kernels(built_lib):
     assert b"conv_direct2_kernel" in blob and b"gru_ring_kernel" in blob and b"conv_direct4_kernel" in blob
     if b"+experiments" in built_lib.ou_version():
         pytest.skip("an EXPERIMENTS build")
-    for name in (b"conv_block3_kernel", b"gru_cluster_kernel"):
+    for name in (b"conv_block3_kernel", b"gru_cluster_kernel", b"conv_chain_kernel", b"conv_splitw_kernel"):
         assert name not in blob, name
     # conv_mfma_kernel<TM, TN, WM, WN, WK, ...>: no instantiation with a 4-way split of the reduction (WK = 4)
     assert b"conv_mfma_kernelILi1ELi2ELi1ELi1ELi4E" not in blob and b"conv_mfma_kernelILi1ELi1ELi1ELi1ELi4E" not in blob
