@@ -404,7 +404,9 @@ struct Runner {
             L.Mp != Bk.c1.Mp)
           ca.depth = 0;
         ca.cv[s2].KW = L.KW; ca.cv[s2].CK = L.CK;
+        if (L.KWP) ca.cv[s2].wu = h->W;  // (a marker: the layer HAS the Winograd-domain copy -- what chain_cost's shape test asks)
       }
+      ca.wino = env.wino && env.conv_direct >= 5;
       return ca;
     };
     auto generic = [&](const ConvL& L) {

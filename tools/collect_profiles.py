@@ -4,7 +4,7 @@ import csv, json, os, shutil, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "final")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06_final"
 FAMS = {"direct2": ("conv_direct2_kernel", "conv_direct2w_kernel", "conv_direct4w_kernel"),
         "direct": ("conv_direct_kernel", "conv_direct_strided_kernel"),
         "direct4": ("conv_direct4_kernel",),
@@ -42,7 +42,7 @@ for n in sorted(os.listdir(src)):
 for n in sorted(os.listdir(src)):
     if n.startswith(("kstats_", "pmc_sq_", "gru_ts", "layers", "direct_ts", "direct_sweep", "ubench_", "tile_sweep", "stress_",
                      "xcc_migrate", "timings", "sharded_rate", "box_health", "d4_sweep", "d4_ts", "lanes_", "free_run", "d2_sweep", "chainw_ts",
-                     "hwq", "env_knobs", "split_", "cumask")):
+                     "hwq", "env_knobs", "split_", "cumask", "summary")):
         shutil.copy(os.path.join(src, n), os.path.join(dst, f"{tag}_{n}"))
 
 KB = 1024.0
