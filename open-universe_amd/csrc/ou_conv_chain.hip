@@ -1012,6 +1012,10 @@ struct RateUpCfg {
 static const RateUpCfg kRateUpCfgs[] = {
     {2, 64, 64, rate_up_kernel<2, 2, 2, 32>, 256, 64},  // PP16 / OR16: 64 -> 32 channels x 2 phases, T/2 -> T
     {2, 96, 96, rate_up_kernel<2, 3, 1, 48>, 192, 32},  // PP24: 96 -> 48 x 2
+    // (round 6, review item 6: {4, 256, 128, rate_up_kernel<4, 8, 1, 64>, 512, 32} -- the level below, 128 -> 64 channels x 4
+    //  phases with its 9-tap FIR and the residual in one launch instead of conv_direct4_kernel 14.5 us + FIR pass 6.5 us --
+    //  was built, parity-green, and measured: 8 launches fewer per enhance, the enhance 0.03-0.09 ms SLOWER at batch 1 and 1-2 %
+    //  slower at batch 8 (profiles/r06_rate_up_deeper_level_ab.txt): the fused block's phases run back to back, as on the down path)
 };
 bool rate_up_supported(const ConvArgs& a) {
   if (a.up < 2 || a.stride != 1 || a.KW != 1 || a.pad != 0 || a.add || a.film || a.in_scale || a.Nq != a.Tin ||
