@@ -14,12 +14,14 @@ Extensions (not in the reference, whose loop is serial on one device, one file p
   generator state left by files 0..k-1, a sharded run cannot reproduce the serial noise; with `--per-file-seed` (forced
   when N > 1) file k uses its own generator seeded with `seed + k` (k = index in the sorted file list), which makes the
   result of a file independent of how the list was sharded;
-* `--batch-size K`: up to K consecutive files (in processing order) of the same sample rate -- of ANY lengths -- share
+* `--batch-size K`: up to K files of the same sample rate -- of ANY lengths -- share
   one `enhance` call (`Universe.enhance_many`; the channels of a file stay rows of the batch).  Every row keeps the
   geometry of the call on that file alone (own padding, normalisation, conv zero padding, GRU length: exact batching,
   ou_enhance_var), and the noise is drawn file by file in processing order with the shapes of the serial loop, so the
   shared generator advances exactly as in the reference and every file gets the noise -- and, to fp32 round-off, the
-  result -- it would get alone.  `--pad-batch` selects the reference's own batch semantics instead: right-zero-padded to
+  result -- it would get alone.  Files are read `--batch-window` ahead (default 4 K) and grouped by length inside the window
+  (a call costs what its longest row costs); every file's generator starts from the state the shared generator has in front
+  of that file in processing order, so the grouping does not change anybody's noise.  `--pad-batch` selects the reference's own batch semantics instead: right-zero-padded to
   the longest like `max_collator` (datasets/datamodule.py:24-42; no mask: the padding takes part in the normalisation,
   as in a reference batch).
 """
@@ -84,6 +86,10 @@ def build_parser():
     parser.add_argument("--batch-size", type=int, default=1,
                         help="Enhance up to this many consecutive files of equal sample rate (any lengths) in one call; "
                              "every file gets the result it would get alone")
+    parser.add_argument("--batch-window", type=int, default=0,
+                        help="With --batch-size: read this many files ahead and group them by length (longest first) -- a call "
+                             "costs what its longest file costs.  Every file still gets the noise of the file-by-file loop "
+                             "(its generator state is taken in processing order).  Default: 4 x batch-size; 1: files as they come")
     parser.add_argument("--in-flight", type=int, default=1,
                         help="Keep this many enhance calls in flight side by side on the device (one stream and workspace "
                              "each, 1..8): same result as the file-by-file loop, bit for bit, at a multiple of its "
@@ -231,45 +237,63 @@ def main(argv=None, model=None):
             done.append(output_path)
         return done
 
-    # --batch-size: files are read in processing order and held only until their group is complete (consecutive files of
-    # equal rate, at most batch_size of them)
+    # --batch-size: files are read in processing order into a window (one sample rate, --batch-window files), sorted by length
+    # inside it and enhanced batch_size at a time
     if any(enhance_kwargs.get(key) is not None for key in ("ensemble", "target")):
         raise ValueError("--batch-size cannot be combined with --ensemble (one call per file needed)")
     kw = {key: v for key, v in enhance_kwargs.items() if key not in ("rng", "ensemble", "ensemble_stat", "target",
                                                                     "fake_score_snr")}
 
-    def flush(group):
-        """group: list of (k, path, audio, fs) with one fs"""
-        if not group:
+    window_size = max(1, args.batch_window if args.batch_window > 0 else 4 * args.batch_size)
+    # Sorting a window by length needs a generator per file that starts where the serial loop's shared generator would stand
+    # in front of that file: with per-file seeds by construction, with the shared generator by taking its state file by file
+    # in processing order and advancing it by the file's draws (Universe.advance_generator_like_enhance).
+    can_sort = per_file_seed or hasattr(model, "advance_generator_like_enhance")
+    if not can_sort:
+        window_size = min(window_size, args.batch_size)
+
+    def flush(window):
+        """window: list of (k, path, audio, fs) with one fs, in processing order"""
+        if not window:
             return
-        fs = group[0][3]
+        fs = window[0][3]
         with torch.no_grad():
-            sigs = [resample(a.to(device), fs, model.fs) for _, _, a, _ in group]
-            if per_file_seed:
-                rngs = []
-                for k, _, _, _ in group:
+            items = []
+            for k, path, a, _ in window:
+                sig = resample(a.to(device), fs, model.fs)
+                if per_file_seed:
                     g = torch.Generator(device=device)
                     g.manual_seed(args.seed + k)
-                    rngs.append(g)
-            else:
-                rngs = rng  # one shared generator, drawn from file by file in processing order
-            enhs = model.enhance_many(sigs, rngs, pad_batch=args.pad_batch, **kw)
-            enhs = [resample(e, model.fs, fs) for e in enhs]
-        for (k, path, _, _), enh in zip(group, enhs):
+                elif can_sort:
+                    g = torch.Generator(device=device)
+                    g.set_state(rng.get_state())
+                    model.advance_generator_like_enhance(rng, sig.shape[0] if sig.ndim == 2 else 1, sig.shape[-1],
+                                                         n_steps=kw.get("n_steps"), warm_start=kw.get("warm_start"),
+                                                         use_aux_signal=bool(kw.get("use_aux_signal")))
+                else:
+                    g = None  # (a model without the hook: consecutive files, the shared generator drawn from in order)
+                items.append((k, path, sig, g))
+            order = sorted(range(len(items)), key=lambda i: (-items[i][2].shape[-1], i)) if can_sort else list(range(len(items)))
+            results = {}
+            for b0 in range(0, len(order), args.batch_size):
+                grp = [items[i] for i in order[b0:b0 + args.batch_size]]
+                rngs = [g for _, _, _, g in grp] if can_sort else rng
+                enhs = model.enhance_many([sig for _, _, sig, _ in grp], rngs, pad_batch=args.pad_batch, **kw)
+                for (k, _, _, _), e in zip(grp, enhs):
+                    results[k] = resample(e, model.fs, fs)
+        for k, path, _, _ in window:  # written in processing order
             output_path = out_path(path)
-            save(output_path, enh.cpu(), fs)
+            save(output_path, results[k].cpu(), fs)
             done.append(output_path)
 
-    group = []
+    window = []
     for k, path in todo:
         audio, fs = load(path)
-        if group:
-            same = fs == group[0][3]
-            if not same or len(group) >= args.batch_size:
-                flush(group)
-                group = []
-        group.append((k, path, audio, fs))
-    flush(group)
+        if window and (fs != window[0][3] or len(window) >= window_size):
+            flush(window)
+            window = []
+        window.append((k, path, audio, fs))
+    flush(window)
     return done
 
 

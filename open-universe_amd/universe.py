@@ -702,6 +702,18 @@ class Universe:
             res.append(o[0] if nd == 1 else o)
         return res
 
+    def advance_generator_like_enhance(self, rng, channels, length, n_steps=None, warm_start=None, use_aux_signal=False):
+        """Advance `rng` by exactly the draws `enhance` makes for a (channels, length) input -- x0, then one z per noisy step
+        (universe.py:326,330,338), each of shape (channels, 1, length + pad) -- without running anything.  For callers that
+        re-order work but owe every input the noise of the serial loop: take `rng.get_state()` in front of an input, call this,
+        and hand a generator restored to that state to the call that really processes the input (the CLI's length-sorted
+        window, bin/enhance.py)."""
+        n_steps = self.diff_kwargs.n_steps if n_steps is None else int(n_steps)
+        n_noise = 0 if use_aux_signal else n_steps - (0 if warm_start is None else int(warm_start))
+        T = int(length) + (self.tot_ds - int(length) % self.tot_ds)
+        for _ in range(n_noise):
+            torch.randn((int(channels), 1, T), dtype=torch.float32, device=self.device, generator=rng)
+
     # ---- hipGraph replay of the hot path ------------------------------------------------------------------------
     def graphed_enhance(self, batch, length, n_steps=None, epsilon=None, keep_rms=False, serial=True):
         """-> callable `run(mix, rng=None)` equivalent to `enhance(mix, n_steps, epsilon, rng=rng, keep_rms=keep_rms)`

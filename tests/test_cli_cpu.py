@@ -176,3 +176,51 @@ def test_cli_groups_consecutive_files_of_equal_rate_any_length():
     assert [[k for k, _ in grp] for grp in g] == [[0, 1], [2, 3], [4, 5]]
     g = cli.group_files(todo, infos, 4, True)
     assert [[k for k, _ in grp] for grp in g] == [[0, 1, 2, 3], [4, 5]]
+
+
+class _NoisyFake(_FakeModel):
+    """enhance(x) = x + noise from the generator it is handed, one draw of the input's shape: a wrong generator state, a
+    wrong grouping or a wrong order changes the output."""
+    tot_ds = 1
+
+    def __init__(self):
+        super().__init__()
+        self.batches = []
+
+    def enhance(self, mix, n_steps: int = None, epsilon: float = None, rng: torch.Generator = None,
+                keep_rms: bool = False) -> torch.Tensor:
+        return mix + torch.randn(mix.shape, generator=rng)
+
+    def enhance_many(self, sigs, rngs, pad_batch=False, **kw):
+        self.batches.append([int(s.shape[-1]) for s in sigs])
+        if not isinstance(rngs, (list, tuple)):
+            rngs = [rngs] * len(sigs)
+        return [s + torch.randn(s.shape, generator=g) for s, g in zip(sigs, rngs)]
+
+    def advance_generator_like_enhance(self, rng, channels, length, **kw):
+        torch.randn((channels, length), generator=rng)
+
+
+def test_cli_length_sorted_window_keeps_the_serial_noise(tmp_path):
+    """--batch-size with the read-ahead window: files are grouped by length inside the window (a call costs what its longest
+    row costs) -- and every file still gets the noise the file-by-file loop would give it from the ONE shared generator: its
+    generator starts from the state taken in front of it in processing order.  Outputs bit-equal to the serial run."""
+    src = tmp_path / "in"
+    src.mkdir()
+    lens = [900, 200, 800, 300, 700, 100, 600, 250, 150]
+    for i, n in enumerate(lens):
+        A.save(src / f"f{i}.wav", 0.001 * torch.randn(2 if i == 2 else 1, n, generator=torch.Generator().manual_seed(i)), 16000)
+    serial = _NoisyFake()
+    cli.main([str(src), str(tmp_path / "o1"), "--seed", "11"], model=serial)
+    batched = _NoisyFake()
+    cli.main([str(src), str(tmp_path / "o2"), "--seed", "11", "--batch-size", "2", "--batch-window", "6"], model=batched)
+    for i in range(len(lens)):
+        a, _ = A.load(tmp_path / "o1" / f"f{i}.wav")
+        b, _ = A.load(tmp_path / "o2" / f"f{i}.wav")
+        assert torch.equal(a, b), i
+    # window 1: files 0..5 sorted by length -> (900, 800), (700, 300), (200, 100); window 2: (600, 250), (150)
+    assert batched.batches == [[900, 800], [700, 300], [200, 100], [600, 250], [150]]
+    # per-file seeds: no state juggling needed, same grouping
+    pf = _NoisyFake()
+    cli.main([str(src), str(tmp_path / "o3"), "--seed", "11", "--batch-size", "2", "--batch-window", "6", "--per-file-seed"], model=pf)
+    assert pf.batches == batched.batches
