@@ -9,6 +9,11 @@ old = json.load(open(path)) if os.path.exists(path) else {}
 keep_min = "--min" in sys.argv  # only ever lower a gate to the new observation (several kernel variants share a name)
 gates = dict(old)
 for k, v in obs.items():
+    if k.startswith("fullstress."):
+        # gated inside its test against the REFERENCE'S OWN self-agreement on those weights (fp32 vs fp64 - 8 dB where that is
+        # below 68 dB): a 60 dB floor here would hold the HIP path to more than the reference manages against itself
+        gates.pop(k, None)
+        continue
     g = float(min(120, max(60, math.floor(v - 15))))
     gates[k] = min(g, old[k]) if (keep_min and k in old) else g
 json.dump(gates, open(path, "w"), indent=1, sort_keys=True)
