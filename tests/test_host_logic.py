@@ -212,3 +212,64 @@ def test_hub_id_is_split_and_both_files_are_fetched(tmp_path, monkeypatch, spec_
     monkeypatch.setattr(huggingface_hub, "hf_hub_download", down)
     with pytest.raises(OSError):  # the reference prints a hint and re-raises (model_loader.py:103-107)
         ML._resolve("nobody/nothing:rev", None)
+
+
+def test_enhance_many_assembles_a_ragged_batch_like_the_serial_loop():
+    """Host side of exact batching (Universe.enhance_many without pad_batch), no GPU: the rows, their lengths, the placement of
+    every entry's noise -- drawn entry by entry with the shapes of the call on that entry alone, (C_i, 1, L_i + pad_i), from ONE
+    shared generator in the serial loop's order -- and the cropping of the outputs."""
+    import torch
+
+    from open_universe_amd.universe import Universe
+
+    m = object.__new__(Universe)
+    m.tot_ds = 10
+    m.device = torch.device("cpu")
+
+    class KW:
+        n_steps, epsilon = 3, 1.3
+
+    m.diff_kwargs = KW()
+    seen = {}
+
+    def fake_enhance(mix, n_steps, epsilon, target, fake_score_snr, rng, use_aux, keep_rms, ensemble, stat, warm, noise, t_raw=None):
+        seen.update(mix=mix.clone(), noise=noise.clone(), t_raw=list(t_raw), n_steps=n_steps)
+        return mix * 2.0
+
+    m._enhance = fake_enhance
+    m._prep = lambda x: x.to(torch.float32).contiguous()
+    sigs = [torch.arange(1, 8, dtype=torch.float32), torch.ones(2, 23), torch.full((10,), 3.0)]  # lengths 7, 23 (2 channels), 10
+    g = torch.Generator().manual_seed(5)
+    outs = Universe.enhance_many(m, sigs, g)
+    assert seen["t_raw"] == [7, 23, 23, 10] and seen["n_steps"] == 3
+    assert seen["mix"].shape == (4, 1, 23) and seen["noise"].shape == (3, 4, 1, 30)  # T = 23 + 7
+    assert torch.equal(seen["mix"][0, 0, :7], sigs[0]) and not seen["mix"][0, 0, 7:].any()
+    # the serial loop's draws from the same generator: entry by entry, step by step, each with its own padded length
+    ref = torch.Generator().manual_seed(5)
+    exp = torch.zeros(3, 4, 1, 30)
+    r = 0
+    for s in sigs:
+        C, L = (s.shape[0], s.shape[1]) if s.ndim == 2 else (1, s.shape[0])
+        Ti = L + (10 - L % 10)
+        for k in range(3):
+            exp[k, r:r + C, :, :Ti] = torch.randn((C, 1, Ti), generator=ref)
+        r += C
+    assert torch.equal(seen["noise"], exp)
+    assert torch.equal(g.get_state(), ref.get_state())  # the shared generator stands where the serial loop leaves it
+    assert not seen["noise"][:, 0, :, 10:].any() and not seen["noise"][:, 3, :, 20:].any()  # zeros behind a row's own pad
+    assert [tuple(o.shape) for o in outs] == [(7,), (2, 23), (10,)]
+    assert torch.equal(outs[0], 2 * sigs[0]) and torch.equal(outs[1], 2 * sigs[1])
+    # equal lengths take the plain path (no t_raw); an empty entry is refused
+    seen.clear()
+
+    def fake_plain(mix, n_steps, epsilon, target, fake_score_snr, rng, use_aux, keep_rms, ensemble, stat, warm, noise, t_raw=None):
+        seen.update(t_raw=t_raw, B=mix.shape[0])
+        return mix
+
+    m._enhance = fake_plain
+    Universe.enhance_many(m, [torch.ones(9), torch.zeros(9)], torch.Generator().manual_seed(1))
+    assert seen == {"t_raw": None, "B": 2}
+    import pytest
+
+    with pytest.raises(ValueError):
+        Universe.enhance_many(m, [torch.ones(9), torch.zeros(0)], None)
