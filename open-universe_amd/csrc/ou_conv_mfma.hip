@@ -491,65 +491,91 @@ hipError_t init_conv_kernels() {
 // zeroes them behind a row's end -- the runner does not fuse ragged batches) keeps ConvArgs::lens in its epilogue.
 bool conv_masks_rows(int cfg) { return cfg >= 0 && !(cfg >= 100 && cfg < 200); }
 
+// ---- the kernel families of a Conv1d launch, in the order they are asked ------------------------------------------------------
+// Each `try_*` answers for ONE family: hipSuccess / a launch error = it took the layer; hipErrorInvalidConfiguration = not a
+// layer for this family (ask the next one); hipErrorNotSupported = the layer would be its, but the requested epilogue (fused
+// FIR, activating store) is not -- the caller's fallback.  `force_cfg` (ou_bench_conv, tests) names a variant code; a family
+// is asked only when the code lies in its range [lo, hi), and then its answer is final.
+namespace {
+// conv_split_kernel (8xx / 9xx): stride-1 k3 / k5 layers with enough work per launch to feed the BF16 matrix pipe.  Rule from
+// tools/ubench/split_conv.hip against the per-layer tables of the fp32 kernels and from A / B runs of the product (profiles/
+// r05_split_*, r05_late_*; re-derived by forcing in round 6, r06_ab_split_rule_*): rows a multiple of 256 (four waves stacked
+// along the rows, each weight fragment fetched once per block) and a whole device's worth of 256 x 128 output blocks, half a
+// device's worth for the k5 layers and on short rows (the 401-frame level, on the split-K fp32 kernels otherwise) -- PP16 /
+// OR16: the 256- and 512-channel levels from B = 16, the 256-channel k5 convs from B = 8.
+hipError_t try_split(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
+  if (!a.wsplit || a.split == 0) return hipErrorInvalidConfiguration;
+  const double tiles = (double)(a.M / 64) * ((a.Nq + 127) / 128) * a.B / 4.0;  // 256 x 128 blocks' worth of output
+  const bool rule = a.M >= 256 && a.M % 256 == 0 && tiles >= ((a.Nq < 1024 || a.KW == 5) ? 0.45 : 0.9) * num_cu;
+  if (!(a.split == 1 || a.force_cfg >= 800 || rule)) return hipErrorInvalidConfiguration;
+  return launch_conv_split(a, num_cu, stream, cfg_out);
+}
+// conv_direct3(w)(s)_kernel (2xx / 5xx): the no-split-K throughput kernels for launches with many columns
+hipError_t try_direct3(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
+  if (a.direct < 3) return hipErrorInvalidConfiguration;
+  return launch_conv_direct3(a, num_cu, stream, cfg_out);
+}
+// conv_direct4_kernel (3xx): 1x1 convs, phase GEMMs and k = s = r rate-change convs with too few columns for the family above.
+// It has no fused up-path FIR: a layer it would take runs as conv + FIR pass (the caller's fallback on hipErrorNotSupported)
+// unless d4_fir_unfused is off.
+hipError_t try_direct4(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
+  if (a.direct < 4) return hipErrorInvalidConfiguration;
+  if (a.fir) {
+    if (a.d4_fir_unfused && a.force_cfg < 0) {
+      ConvArgs probe = a;
+      probe.fir = nullptr; probe.fir_len = 0;
+      if (launch_conv_direct4(probe, num_cu, stream, nullptr, true) == hipSuccess) return hipErrorNotSupported;
+    }
+    return a.force_cfg >= 0 ? hipErrorNotSupported : hipErrorInvalidConfiguration;  // (forced onto a family without the FIR epilogue)
+  }
+  return launch_conv_direct4(a, num_cu, stream, cfg_out, false);
+}
+// conv_direct4w_kernel (6xx / 7xx): stride-1 k3 / k5 layers with few columns (the 401-frame levels at batch 1), minimal filtering
+hipError_t try_direct4w(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
+  if (a.direct < 5) return hipErrorInvalidConfiguration;
+  return launch_conv_direct4w(a, num_cu, stream, cfg_out);
+}
+// conv_direct_kernel / conv_direct2(w)_kernel / conv_direct_strided_kernel (1xx as a request; 50 .. 99 and 4xx as answers): the
+// split-K kernels of the deep levels.  Up to deep_factor blocks of 64 x 128 per CU (measured: PP16 B = 8 33.3 -> 32.3 ms, OR16
+// B = 16 63.4 -> 60.2 ms when the limit goes from 3 to 6-12; beyond that nothing moves); longer rows only for the wide-load
+// variant (a 64-channel k5 conv at T = 32 080 runs 19 vs 24 us on it).
+hipError_t try_direct(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
+  if (a.direct == 0) return hipErrorInvalidConfiguration;
+  const long wide = (long)((a.M + 63) / 64) * ((a.Nq + 127) / 128) * a.B;
+  const bool wide_ok = a.wd && a.direct >= 2 && a.stride == 1 && a.up == 1;
+  const bool deep = ((a.Nq <= 16384 || wide_ok) && wide < (long)a.deep_factor * num_cu) || a.force_cfg >= 100;
+  if (!deep) return hipErrorInvalidConfiguration;
+  return launch_conv_direct(a, num_cu, stream, cfg_out);
+}
+struct ConvFamily {
+  int lo, hi;          // force_cfg codes that name this family
+  bool final_if_forced;  // a forced request ends with this family's answer (the first-generation family falls through to the
+                         // LDS kernel even when forced: force_cfg 100 .. 199 also covers layers only that kernel takes)
+  hipError_t (*attempt)(const ConvArgs&, int, hipStream_t, int*);
+};
+const ConvFamily kConvFamilies[] = {
+    {800, 1100, true, try_split},
+    {200, 300, true, try_direct3},   // (and 500 .. 599: see forced_into)
+    {300, 500, true, try_direct4},
+    {600, 800, true, try_direct4w},
+    {100, 200, false, try_direct},
+};
+bool forced_into(const ConvFamily& f, int cfg) {
+  if (cfg >= f.lo && cfg < f.hi) return true;
+  return f.attempt == try_direct3 && cfg >= 500 && cfg < 600;
+}
+}  // namespace
+
 hipError_t launch_conv(const ConvArgs& a, int num_cu, hipStream_t stream, int* cfg_out) {
   if (a.Cin % a.CK || a.CK < 2 || (a.CK & (a.CK - 1)) || a.Mp % 64 || a.Nq <= 0) return hipErrorInvalidValue;
-  // Deep levels (what the 8-wave split-K configs below were built for): the register-direct kernels.  Wide levels
-  // (many blocks of 64 x 128 per CU without splitting K) stay on the LDS-tiled configs.
-  // Stride-1 k3 / k5 layers with enough work per launch to feed the BF16 matrix pipe: the bf16-split kernel (conv_split_kernel,
-  // six bf16 products per fp32 product).  Rule from tools/ubench/split_conv.hip against the per-layer tables of the fp32 kernels and
-  // from A / B runs of the product (profiles/r05_split_*, r05_late_*): rows a multiple of 256 (four waves stacked along the rows, each
-  // weight fragment fetched once per block) and a whole device's worth of 256 x 128 output blocks, half a device's worth for the k5
-  // layers and on short rows (the 401-frame level, on the split-K fp32 kernels otherwise) -- PP16 / OR16: the 256- and 512-channel
-  // levels from B = 16, the 256-channel k5 convs from B = 8 (24.2 -> 24.05 ms per call there; k3 at B = 8: level, stays).
-  if (a.wsplit && a.split != 0 && (a.force_cfg < 0 || (a.force_cfg >= 800 && a.force_cfg < 1100))) {
-    const double tiles = (double)(a.M / 64) * ((a.Nq + 127) / 128) * a.B / 4.0;  // 256 x 128 blocks' worth of output
-    const bool rule = a.M >= 256 && a.M % 256 == 0 && tiles >= ((a.Nq < 1024 || a.KW == 5) ? 0.45 : 0.9) * num_cu;
-    if (a.split == 1 || a.force_cfg >= 800 || rule) {
-      hipError_t e = launch_conv_split(a, num_cu, stream, cfg_out);
-      if (e != hipErrorInvalidConfiguration) return e;
-      if (a.force_cfg >= 800) return e;
-    }
-  }
-  const bool force_d3 = (a.force_cfg >= 200 && a.force_cfg < 300) || (a.force_cfg >= 500 && a.force_cfg < 600);
-  if (a.direct >= 3 && (a.force_cfg < 0 || force_d3)) {
-    hipError_t e = launch_conv_direct3(a, num_cu, stream, cfg_out);
+  // Deep levels and the throughput regime: the register-direct families, most specific first.  What none of them takes (wide
+  // levels at small batch, layers without a direct form) stays on the LDS-tiled configs below.
+  for (const ConvFamily& f : kConvFamilies) {
+    const bool forced = a.force_cfg >= 0 && forced_into(f, a.force_cfg);
+    if (a.force_cfg >= 0 && !forced) continue;
+    const hipError_t e = f.attempt(a, num_cu, stream, cfg_out);
     if (e != hipErrorInvalidConfiguration) return e;
-    if (a.force_cfg >= 200) return e;
-  }
-  // 1x1 convs, phase GEMMs and k = s = r rate-change convs with too few columns for the no-split-K kernel above: the
-  // wide-load split-K kernel (conv_direct4_kernel).  It has no fused up-path FIR: a layer it would take runs as conv + FIR
-  // pass (the caller's fallback on hipErrorNotSupported) unless a.d4_fir_unfused is off.
-  if (a.direct >= 4 && (a.force_cfg < 0 || (a.force_cfg >= 300 && a.force_cfg < 500))) {
-    if (a.fir) {
-      if (a.d4_fir_unfused && a.force_cfg < 0) {
-        ConvArgs probe = a;
-        probe.fir = nullptr; probe.fir_len = 0;
-        if (launch_conv_direct4(probe, num_cu, stream, nullptr, true) == hipSuccess) return hipErrorNotSupported;
-      }
-    } else {
-      hipError_t e = launch_conv_direct4(a, num_cu, stream, cfg_out, false);
-      if (e != hipErrorInvalidConfiguration) return e;
-      if (a.force_cfg >= 300) return e;
-    }
-  }
-  // stride-1 k3 / k5 layers with few columns (the 401-frame levels at batch 1): minimal filtering on 16 / 32-row tiles
-  if (a.direct >= 5 && (a.force_cfg < 0 || (a.force_cfg >= 600 && a.force_cfg < 800))) {
-    hipError_t e = launch_conv_direct4w(a, num_cu, stream, cfg_out);
-    if (e != hipErrorInvalidConfiguration) return e;
-    if (a.force_cfg >= 600) return e;
-  }
-  if (a.direct != 0 && (a.force_cfg < 0 || (a.force_cfg >= 100 && a.force_cfg < 200))) {
-    const long wide = (long)((a.M + 63) / 64) * ((a.Nq + 127) / 128) * a.B;
-    // (longer rows only for the wide-load variant: a 64-channel k5 conv at T = 32 080 runs 19 vs 24 us on it)
-    const bool wide_ok = a.wd && a.direct >= 2 && a.stride == 1 && a.up == 1;
-    // up to 8 blocks of 64 x 128 per CU (measured: PP16 B = 8 33.3 -> 32.3 ms, OR16 B = 16 63.4 -> 60.2 ms when the limit
-    // goes from 3 to 6-12; beyond that nothing moves: those layers are not direct-capable anyway)
-    const long deep_factor = a.deep_factor;
-    const bool deep = ((a.Nq <= 16384 || wide_ok) && wide < deep_factor * num_cu) || a.force_cfg >= 100;
-    if (deep) {
-      hipError_t e = launch_conv_direct(a, num_cu, stream, cfg_out);
-      if (e != hipErrorInvalidConfiguration) return e;
-    }
+    if (forced && f.final_if_forced) return e;
   }
   if (a.fir) return hipErrorNotSupported;  // only the direct kernel has the fused FIR epilogue
   int pick = -1;
