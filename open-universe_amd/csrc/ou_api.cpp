@@ -36,7 +36,7 @@ struct Options {
   int split = -1;              // ConvArgs::split
   int dbg_dec0_under_gru = 0;  // measurement only, INVALID results (see run_score); experiments library only
   int tile_prefetch = 1;
-  int trace = 0, no_overlap = 0, ts = 0, deep_factor = 8, mask_fused = 1, split_wino = 1;
+  int trace = 0, no_overlap = 0, ts = 0, deep_factor = 8, mask_fused = 1, split_wino = 1, d2_tile_rule = 1;
   double tile_min = -1.0;      // < 0: the launcher's default
   std::string chain_ts;        // ou_set_stamp_layer (tuning)
 };
@@ -142,6 +142,7 @@ const OptDesc kOptions[] = {
     {"block3", &Options::block3, nullptr, false, "1: the three body convs of a deep-level ConvBlock in one launch (experiments build only)"},
     {"xcd_map", &Options::xcd_map, nullptr, false, "block -> tile mapping of the LDS-tiled conv kernel (-1: launcher's choice)"},
     {"d2_map", &Options::d2_map, nullptr, false, "block -> tile mapping of the wide-load split-K kernels (-1: launcher's choice)"},
+    {"d2_tile_rule", &Options::d2_tile_rule, nullptr, false, "0: round 5's 64- vs 32-column rule of the wide-load split-K kernels (ignores that only 64-column tiles have minimal filtering)"},
     {"d2_wk", &Options::d2_wk, nullptr, false, "4 / 8: K slices of conv_direct2_kernel (0: launcher's rule)"},
     {"d4_fir", &Options::d4_fir, nullptr, false, "0: up convs with a fusable FIR stay on the first-generation fused kernel"},
     {"d4_short", &Options::d4_short, nullptr, false, "0: the 401-frame levels at batch 1 stay on the first-generation kernels"},
@@ -326,7 +327,7 @@ struct Runner {
     a.B = B; a.Cin = L.Cin; a.Tin = in.T; a.Cout = L.Cout; a.M = L.M; a.Mp = L.Mp; a.KW = L.KW;
     a.stride = L.stride; a.pad = L.pad; a.up = L.up; a.CK = L.CK; a.Nq = Nq; a.Tout = Tout;
     a.force_cfg = h->force_cfg; a.force_sc = h->force_sc;
-    a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct; a.d4_fir_unfused = env.d4_fir; a.d4_force = env.d4_force; a.d4_short = env.d4_short; a.deep_factor = env.deep_factor; a.d2_wk = env.d2_wk; a.wino = env.wino; a.d2_map = env.d2_map;
+    a.dbg = env.dbg; a.force_xcd_map = env.xcd_map; a.direct = env.conv_direct; a.d4_fir_unfused = env.d4_fir; a.d4_force = env.d4_force; a.d4_short = env.d4_short; a.deep_factor = env.deep_factor; a.d2_tile_rule = env.d2_tile_rule; a.d2_wk = env.d2_wk; a.wino = env.wino; a.d2_map = env.d2_map;
     a.tile_min = env.tile_min; a.tile_prefetch = env.tile_prefetch;
     a.tstamps = h->tstamps;
     // ragged batch: the kernel keeps "zero behind the row's own end" in its epilogue where its family can (conv_masks_rows)

@@ -1112,6 +1112,14 @@ hipError_t launch_conv_direct(const ConvArgs& a, int num_cu, hipStream_t stream,
   // 280 (first up conv) lose to 624 / 520 by 20 %.
   const long b64 = gm * ((a.Nq + 63) / 64) * a.B, b32 = gm * ((a.Nq + 31) / 32) * a.B;
   int tn = 2 * ((b64 + num_cu - 1) / num_cu) <= (b32 + num_cu - 1) / num_cu ? 2 : 1;
+  // Round 6: only the 64-column tiles have the minimal-filtering form (conv_direct2w_kernel: (KW + 1) / (2 KW) of the MFMAs), so a
+  // 64-column round costs 4/3 (k3) / 6/5 (k5) of a 32-column one there, not 2 -- the 512-channel k3 convs of the 401-frame level
+  // at batch 8 (896 blocks of 64 columns = 4 rounds against 1 664 of 32 = 7) ran 54 us on the plain 32-column kernel where the
+  // minimal-filtering form takes 40-41 (profiles/r06_d2_tile_rule_ab.txt).
+  if (a.d2_tile_rule && tn == 1 && a.wino && a.direct >= 5 && a.wu && !a.fir && a.stride == 1 && a.up == 1 && (a.KW == 3 || a.KW == 5)) {
+    const double c64 = 2.0 * (a.KW + 1) / (2.0 * a.KW) * (double)((b64 + num_cu - 1) / num_cu);
+    if (c64 <= (double)((b32 + num_cu - 1) / num_cu)) tn = 2;
+  }
   if (a.force_cfg == 105) tn = 2;
   if (a.force_cfg == 106) tn = 1;
   void (*kern)(ConvArgs) = nullptr;

@@ -57,6 +57,7 @@ struct ConvArgs {
   int d4_fir_unfused = 1;              // OU_D4_FIR=0: up convs with a fusable FIR stay on the first-generation fused kernel
   int d4_short = 1;                    // OU_D4_SHORT=0: the 401-frame levels at batch 1 stay on the first-generation kernels
   int d4_force = 0;                    // OU_D4_FORCE = 10 TM + log2(WK): that tile shape wherever a layer admits it (tests / tuning)
+  int d2_tile_rule = 1;                // option d2_tile_rule: 0 = round 5's tile-width rule of the wide-load split-K kernels (A / B)
   int deep_factor = 8;                 // option deep_factor: up to this many blocks of 64 x 128 per CU a layer is "deep" (split-K kernels)
   // Anti-alias FIR of the up path fused into the epilogue (direct kernel, up > 1, KW == 1 only; launch_conv returns
   // hipErrorNotSupported otherwise and the caller runs launch_fir after a plain launch):
