@@ -383,8 +383,8 @@ struct Runner {
   int plan_chain(const BlockL& Bk, int T) {
     h->fuse_mode = env.fuse; h->fuse_nc = env.fuse_nc;
     if (h->fuse_mode == 0) return 0;
-    // ragged batch: the fused body keeps conv1 / conv2 tiles in LDS, where nothing zeroes them behind a row's own end
-    if (ragged) return 0;
+    // (ragged batch: conv_chainw_kernel zeroes its LDS tiles and its output behind every row's own end -- ChainArgs::lens)
+    if (ragged && !env.mask_fused) return 0;  // (the separate-mask form has no place to mask inside a fused body)
     // Throughput regime: with >= ~2 wave tiles per SIMD the three convs run unfused on conv_direct3_kernel at 70-100 TFLOP/s
     // each, ahead of the fused body's ~75 (measured end to end: PP16 B = 4 19.2 -> 18.4 ms, OR16 B = 16 57.7 -> 55.5 ms, B = 8
     // even); below that the fused launch wins (B = 1: 24 us for all three convs).
@@ -408,6 +408,7 @@ struct Runner {
         if (L.KWP) ca.cv[s2].wu = h->W;  // (a marker: the layer HAS the Winograd-domain copy -- what chain_cost's shape test asks)
       }
       ca.wino = env.wino && env.conv_direct >= 5;
+      ca.lens = ragged ? lens_of(T) : nullptr;
       return ca;
     };
     auto generic = [&](const ConvL& L) {
@@ -512,6 +513,7 @@ struct Runner {
         }
         ca.force_nc = h->fuse_nc;
         ca.wino = env.wino && env.conv_direct >= 5;
+        ca.lens = lens_of(hu.T);
         if (!env.chain_ts.empty() && nm == env.chain_ts) ca.tstamps = (long long*)(base + cap - (16u << 20));
         int variant = -1;
         if (h->profile && h->prof_dev && h->prof_used < kProfSlots) {

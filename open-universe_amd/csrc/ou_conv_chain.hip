@@ -314,6 +314,9 @@ __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, i
   const int lhalf = lane >> 5, l31 = lane & 31;
   const int tile = blockIdx.x % ntiles, b = blockIdx.x / ntiles;
   const int T = p.T, Mp = p.Mp;
+  // ragged batch: every stage's tile is zero from the row's own end on (what 'same' padding is for a row alone); x, add and res
+  // are zero there already
+  const int rlen = ragged_len(p.lens, b), Tl = rlen < T ? rlen : T;
   if (p.prof && tid == 0) atomicMin(p.prof + (blockIdx.x & 15), (unsigned long long)__builtin_amdgcn_s_memrealtime());
   const int t0 = tile * TN;
   constexpr int KW0 = D3 ? 5 : 3, PAD0 = (KW0 - 1) / 2, R0 = D3 ? 2 : 1;  // halo still needed downstream of stage 0
@@ -402,13 +405,14 @@ __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, i
     const float* Ua = D3 ? (s == 0 ? Ua0 : (s == 1 ? U2 : U3)) : Ua0;
     constexpr int Rs = NS - 1 - s;                  // halo still needed downstream of this stage (k3 convs follow)
     const int t = t0 - Rs + pcol;                   // time of output u = pcol (even)
-    const bool in0 = t >= 0 && t < T, in1 = t + 1 >= 0 && t + 1 < T;
+    const bool in0 = t >= 0 && t < Tl, in1 = t + 1 >= 0 && t + 1 < Tl;   // live samples of this row
+    const bool on0 = t >= 0 && t < T, on1 = t + 1 >= 0 && t + 1 < T;     // samples of the tensor
     // epilogue operand (cond add of conv1 / residual of the last conv), requested before the channel loop
     f32x2 ev[16];
     const float* src = last ? p.res : (first3 ? p.add : nullptr);
     if (src) {
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(src + rowbase, plane);
-      const int vo = (in0 || in1) ? (lrow * T + t) * 4 : (int)0x80000000;  // (t even, T even: whole pairs inside or outside)
+      const int vo = (on0 || on1) ? (lrow * T + t) * 4 : (int)0x80000000;  // (t even, T even: whole pairs inside or outside)
 #pragma unroll
       for (int r = 0; r < 16; r++)
         ev[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, ((r & 3) + 8 * (r >> 2)) * Tb, 0));
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, i
       const float an = p.cv[s + 1].alpha;
       float* out_l = outb + lrow * XS + pcol;
       const __amdgpu_buffer_rsrc_t rc = make_rsrc((p.c1_out ? p.c1_out : p.y) + rowbase, plane);
-      const bool own0 = in0 && t >= t0 && t < t0 + TN, own1 = in1 && t + 1 >= t0 && t + 1 < t0 + TN;
+      const bool own0 = on0 && t >= t0 && t < t0 + TN, own1 = on1 && t + 1 >= t0 && t + 1 < t0 + TN;
       float v0[16], v1[16];
 #pragma unroll
       for (int r = 0; r < 16; r++) {
@@ -535,8 +539,8 @@ __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, i
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const int kr = (r & 3) + 8 * (r >> 2);
-            buf_store(v0[r], rc, vo0, kr * Tb);
-            buf_store(v1[r], rc, vo1, kr * Tb);
+            buf_store(in0 ? v0[r] : 0.f, rc, vo0, kr * Tb);
+            buf_store(in1 ? v1[r] : 0.f, rc, vo1, kr * Tb);
           }
         }
       }
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, i
       }
     } else {
       const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + rowbase, plane);
-      const bool st0 = in0 && pcol < TN, st1 = in1 && pcol + 1 < TN;
+      const bool st0 = on0 && pcol < TN, st1 = on1 && pcol + 1 < TN;
       // (pairs are whole: t, T and TN are even; a store past the signal or the tile goes to an out-of-range offset = dropped)
       const int vo = (st0 && st1) ? (lrow * T + t) * 4 : (int)0x80000000;
 #pragma unroll
@@ -559,6 +563,7 @@ __global__ __launch_bounds__(256) void conv_chainw_kernel(ChainArgs p, int TN, i
         const int kr = (r & 3) + 8 * (r >> 2);
         float v0 = o0[r] + bias_l[kr], v1 = o1[r] + bias_l[kr];
         if (p.res) { v0 = (v0 + ev[r].x) * p.res_scale; v1 = (v1 + ev[r].y) * p.res_scale; }
+        v0 = in0 ? v0 : 0.f; v1 = in1 ? v1 : 0.f;
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{v0, v1}), ry, vo, kr * Tb, 0);
       }
     }
@@ -657,6 +662,7 @@ double chain_cost(const ChainArgs& a, int num_cu, int* nc_out) {
     if (nc_out) *nc_out = kind == 1 ? 256 : 128;
     return (double)((blocks + num_cu - 1) / num_cu) * ((kind == 1 ? 224 : 256) * 64.0 / 0.7 + 12000.0);
   }
+  if (a.lens) return -1.0;  // (only conv_chainw_kernel zeroes its stages behind a row's own end)
   double best = -1.0;
   for (int i = 0; i < kNumChainVariants; i++) {
     const ChainVariant& v = kChainVariants[i];

@@ -220,6 +220,7 @@ struct ChainArgs {
   ChainConv cv[3];
   int force_nc = 0;            // tuning: 128 / 256 columns per tile (0: chosen by the launcher)
   int wino = 1;                // minimal-filtering form where there is one (32 channels, depth 3); OU_WINO / OU_CONV_DIRECT < 5: 0
+  const int* lens = nullptr;   // ragged batch: valid samples per row at this level (conv_chainw_kernel zeroes every stage behind them)
   unsigned long long* prof = nullptr;
   long long* tstamps = nullptr;  // tuning: per-wave phase cycle counts
 };

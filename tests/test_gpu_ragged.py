@@ -204,12 +204,14 @@ def test_masks_in_the_epilogues_equal_separate_mask_launches(name, B, secs, stee
     lens[-1] = (lens[-1] // spec.tot_ds) * spec.tot_ds  # one row with a whole extra block of padding
     sigs = _signals(spec, lens)
     noise = _noise_for(spec, lens, 2, 300)
+    steer.set(fuse=0)  # (small batches would run their 64-channel ConvBlock bodies fused with in-kernel masks: next test)
     rows, full = _run_ragged(model, spec, sigs, noise, 2)
     n_fused = sum(model.launch_stats())
     steer.set(mask_fused=0)
     rows0, full0 = _run_ragged(model, spec, sigs, noise, 2)
     n_sep = sum(model.launch_stats())
     steer.unset("mask_fused")
+    steer.unset("fuse")
     assert torch.equal(full, full0)
     assert n_fused < n_sep, (n_fused, n_sep)
     # and the invariant holds in the fused form too: a deep tensor of the last score pass is zero behind every row
@@ -218,3 +220,37 @@ def test_masks_in_the_epilogues_equal_separate_mask_launches(name, B, secs, stee
     for b, L in enumerate(lens):
         lb = (L + (spec.tot_ds - L % spec.tot_ds)) * t.shape[-1] // T
         assert not t[b, :, lb:].any() and t[b, :, :lb].abs().max() > 0
+
+
+@pytest.mark.parametrize("name,B", [("PP16", 2), ("PP16", 3), ("OR16", 2)])
+def test_small_ragged_batches_keep_their_fused_convblock_bodies(name, B, steer):
+    """Batches of two or three utterances run the 64-channel ConvBlock bodies on conv_chainw_kernel (conv2 + conv3 in one launch,
+    the intermediate tile in LDS).  With rows of different lengths the kernel zeroes BOTH stages behind every row's own end
+    (ChainArgs::lens) -- the intermediate tile never exists in memory, so no mask launch could do it.  Against the unfused walk
+    (option fuse = 0, masks in the conv epilogues): >= 100 dB on every row, fewer launches; against every utterance alone:
+    >= 100 dB; the block outputs are zero behind every row."""
+    model, spec, sd = get_model(name)
+    td = spec.tot_ds
+    lens = [int(spec.fs * 2.0) + 77, int(spec.fs * 1.2) // td * td, int(spec.fs * 1.7) + 1][:B]
+    sigs = _signals(spec, lens, seed=2200)
+    noise = _noise_for(spec, lens, 2, 910)
+    rows, full = _run_ragged(model, spec, sigs, noise, 2)
+    n_fused = sum(model.launch_stats())
+    T = max(L + (td - L % td) for L in lens)
+    for nm in ("score.enc1.v", "score.dec3.v"):
+        t = model.tensor(nm)
+        for b, L in enumerate(lens):
+            lb = (L + (td - L % td)) * t.shape[-1] // T
+            assert not t[b, :, lb:].any() and t[b, :, :lb].abs().max() > 0, (nm, b)
+    steer.set(fuse=0)
+    rows0, full0 = _run_ragged(model, spec, sigs, noise, 2)
+    n_unfused = sum(model.launch_stats())
+    steer.unset("fuse")
+    assert n_fused < n_unfused, (n_fused, n_unfused)
+    vs_unfused = [O.si_sdr(rows0[b], rows[b]) for b in range(B)]
+    vs_alone = []
+    for b in range(B):
+        vs_alone.append(O.si_sdr(_run_alone(model, sigs[b], noise[b], 2), rows[b]))
+        assert not full[b, 0, lens[b]:].any()
+    record(f"ragged_fused_bodies.{name}.B{B}.vs_unfused", worst(vs_unfused), 100)
+    record(f"ragged_fused_bodies.{name}.B{B}.vs_alone", worst(vs_alone), 100)
