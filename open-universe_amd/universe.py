@@ -72,6 +72,7 @@ class Universe:
         # no host sync) and examined at the start of the next call, in synchronize() and in _status(force=True).
         self.check_status = True
         self._status_host = torch.zeros(64, dtype=torch.int32).pin_memory()
+        self._status_np = self._status_host.numpy()  # (same pinned memory: read per call without building tensors)
         self._gru_recoveries_seen = {}   # workspace key -> recovery counter already acted upon
         self.gru_agent_scope = False     # True once the GRU publishes were switched to agent-scope stores for good
         self._status_event = None
@@ -94,6 +95,7 @@ class Universe:
         self._ws_cache = {}
         self._ws_need = {}
         self._cond_key = None
+        self._sigma_cache = {}
         self._lanes = (1, 0)
         for k, v in type(self).default_options.items():
             self.set_option(k, v)
@@ -298,13 +300,13 @@ class Universe:
 
     def _raise_on_status(self):
         self._status_event = None
-        v = int(self._status_host[0])
+        v = int(self._status_np[0])
         # word 20: waits the GRU clusters' safety net cut short by repeating a publish (0 on an idle device; a member that was
         # merely late -- starved by the kernels of other streams or lanes -- counts too); word 33: those among them where the
         # awaited granule was visible to a system-scope load / an atomic but not to the agent-scope load of the gather.  The
         # first time word 33 moves, the cheaper publish form has shown that it cannot be relied upon on this device / in this
         # process mix: switch to agent-scope (write-through) publishes for good -- +0.1 ms per GRU pass, no more recoveries.
-        rec, lost = int(self._status_host[20]), int(self._status_host[33])
+        rec, lost = int(self._status_np[20]), int(self._status_np[33])
         if lost and not self.gru_agent_scope and not v:
             import warnings
 
@@ -343,9 +345,10 @@ class Universe:
         if self._ws is None:
             return
         st = torch.cuda.current_stream(self.device)
-        self._status_ws = self._ws
-        with torch.cuda.stream(st):
-            self._status_host.copy_(self._ws[:256].view(torch.int32), non_blocking=True)
+        if self._status_ws is not self._ws:
+            self._status_ws = self._ws
+            self._status_words = self._ws[:256].view(torch.int32)
+        self._status_host.copy_(self._status_words, non_blocking=True)  # (on the current stream, behind the call's last kernel)
         ev = torch.cuda.Event()
         ev.record(st)
         self._status_event = ev
@@ -555,9 +558,6 @@ class Universe:
         if target is not None:
             x = self._enhance_with_oracle_score(mix, target, n_steps, epsilon, fake_score_snr, rng, pad)
         else:
-            # discretised schedule exactly as the reference builds it (universe.py:308-311)
-            time = torch.linspace(0, 1, n_steps).to(torch.float32).flip(dims=[0])
-            sigma = self.get_std_dev(time).to(torch.float32).contiguous()
             n_start = 0 if warm_start is None else int(warm_start)
             n_noise = 0 if use_aux_signal else n_steps - n_start
             if t_raw is not None:
@@ -568,13 +568,30 @@ class Universe:
                     raise ValueError(f"noise must be a tensor of shape {(n_noise, B, 1, T)}")
             elif noise is None:
                 # draw order of the reference: x0, then z_n for n = n_start .. N-2 (universe.py:326,330,338)
-                draws = [torch.randn((B, 1, T), dtype=torch.float32, device=self.device, generator=rng)
-                         for _ in range(n_noise)]
-                noise_t = torch.stack(draws, dim=0) if draws else None
+                # (each draw lands in its slice of the tensor the C ABI takes: the same n separate (B, 1, T) draws -- generator
+                # state and values are those of the reference's loop -- without a stack copy per draw behind them)
+                # (n_noise <= 0: warm_start >= n_steps -- the C ABI refuses the call below)
+                noise_t = torch.empty((n_noise, B, 1, T), dtype=torch.float32, device=self.device) if n_noise > 0 else None
+                for k in range(n_noise):
+                    torch.randn((B, 1, T), generator=rng, out=noise_t[k])
+            elif torch.is_tensor(noise):  # (all steps in one (n, B, 1, T) tensor: taken as it is)
+                noise_t = self._prep(noise[:n_noise]) if n_noise else None
+                if n_noise and tuple(noise_t.shape) != (n_noise, B, 1, T):
+                    raise ValueError(f"noise must be a tensor of shape {(n_noise, B, 1, T)}")
             else:
                 noise_t = torch.stack([self._prep(z) for z in noise[:n_noise]], dim=0) if n_noise else None
                 if n_noise and noise_t.shape != (n_noise, B, 1, T):
                     raise ValueError(f"noise must be {n_noise} tensors of shape {(B, 1, T)}")
+            # discretised schedule exactly as the reference builds it (universe.py:308-311) -- host arithmetic, done once per
+            # (n_steps, schedule) and AFTER the draws are in the queue: the device is idle while the host prepares a call
+            skey = (int(n_steps), float(self.diff_kwargs.sigma_min), float(self.diff_kwargs.sigma_max))
+            sigma = self._sigma_cache.get(skey)
+            if sigma is None:
+                time = torch.linspace(0, 1, n_steps).to(torch.float32).flip(dims=[0])
+                sigma = self.get_std_dev(time).to(torch.float32).contiguous()
+                if len(self._sigma_cache) > 64:
+                    self._sigma_cache.clear()
+                self._sigma_cache[skey] = sigma
             out = torch.empty(B, 1, mix_len, dtype=torch.float32, device=self.device)
             ws = self._workspace(B, T)
             flags = (_lib.OU_ENH_KEEP_RMS if keep_rms else 0) | (_lib.OU_ENH_USE_AUX_SIGNAL if use_aux_signal else 0)
@@ -663,6 +680,8 @@ class Universe:
         n_steps = self.diff_kwargs.n_steps if n_steps is None else int(n_steps)
         T = l_max + (self.tot_ds - l_max % self.tot_ds)
         n_start = 0 if warm_start is None else int(warm_start)
+        if n_start >= n_steps:
+            raise ValueError("warm_start must be < n_steps")
         n_noise = 0 if use_aux_signal else n_steps - n_start
         if not pad_batch and any(n != l_max for n in lens):
             # exact batching of different lengths: per-row geometry through the whole path
@@ -686,12 +705,15 @@ class Universe:
                 r0 += r.shape[0]
                 res.append(o[0] if nd == 1 else o)
             return res
-        per_entry = []
+        # entry by entry, step by step (the serial loop's draw order), every draw straight into its rows of the step's tensor
+        B = sum(r.shape[0] for r in rows)
+        noise = torch.empty((n_noise, B, 1, T), dtype=torch.float32, device=self.device)
+        r0 = 0
         for i, r in enumerate(rows):
             g = rngs[i] if isinstance(rngs, (list, tuple)) else rngs
-            per_entry.append([torch.randn((r.shape[0], 1, T), dtype=torch.float32, device=self.device, generator=g)
-                              for _ in range(n_noise)])
-        noise = [torch.cat([d[n] for d in per_entry], dim=0) for n in range(n_noise)]
+            for k in range(n_noise):
+                torch.randn((r.shape[0], 1, T), generator=g, out=noise[k, r0:r0 + r.shape[0]])
+            r0 += r.shape[0]
         mix = torch.cat([torch.nn.functional.pad(r, (0, l_max - r.shape[-1])) for r in rows], dim=0)[:, None, :]
         out = self._enhance(mix, n_steps, epsilon, None, None, None, use_aux_signal, keep_rms, None, "median",
                             warm_start, noise)
