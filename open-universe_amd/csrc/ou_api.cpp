@@ -1303,8 +1303,13 @@ int enhance_impl(ou_handle* h, const float* mix, float* out, const float* noise,
     r.rows_dev = P.rows;
   }
   const float level = (float)std::pow(10.0, (double)m.cfg.level_db / 20.0);
-  if (r.ragged) r.chk(launch_pad_normalize_var(mix, P.mixn.p, P.stats, P.rows, B, T_raw, T, level, st), "normalize");
-  else r.chk(launch_pad_normalize(mix, P.mixn.p, P.stats, B, T_raw, T, pad_left, level, st), "normalize");
+  // (launched behind the fork of the first score-encoder pass when there is one: the side stream's first kernel starts an event
+  // latency -- ~10 us -- after the fork, and this launch is what the device has to do in the meantime)
+  auto normalize = [&]() {
+    if (r.ragged) r.chk(launch_pad_normalize_var(mix, P.mixn.p, P.stats, P.rows, B, T_raw, T, level, st), "normalize");
+    else r.chk(launch_pad_normalize(mix, P.mixn.p, P.stats, B, T_raw, T, pad_left, level, st), "normalize");
+  };
+  bool normalized = false;
   const size_t nBT = (size_t)B * T;
   const int keep_rms = (flags & OU_ENH_KEEP_RMS) ? 1 : 0;
   const int peak = (flags & OU_ENH_NO_PEAK_GUARD) ? 0 : 1;
@@ -1344,6 +1349,8 @@ int enhance_impl(ou_handle* h, const float* mix, float* out, const float* noise,
       r.mask(P.x);
       const size_t save = r.off;
       r.fork(st, 2);
+      normalize();
+      normalized = true;
       r.st = h->aux[2];
       r.off = mark;
       E0 = run_score_enc(r, P, P.x.p, P.coef + n_start, 0, P.film + (size_t)n_start * m.film.rows, 0, T);
@@ -1353,6 +1360,7 @@ int enhance_impl(ou_handle* h, const float* mix, float* out, const float* noise,
       have_e0 = true;
     }
   }
+  if (!normalized) normalize();
   run_condition(r, P, P.mixn.p, T);
   r.gru_shared = false;
   if (!r.dry && r.ok() && r.off != mark) return fail(h, OU_EINVAL, "internal: workspace layout mismatch");
