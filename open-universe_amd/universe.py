@@ -692,8 +692,11 @@ class Universe:
                 g = rngs[i] if isinstance(rngs, (list, tuple)) else rngs
                 Ti = n + (self.tot_ds - n % self.tot_ds)
                 for k in range(n_noise):  # the draws of the call on this entry alone, in its order (x0 first)
-                    noise_t[k, r0:r0 + r.shape[0], :, :Ti] = torch.randn((r.shape[0], 1, Ti), dtype=torch.float32,
-                                                                         device=self.device, generator=g)
+                    dst = noise_t[k, r0:r0 + r.shape[0], :, :Ti]
+                    if dst.is_contiguous():  # (one row: the draw goes straight to its place)
+                        torch.randn((r.shape[0], 1, Ti), generator=g, out=dst)
+                    else:
+                        dst.copy_(torch.randn((r.shape[0], 1, Ti), dtype=torch.float32, device=self.device, generator=g))
                 t_raw += [n] * r.shape[0]
                 r0 += r.shape[0]
             mix = torch.cat([torch.nn.functional.pad(r, (0, l_max - r.shape[-1])) for r in rows], dim=0)[:, None, :]
