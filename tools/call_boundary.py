@@ -23,6 +23,7 @@ def run():
     model = UniverseGAN(spec, state_dict=S.synthetic_state_dict(spec, seed=0), device="cuda:0")
     mix = torch.randn(1, 1, 64000, device="cuda:0") * 0.1
     rng = torch.Generator(device="cuda:0").manual_seed(1)
+    model.check_status = "free" not in sys.argv  # (`run free`: no status wait per call)
     for _ in range(40):
         model.enhance(mix, rng=rng)
     torch.cuda.synchronize()
